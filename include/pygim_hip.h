@@ -1,0 +1,148 @@
+/*
+ * pygim_hip.h -- C ABI of the MI355X (gfx950) aggregation backend.
+ *
+ * This is the drop-in boundary for PyGim's backend_pim SpMM/SpMV path: every
+ * entry point replaces one function the reference reaches through
+ * torch.ops.pim_ops.* (registered in backend_pim/<variant>/pytorch_api.cpp).
+ * Plain pointers and sizes only; no torch types.  All functions return 0 on
+ * success and a non-zero pygim_status otherwise; pygim_last_error() then holds a
+ * message (thread-local).
+ *
+ * Pointer convention: every data pointer may be a HOST pointer or a DEVICE (HIP)
+ * pointer; the library asks the HIP runtime which.  Host data is staged through
+ * device buffers owned by the group (one-time for the sparse arrays -- the
+ * reference's copy_sparse_csr/copy_sparse_coo -- and per call for dense parts).
+ * Device data is used in place: the caller keeps it alive for the lifetime of
+ * the group, the same ownership rule the reference has for the raw data_ptr()s
+ * it stores (spmm_default/pytorch_api.cpp:230-232, 312-314).
+ *
+ * Threading: like the reference (one process-global `dpus` singleton,
+ * spmm_default/pytorch_api.cpp:152) the library holds one device context per
+ * process; calls are not re-entrant for the same group handle.
+ */
+#ifndef PYGIM_HIP_H
+#define PYGIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PYGIM_OK = 0,
+    PYGIM_ERR_INVALID = 1,   /* bad argument / shape / dtype / handle          */
+    PYGIM_ERR_NO_DEVICE = 2, /* no HIP device, or pygim_init not called         */
+    PYGIM_ERR_HIP = 3,       /* a HIP runtime call failed                       */
+    PYGIM_ERR_UNSORTED = 4   /* COO input not sorted by row (must be coalesced) */
+} pygim_status;
+
+/* val_dt of the reference (spmm_default/support/common.h:39-60), chosen at run
+ * time here instead of one library per type. */
+typedef enum {
+    PYGIM_INT8 = 0,
+    PYGIM_INT16 = 1,
+    PYGIM_INT32 = 2,
+    PYGIM_INT64 = 3,
+    PYGIM_FLT32 = 4,
+    PYGIM_DBL64 = 5
+} pygim_dtype;
+
+typedef enum { PYGIM_CSR = 0, PYGIM_COO = 1 } pygim_format;
+
+/* ---- device set-up --------------------------------------------------------
+ * pygim_init_ranks replaces dpu_init_ranks (spmm_default/pytorch_api.cpp:154,
+ * spmv_sparseP/pytorch_api.cpp:132; grande's int[]-returning form
+ * spmm_grande/pytorch_api.cpp:157-166).  nr_ranks = number of (sparse part x
+ * dense part) partitions the caller will create.  If units_per_rank is not NULL
+ * it receives nr_ranks entries: the number of feature windows the grande layout
+ * should cut per sparse part (grande's "DPUs per rank"; here one window per XCD).
+ * pygim_init_units replaces dpu_init_dpus (:158 / grande :168-177).
+ * pygim_release replaces dpu_release (:162): frees every live group.          */
+int pygim_init_ranks(int64_t nr_ranks, int64_t *units_per_rank);
+int pygim_init_units(int64_t nr_units, int64_t *units_per_rank, int64_t *nr_ranks_out);
+int pygim_release(void);
+int pygim_is_initialized(void);
+const char *pygim_last_error(void);
+/* name / CU count / bytes of HBM of the device in use */
+int pygim_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- sparse group: create / free -------------------------------------------
+ * Replaces spmm_csr_to_device_group / spmm_coo_to_device_group
+ * (spmm_default/pytorch_api.cpp:204-243, 286-329), grande's
+ * spmm_csr_to_device_group (spmm_grande/pytorch_api.cpp:221-264) and
+ * spmv_coo_to_device_group (spmv_sparseP/pytorch_api.cpp:184-228).
+ *
+ *  n_parts          sparse column blocks of A (backend_pim/spmm.py:127-136);
+ *                   block i is nrows[i] x ncols[i] with LOCAL column ids.
+ *  idx0[i]          CSR: rowptr, nrows[i]+1 int32;  COO: row index, nnz[i] int32,
+ *                   sorted by (row, col) as torch's coalesce() leaves it.
+ *  colind[i]        nnz[i] int32.
+ *  values[i]        nnz[i] elements of `dtype`; values == NULL or values[i] ==
+ *                   NULL means all-ones (backend_pim/spmm.py:36-37, 48-49).
+ *  n_dense[i]       number of dense (feature) parts paired with sparse part i.
+ *                   Default/spmv layout: the same list for every part -- pass the
+ *                   count in n_dense[0..n_parts) and the widths once per part.
+ *  dense_cols       concatenated widths, sum_i n_dense[i] entries; for each part
+ *                   they must add up to h_size.
+ *  out_handle       opaque handle (the reference returns its csr_info_group*
+ *                   as an int64, pytorch_api.cpp:240).
+ */
+int pygim_group_create(int format, int dtype, int n_parts,
+                       const int32_t *const *idx0, const int32_t *const *colind,
+                       const void *const *values, const int64_t *nrows, const int64_t *ncols,
+                       const int64_t *nnz, const int64_t *n_dense, const int64_t *dense_cols,
+                       int64_t h_size, int64_t *out_handle);
+/* Replaces spmm_free_group (spmm_default/pytorch_api.cpp:198-201). */
+int pygim_group_free(int64_t handle);
+
+/* ---- run -----------------------------------------------------------------
+ * pygim_spmm_run_group replaces spmm_csr_run_group / spmm_coo_run_group
+ * (spmm_default/pytorch_api.cpp:248-280, 332-367): B_parts[j] is a row-major
+ * [total_cols, dense_cols[j]] array holding feature block j of X for ALL sparse
+ * parts (sparse part i reads the rows that start at the sum of the previous
+ * parts' ncols, spmm_mul_csr.c:356-363); out is row-major [nrows[0], h_size] and
+ * is fully overwritten (the reference returns a fresh torch::zeros + merge).
+ *
+ * pygim_grande_run_group replaces grande's spmm_csr_run_group
+ * (spmm_grande/pytorch_api.cpp:269-321): B_windows holds, part after part, one
+ * window per dense part of that sparse part, each row-major
+ * [ncols[i], window_ld[k]] of which the first dense_cols[k] columns are used
+ * (backend_pim/grande.py:12-23 pads windows to 8 bytes).
+ *
+ * pygim_spmv_run_group replaces spmv_coo_run_group
+ * (spmv_sparseP/pytorch_api.cpp:231-266): B_vectors[j] is vector j ([ncols,1]);
+ * out is [nrows[0], n_dense] -- one SpMV result per column.
+ *
+ * stream: a hipStream_t (NULL = the default stream).  With device pointers the
+ * call only enqueues work; with host pointers it returns after the result has
+ * been copied back.                                                           */
+int pygim_spmm_run_group(int64_t handle, const void *const *B_parts, void *out, void *stream);
+int pygim_grande_run_group(int64_t handle, const void *const *B_windows, const int64_t *window_ld,
+                           void *out, void *stream);
+int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out, void *stream);
+
+/* One block product on resident data, the building brick of the three calls
+ * above and of the multi-GPU layer: C[0:nrows, c_col0 : c_col0+width] (+)=
+ * A_part . X[:, 0:width] with row strides ldx / ldc in elements.  X and C must
+ * be device pointers.                                                         */
+int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc,
+                    int64_t width, int accumulate, void *stream);
+
+/* ---- introspection -----------------------------------------------------------
+ * Milliseconds of the last host-pointer run, in the reference's Timer buckets
+ * (support/timer.h; printed as [DATA] lines, spmm_mul_csr.c:563-580):
+ * [0] load_dense (H2D)  [1] kernel  [2] retrieve (D2H)  [3] merge (always 0: no
+ * host merge here)  [4] one-time sparse upload + analysis of the group.       */
+int pygim_group_timers(int64_t handle, double out_ms[5]);
+/* shape / plan of a group: total_rows, total_cols, h, n_parts, n_long_rows
+ * (rows split over several waves), all_ones flag.                             */
+int pygim_group_info(int64_t handle, int64_t out[6]);
+/* Kernel tunables (for A/B runs): name in {"long_row_threshold", "force_vec_bytes",
+ * "csr_kernel"}; returns the previous value.                                   */
+int64_t pygim_set_tunable(const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGIM_HIP_H */

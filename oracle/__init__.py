@@ -1,0 +1,208 @@
+"""numpy front-end of the CPU oracle (oracle/spmm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from pygim_amd/.  Parity status is stated in
+the header of spmm_oracle.c ("parity unpinned" for the arithmetic, partitioning
+pinned against oracle/_ref).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_partition.so")
+
+SUFFIX = {
+    np.dtype(np.int8): "i8",
+    np.dtype(np.int16): "i16",
+    np.dtype(np.int32): "i32",
+    np.dtype(np.int64): "i64",
+    np.dtype(np.float32): "f32",
+    np.dtype(np.float64): "f64",
+}
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "spmm_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(_REF_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _sfx(x):
+    return SUFFIX[np.dtype(x.dtype)]
+
+
+def spmm_csr(rowptr, colind, values, x, ldx=None):
+    """y = A @ x in the reference's row->feature->entry order; values None = ones."""
+    x = np.ascontiguousarray(x)
+    rowptr, colind = _u32(rowptr), _u32(colind)
+    nrows, ncols = len(rowptr) - 1, x.shape[1] if ldx is None else None
+    if ldx is None:
+        ldx = x.shape[1]
+    else:
+        ncols = x.shape[1]
+    if values is not None:
+        values = np.ascontiguousarray(values, dtype=x.dtype)
+    y = np.zeros((nrows, ncols), dtype=x.dtype)
+    getattr(lib(), "oracle_spmm_csr_" + _sfx(x))(
+        _p(y), ctypes.c_uint32(nrows), _p(rowptr), _p(colind), _p(values), _p(x),
+        ctypes.c_uint32(ncols), ctypes.c_uint32(ldx))
+    return y
+
+
+def spmm_coo(row, col, values, x, nrows):
+    x = np.ascontiguousarray(x)
+    row, col = _u32(row), _u32(col)
+    if values is not None:
+        values = np.ascontiguousarray(values, dtype=x.dtype)
+    y = np.zeros((nrows, x.shape[1]), dtype=x.dtype)
+    getattr(lib(), "oracle_spmm_coo_" + _sfx(x))(
+        _p(y), ctypes.c_uint32(len(row)), _p(row), _p(col), _p(values), _p(x),
+        ctypes.c_uint32(x.shape[1]))
+    return y
+
+
+def spmm_csr_rowpar(rowptr, colind, values, x, nthreads=1, out=None):
+    """Row-parallel CSR product (the cpu_baseline 'port'); same sums, same order."""
+    x = np.ascontiguousarray(x)
+    rowptr, colind = _u32(rowptr), _u32(colind)
+    nrows = len(rowptr) - 1
+    if values is not None:
+        values = np.ascontiguousarray(values, dtype=x.dtype)
+    y = np.zeros((nrows, x.shape[1]), dtype=x.dtype) if out is None else out
+    getattr(lib(), "oracle_spmm_csr_rowpar_" + _sfx(x))(
+        _p(y), ctypes.c_uint32(nrows), _p(rowptr), _p(colind), _p(values), _p(x),
+        ctypes.c_uint32(x.shape[1]), ctypes.c_int(nthreads))
+    return y
+
+
+def group(is_coo, ptr_or_row, colind, values, nrows, ncols, x_parts, h):
+    """Group product over sparse column blocks x dense feature blocks.
+
+    ptr_or_row / colind / values: lists (one per sparse part); values may be None.
+    x_parts: list of [total_cols, h_j] arrays.  Returns out[nrows[0], h].
+    """
+    n = len(colind)
+    dt = x_parts[0].dtype
+    pr = [_u32(a) for a in ptr_or_row]
+    ci = [_u32(a) for a in colind]
+    vals = None if values is None else [np.ascontiguousarray(v, dtype=dt) for v in values]
+    xs = [np.ascontiguousarray(x) for x in x_parts]
+    VP = ctypes.c_void_p
+    arr = lambda lst: (VP * len(lst))(*[a.ctypes.data for a in lst])
+    nnz = np.array([len(c) for c in ci], dtype=np.uint32)
+    nr = np.array(nrows, dtype=np.uint32)
+    nc = np.array(ncols, dtype=np.uint32)
+    dn = np.array([x.shape[1] for x in xs], dtype=np.uint32)
+    out = np.zeros((int(nr[0]), h), dtype=dt)
+    getattr(lib(), "oracle_group_" + SUFFIX[np.dtype(dt)])(
+        _p(out), ctypes.c_int(1 if is_coo else 0), ctypes.c_uint32(n), arr(pr), arr(ci),
+        None if vals is None else arr(vals), _p(nr), _p(nc), _p(nnz),
+        ctypes.c_uint32(len(xs)), arr(xs), _p(dn), ctypes.c_uint32(h))
+    return out
+
+
+def partition_by_row(nrows, nparts):
+    split = np.zeros(nparts + 1, dtype=np.uint32)
+    lib().oracle_partition_by_row(ctypes.c_uint32(nrows), _p(split), ctypes.c_int(nparts))
+    return split
+
+
+def partition_by_nnz(rowptr, nparts):
+    rowptr = _u32(rowptr)
+    split = np.zeros(nparts + 1, dtype=np.uint32)
+    lib().oracle_partition_by_nnz(ctypes.c_uint32(len(rowptr) - 1), _p(rowptr), _p(split),
+                                  ctypes.c_int(nparts))
+    return split
+
+
+def partition_equal_nnz(nnz, nparts):
+    split = np.zeros(nparts + 1, dtype=np.uint32)
+    lib().oracle_partition_equal_nnz(ctypes.c_uint32(nnz), _p(split), ctypes.c_int(nparts))
+    return split
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+# --------------------------------------------------------------------------- #
+# oracle/_ref : the reference's own support/partition.c, compiled in place.    #
+# --------------------------------------------------------------------------- #
+class _RefCSR(ctypes.Structure):
+    # support/matrix.h:23-33
+    _fields_ = [("nrows", ctypes.c_uint32), ("ncols", ctypes.c_uint32), ("nnz", ctypes.c_uint32),
+                ("rowptr", ctypes.c_void_p), ("colind", ctypes.c_void_p), ("values", ctypes.c_void_p),
+                ("rowptr_size", ctypes.c_uint32), ("colind_size", ctypes.c_uint32),
+                ("values_size", ctypes.c_uint32)]
+
+
+class _RefCOO(ctypes.Structure):
+    # support/matrix.h:10-19
+    _fields_ = [("nrows", ctypes.c_uint32), ("ncols", ctypes.c_uint32), ("nnz", ctypes.c_uint32),
+                ("rows", ctypes.c_void_p), ("rowind", ctypes.c_void_p), ("colind", ctypes.c_void_p),
+                ("val", ctypes.c_void_p), ("nnz_size", ctypes.c_uint32)]
+
+
+def have_ref():
+    return os.path.exists(_REF_PATH)
+
+
+def ref_partition_by_nnz_csr(rowptr, nparts):
+    ref = ctypes.CDLL(_REF_PATH)
+    rowptr = _u32(rowptr)
+    m = _RefCSR(len(rowptr) - 1, 0, int(rowptr[-1]), rowptr.ctypes.data, None, None, len(rowptr), 0, 0)
+    # the reference writes split[split_cnt] before checking bounds only up to nparts; give slack
+    split = np.zeros(nparts + 2, dtype=np.uint32)
+    ref.partition_by_nnz_csr(ctypes.byref(m), _p(split), ctypes.c_int(nparts))
+    return split[: nparts + 1]
+
+
+def ref_partition_by_row_csr(nrows, nparts):
+    ref = ctypes.CDLL(_REF_PATH)
+    m = _RefCSR(nrows, 0, 0, None, None, None, 0, 0, 0)
+    split = np.zeros(nparts + 2, dtype=np.uint32)
+    ref.partition_by_row_csr(ctypes.byref(m), _p(split), ctypes.c_int(nparts))
+    return split[: nparts + 1]
+
+
+def ref_partition_by_nnz_rgrn_coo(rows_hist, nparts):
+    ref = ctypes.CDLL(_REF_PATH)
+    rows_hist = _u32(rows_hist)
+    m = _RefCOO(len(rows_hist), 0, int(rows_hist.sum()), rows_hist.ctypes.data, None, None, None, 0)
+    split = np.zeros(nparts + 2, dtype=np.uint32)
+    ref.partition_by_nnz_rgrn_coo(ctypes.byref(m), _p(split), ctypes.c_int(nparts))
+    return split[: nparts + 1]
+
+
+def ref_partition_tsklt_by_nnz_coo(nnz, nparts):
+    ref = ctypes.CDLL(_REF_PATH)
+    split = np.zeros(nparts + 2, dtype=np.uint32)
+    ref.partition_tsklt_by_nnz_coo(ctypes.c_uint32(nnz), _p(split), ctypes.c_int(nparts))
+    return split[: nparts + 1]

@@ -1,0 +1,157 @@
+"""ctypes binding of the C-ABI HIP library (include/pygim_hip.h).
+
+The library is built in-tree (``pygim_amd/libpygim_hip.so``, see csrc/Makefile or
+``__graft_entry__.build``).  There is no fallback: if it is missing, importing the
+ops fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PYGIM_HIP_LIB", os.path.join(_HERE, "libpygim_hip.so"))
+
+# symbols include/pygim_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "pygim_init_ranks", "pygim_init_units", "pygim_release", "pygim_is_initialized", "pygim_last_error",
+    "pygim_device_info", "pygim_group_create", "pygim_group_free", "pygim_spmm_run_group",
+    "pygim_grande_run_group", "pygim_spmv_run_group", "pygim_block_run", "pygim_group_timers",
+    "pygim_group_info", "pygim_set_tunable",
+]
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
+INT8, INT16, INT32, INT64, FLT32, DBL64 = range(6)
+CSR, COO = 0, 1
+
+
+class PygimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pygim_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the .so is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                f"(`make -C pygim_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                f"This backend has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        c_i64, c_int, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+        p_i64 = ctypes.POINTER(ctypes.c_int64)
+        L.pygim_last_error.restype = ctypes.c_char_p
+        L.pygim_init_ranks.argtypes = [c_i64, p_i64]
+        L.pygim_init_units.argtypes = [c_i64, p_i64, p_i64]
+        L.pygim_device_info.argtypes = [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), p_i64]
+        L.pygim_group_create.argtypes = [c_int, c_int, c_int, vp, vp, vp, p_i64, p_i64, p_i64, p_i64, p_i64, c_i64,
+                                         p_i64]
+        L.pygim_group_free.argtypes = [c_i64]
+        L.pygim_spmm_run_group.argtypes = [c_i64, vp, vp, vp]
+        L.pygim_grande_run_group.argtypes = [c_i64, vp, p_i64, vp, vp]
+        L.pygim_spmv_run_group.argtypes = [c_i64, vp, vp, vp]
+        L.pygim_block_run.argtypes = [c_i64, c_int, vp, c_i64, vp, c_i64, c_i64, c_int, vp]
+        L.pygim_group_timers.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double)]
+        L.pygim_group_info.argtypes = [c_i64, p_i64]
+        L.pygim_set_tunable.argtypes = [ctypes.c_char_p, c_i64]
+        L.pygim_set_tunable.restype = c_i64
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PygimError(rc, lib().pygim_last_error().decode())
+
+
+def i64_array(values):
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(int(p) if p else None) for p in ptrs])
+
+
+def init_ranks(nr_ranks, want_units=False):
+    out = (ctypes.c_int64 * max(int(nr_ranks), 1))()
+    check(lib().pygim_init_ranks(int(nr_ranks), out))
+    return list(out)[: int(nr_ranks)] if want_units else None
+
+
+def init_units(nr_units):
+    n = max((int(nr_units) + 7) // 8, 1)
+    out = (ctypes.c_int64 * n)()
+    ranks = ctypes.c_int64(0)
+    check(lib().pygim_init_units(int(nr_units), out, ctypes.byref(ranks)))
+    return list(out)[: ranks.value]
+
+
+def release():
+    check(lib().pygim_release())
+
+
+def is_initialized():
+    return bool(lib().pygim_is_initialized())
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cu = ctypes.c_int(0)
+    mem = ctypes.c_int64(0)
+    check(lib().pygim_device_info(name, 256, ctypes.byref(cu), ctypes.byref(mem)))
+    return name.value.decode(), cu.value, mem.value
+
+
+def group_create(fmt, dtype, idx0_ptrs, col_ptrs, val_ptrs, nrows, ncols, nnz, n_dense, dense_cols, h):
+    n = len(col_ptrs)
+    handle = ctypes.c_int64(0)
+    vals = None if val_ptrs is None else ptr_array(val_ptrs)
+    check(lib().pygim_group_create(fmt, dtype, n, ptr_array(idx0_ptrs), ptr_array(col_ptrs), vals, i64_array(nrows),
+                                   i64_array(ncols), i64_array(nnz), i64_array(n_dense), i64_array(dense_cols),
+                                   int(h), ctypes.byref(handle)))
+    return handle.value
+
+
+def group_free(handle):
+    check(lib().pygim_group_free(int(handle)))
+
+
+def spmm_run_group(handle, b_ptrs, out_ptr, stream=0):
+    check(lib().pygim_spmm_run_group(int(handle), ptr_array(b_ptrs), ctypes.c_void_p(out_ptr),
+                                     ctypes.c_void_p(stream or None)))
+
+
+def grande_run_group(handle, b_ptrs, lds, out_ptr, stream=0):
+    check(lib().pygim_grande_run_group(int(handle), ptr_array(b_ptrs), i64_array(lds), ctypes.c_void_p(out_ptr),
+                                       ctypes.c_void_p(stream or None)))
+
+
+def spmv_run_group(handle, b_ptrs, out_ptr, stream=0):
+    check(lib().pygim_spmv_run_group(int(handle), ptr_array(b_ptrs), ctypes.c_void_p(out_ptr),
+                                     ctypes.c_void_p(stream or None)))
+
+
+def block_run(handle, part, x_ptr, ldx, c_ptr, ldc, width, accumulate=False, stream=0):
+    check(lib().pygim_block_run(int(handle), int(part), ctypes.c_void_p(x_ptr), int(ldx), ctypes.c_void_p(c_ptr),
+                                int(ldc), int(width), 1 if accumulate else 0, ctypes.c_void_p(stream or None)))
+
+
+def group_timers(handle):
+    out = (ctypes.c_double * 5)()
+    check(lib().pygim_group_timers(int(handle), out))
+    return list(out)
+
+
+def group_info(handle):
+    out = (ctypes.c_int64 * 6)()
+    check(lib().pygim_group_info(int(handle), out))
+    keys = ["total_rows", "total_cols", "h", "n_parts", "n_long_rows", "all_ones"]
+    return dict(zip(keys, list(out)))
+
+
+def set_tunable(name, value):
+    return int(lib().pygim_set_tunable(name.encode(), int(value)))

@@ -1,0 +1,103 @@
+"""Shared machinery of the three ``backend_pim`` wrappers.
+
+Mirrors what backend_pim/spmm.py, grande.py and spmv.py of the reference each
+re-implement: holding the raw SparseTensor, cutting it into ``sp_parts`` column
+blocks (spmm.py:127-136), materialising per-part int32 CSR / coalesced COO arrays
+(spmm.py:31-55) and calling ``torch.ops.pim_ops``.
+"""
+from __future__ import annotations
+
+import torch
+
+TORCH_TYPES = {"INT64": torch.int64, "INT32": torch.int32, "INT16": torch.int16, "INT8": torch.int8,
+               "FLT32": torch.float32, "DBL64": torch.float64}
+
+
+class CSRPart:
+    """int32 CSR arrays of one column block (what the reference reads back from a
+    torch.sparse_csr_tensor: crow_indices / col_indices / values)."""
+
+    def __init__(self, crow, col, values, shape):
+        self._crow, self._col, self._values, self._shape = crow, col, values, tuple(shape)
+
+    def crow_indices(self):
+        return self._crow
+
+    def col_indices(self):
+        return self._col
+
+    def values(self):
+        return self._values
+
+    def size(self, dim):
+        return self._shape[dim]
+
+
+def part_values(item, dtype):
+    """Edge values of a part in the compute dtype; all ones when the adjacency has none
+    (spmm.py:36-39, 48-51)."""
+    value = item.storage.value()
+    if value is None:
+        return torch.ones(item.nnz(), dtype=dtype, device=item.device())
+    return value.type(dtype)
+
+
+def split_widths(total, nparts):
+    """ceil-sized blocks with the remainder in the last one (spmm.py:62-72, 129-133)."""
+    width = (total + nparts - 1) // nparts
+    sizes = [width] * nparts
+    if nparts * width != total:
+        sizes[-1] = total - (nparts - 1) * width
+    return sizes
+
+
+class SparseGroupBase:
+    def __init__(self, coo, dtype=torch.int32, format=""):
+        self.raw = coo
+        self.dtype = dtype
+        self.format = format
+        self.sp_info_ptr = None
+        self.result = None
+        self.parts = [self.raw]
+        self.csr, self.coo = [], []
+        self.dense_parts = 0
+        self.hidden_size = 0
+        self.nparts = 1
+
+    # -- partitioning -----------------------------------------------------------
+    def col_split(self, nparts=4):
+        assert nparts > 0
+        if nparts != len(self.parts):
+            assert len(self.parts) == 1
+            step = (self.raw.size(1) + nparts - 1) // nparts
+            cuts = [(i * step, (i + 1) * step) for i in range(nparts - 1)] + [((nparts - 1) * step, None)]
+            self.parts = [self.raw[:, a:b] if b is not None else self.raw[:, a:] for a, b in cuts]
+            self.csr, self.coo = [], []
+        return self.parts
+
+    def row_split(self, nparts=4):
+        # not implemented in the reference either (spmm.py:124-125); the multi-GPU row split
+        # lives in pygim_amd.dist
+        assert False
+
+    # -- per-part arrays ----------------------------------------------------------
+    def build_csr(self):
+        self.csr = []
+        for item in self.parts:
+            rowptr, col, _ = item.csr()
+            self.csr.append(CSRPart(rowptr.int().contiguous(), col.int().contiguous(),
+                                    part_values(item, self.dtype).contiguous(), item.sizes()))
+
+    def _coalesced(self, item, shape):
+        row, col, _ = item.coo()
+        return torch.sparse_coo_tensor(torch.stack([row, col], dim=0), part_values(item, self.dtype),
+                                       shape).coalesce()
+
+    def build_coo(self):
+        self.coo = [self._coalesced(item, item.sizes()) for item in self.parts]
+
+    def _coo_arrays(self):
+        self.row_indices = [c.indices()[0].int().contiguous() for c in self.coo]
+        self.col_indices = [c.indices()[1].int().contiguous() for c in self.coo]
+        self.values = [c.values() for c in self.coo]
+        return [c.size(0) for c in self.coo], [c.size(1) for c in self.coo]

@@ -1,0 +1,74 @@
+"""SparseP-style SpMV wrapper -- same public surface as the reference's backend_pim/spmv.py.
+
+An SpMM with h features runs as h SpMVs, ``groups`` (= ds_parts) vectors per backend
+call (spmv.py:89-102).  Integer dtypes only (``torch.iinfo``, spmv.py:45); the matrix is
+padded to a multiple of 64/bits rows and columns (spmv.py:45-51) and results are cut
+back to the true row count (spmv.py:93).
+"""
+import torch
+
+from ._common import TORCH_TYPES, SparseGroupBase, split_widths  # noqa: F401
+
+
+def dense_split(B, nparts, dim=1):
+    if nparts == 1:
+        return [B.contiguous()]
+    return [chunk.contiguous() for chunk in torch.chunk(B, nparts, dim)]
+
+
+class SparseTensorCOO(SparseGroupBase):
+    def __init__(self, coo, dtype=torch.int32, groups=32):
+        super().__init__(coo.int(), dtype=dtype, format="")
+        self.groups = groups
+
+    def build_coo(self):
+        quantum = 64 // torch.iinfo(self.dtype).bits
+        self.coo = []
+        for item in self.parts:
+            extra = (-item.size(0)) % quantum
+            self.coo.append(self._coalesced(item, (item.size(0) + extra, item.size(1) + extra)))
+
+    def to_pim_group_coo(self, hidden_size, rank_pre_spmv=1):
+        B_parts = hidden_size
+        self.format = "COO"
+        self.hidden_size = hidden_size
+        self.dense_parts = B_parts
+        self.max_B_parts_ncols = (hidden_size + B_parts - 1) / B_parts
+        if len(self.coo) != len(self.parts):
+            self.build_coo()
+        nrows, ncols = self._coo_arrays()
+        self.sp_info_ptr = torch.ops.pim_ops.spmv_coo_to_device_group(
+            self.row_indices, self.col_indices, self.values, nrows, ncols, split_widths(hidden_size, B_parts),
+            hidden_size, rank_pre_spmv)
+
+    def _pad_rows(self, B):
+        # the backend multiplies the PADDED matrix: give the vectors its column count
+        # (the reference reads past the end of the unpadded vector here)
+        want = self.coo[0].size(1)
+        if B.size(0) == want:
+            return B
+        return torch.nn.functional.pad(B, (0, 0, 0, want - B.size(0)))
+
+    def mul_single(self, B: torch.Tensor):
+        assert self.hidden_size == B.size(1)
+        vectors = dense_split(self._pad_rows(B), self.dense_parts)
+        res = torch.ops.pim_ops.spmv_coo_run_group(self.sp_info_ptr, vectors)
+        return res[:self.raw.size(0), ...]
+
+    def mul(self, B: torch.Tensor):
+        panels = dense_split(B, B.size(1) // self.groups)
+        return torch.cat([self.mul_single(panel) for panel in panels], dim=1)
+
+    def col_split(self, nparts=4):
+        assert False
+
+
+def prepare_pim_spmv(adj_t, args):
+    assert args.sp_format == "COO"
+    A = SparseTensorCOO(adj_t, dtype=args.data_type, groups=args.ds_parts)
+    A.to_pim_group_coo(args.ds_parts, args.sp_parts)
+    return A
+
+
+def pim_spmv(x, adj_t: SparseTensorCOO):
+    return adj_t.mul(x)

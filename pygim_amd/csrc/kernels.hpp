@@ -1,0 +1,522 @@
+// kernels.hpp -- gfx950 (CDNA4) device code of the aggregation backend.
+//
+// What is computed (the reference's device loop, spmm_default/dpu_kernels/
+// spmm_mul_csr_dpu.c:108-126 and spmm_mul_coo_dpu.c:142-390):
+//     C[r, k] = sum over stored entries e of row r, in stored order, of
+//               val[e] * X[col[e], k]
+// in val_dt arithmetic (spmm_default/support/common.h:39-60): integers are
+// two's-complement modular at the element width, floats are summed in stored
+// order.  How it is computed is CDNA4-specific:
+//   * a 64-lane wavefront spreads over the FEATURE dimension with one 16-byte
+//     vector per lane (1 KiB of a row of X per wave-instruction), so every
+//     gather of an X row is one fully coalesced global_load_dwordx4;
+//   * column ids (and values) of up to 64 entries are fetched with one coalesced
+//     load per wave and handed out through v_readlane (scalar registers), so the
+//     address of each gathered row is scalar-base + lane offset;
+//   * 8 row gathers are kept in flight per wave before the first add;
+//   * sums stay in registers in stored order -> bit-identical to a sequential CPU
+//     loop for every row handled by a single wave.
+// Rows longer than a threshold are cut into fixed-size segments handled by
+// separate waves; the segment sums are added in segment order by a second small
+// kernel (deterministic, no atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace pygim {
+
+// ---------------------------------------------------------------------------
+// element traits: accumulator type (modular for integers) and bit-broadcast
+// ---------------------------------------------------------------------------
+template <typename T> struct AccOf { using type = T; };
+template <> struct AccOf<int8_t> { using type = uint32_t; };
+template <> struct AccOf<int16_t> { using type = uint32_t; };
+template <> struct AccOf<int32_t> { using type = uint32_t; };
+template <> struct AccOf<int64_t> { using type = uint64_t; };
+
+template <typename T> __device__ __forceinline__ typename AccOf<T>::type to_acc(T v) {
+    using A = typename AccOf<T>::type;
+    if constexpr (std::is_floating_point<T>::value) return v;
+    else if constexpr (sizeof(T) == 8) return (A)v;
+    else return (A)(int32_t)v;  // sign-extend, then wrap
+}
+template <typename T> __device__ __forceinline__ T from_acc(typename AccOf<T>::type a) {
+    if constexpr (std::is_floating_point<T>::value) return a;
+    else return (T)a;  // truncation == reduction mod 2^bits
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// broadcast the value held by lane `src` (wave-uniform index) to a scalar
+template <typename T> __device__ __forceinline__ T bcast_lane(T v, int src) {
+    if constexpr (sizeof(T) == 8) {
+        union { T t; uint32_t u[2]; } in, out;
+        in.t = v;
+        out.u[0] = __builtin_amdgcn_readlane(in.u[0], src);
+        out.u[1] = __builtin_amdgcn_readlane(in.u[1], src);
+        return out.t;
+    } else if constexpr (sizeof(T) == 4) {
+        union { T t; uint32_t u; } in, out;
+        in.t = v;
+        out.u = __builtin_amdgcn_readlane(in.u, src);
+        return out.t;
+    } else {
+        int32_t w = (int32_t)v;
+        return (T)__builtin_amdgcn_readlane(w, src);
+    }
+}
+
+// per-lane shuffle inside a power-of-two lane group
+template <typename T> __device__ __forceinline__ T shfl_lane(T v, int src) {
+    if constexpr (sizeof(T) == 8) {
+        union { T t; int u[2]; } in, out;
+        in.t = v;
+        out.u[0] = __shfl(in.u[0], src);
+        out.u[1] = __shfl(in.u[1], src);
+        return out.t;
+    } else if constexpr (sizeof(T) == 4) {
+        union { T t; int u; } in, out;
+        in.t = v;
+        out.u = __shfl(in.u, src);
+        return out.t;
+    } else {
+        return (T)__shfl((int)v, src);
+    }
+}
+
+template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
+template <typename T> struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T *p, T (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = *p;
+    } else {
+        using V = typename VecOf<T, VEC>::type;
+        V v = *reinterpret_cast<const V *>(p);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) out[k] = v[k];
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T *p, const T (&in)[VEC]) {
+    if constexpr (VEC == 1) {
+        *p = in[0];
+    } else {
+        using V = typename VecOf<T, VEC>::type;
+        V v;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) v[k] = in[k];
+        *reinterpret_cast<V *>(p) = v;
+    }
+}
+
+// acc[k] += a * x[k] in val_dt arithmetic.  Floats: separate multiply and add
+// (the file is built with -ffp-contract=off) so that the rounding matches a
+// CPU loop compiled without FMA contraction.
+template <typename T, int VEC>
+__device__ __forceinline__ void axpy(typename AccOf<T>::type (&acc)[VEC], typename AccOf<T>::type a,
+                                     const T (&x)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] += a * to_acc<T>(x[k]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void add_only(typename AccOf<T>::type (&acc)[VEC], const T (&x)[VEC]) {
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] += to_acc<T>(x[k]);
+}
+
+// write VEC results at C[f0 .. f0+VEC) of a row whose valid width is w
+template <typename T, int VEC>
+__device__ __forceinline__ void emit(T *crow, uint32_t f0, uint32_t w, typename AccOf<T>::type (&acc)[VEC],
+                                     bool accumulate) {
+    if (f0 >= w) return;
+    T *p = crow + f0;
+    if (f0 + VEC <= w) {
+        T o[VEC];
+        if (accumulate) {
+            T old[VEC];
+            load_vec<T, VEC>(p, old);
+#pragma unroll
+            for (int k = 0; k < VEC; k++) o[k] = from_acc<T>(to_acc<T>(old[k]) + acc[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) o[k] = from_acc<T>(acc[k]);
+        }
+        store_vec<T, VEC>(p, o);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++)
+            if (f0 + k < w) p[k] = accumulate ? from_acc<T>(to_acc<T>(p[k]) + acc[k]) : from_acc<T>(acc[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One wave accumulates the stored entries [s, e) of one row over the 64*VEC
+// features starting at f_base (wave-uniform s, e).  Gathers are issued 8 deep.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC>
+__device__ __forceinline__ void wave_segment(typename AccOf<T>::type (&acc)[VEC], uint32_t s, uint32_t e,
+                                             const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+                                             const T *__restrict__ xlane /* X + f0 of this lane */,
+                                             int64_t ldx, bool lane_on, int lane) {
+    using A = typename AccOf<T>::type;
+    constexpr int DEPTH = 8;
+    uint32_t mycol_next = (s + lane < e) ? __builtin_nontemporal_load(colind + s + lane) : 0u;
+    T myval_next = T(1);
+    if (vals) myval_next = (s + lane < e) ? __builtin_nontemporal_load(vals + s + lane) : T(0);
+    for (uint32_t e0 = s; e0 < e; e0 += 64) {
+        const uint32_t n = min(64u, e - e0);
+        const uint32_t mycol = mycol_next;
+        const T myval = myval_next;
+        // prefetch the next 64 column ids while this batch is gathered
+        const uint32_t nx = e0 + 64 + lane;
+        if (e0 + 64 < e) {
+            mycol_next = (nx < e) ? __builtin_nontemporal_load(colind + nx) : 0u;
+            if (vals) myval_next = (nx < e) ? __builtin_nontemporal_load(vals + nx) : T(0);
+        }
+        uint32_t j = 0;
+        for (; j + DEPTH <= n; j += DEPTH) {
+            T x[DEPTH][VEC];
+#pragma unroll
+            for (int u = 0; u < DEPTH; u++) {
+                const uint32_t c = __builtin_amdgcn_readlane(mycol, j + u);
+                if (lane_on) load_vec<T, VEC>(xlane + (int64_t)c * ldx, x[u]);
+            }
+            if (lane_on) {
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) {
+                    if (vals) axpy<T, VEC>(acc, to_acc<T>(bcast_lane<T>(myval, j + u)), x[u]);
+                    else add_only<T, VEC>(acc, x[u]);
+                }
+            }
+        }
+        for (; j < n; j++) {
+            T x[VEC];
+            const uint32_t c = __builtin_amdgcn_readlane(mycol, j);
+            if (lane_on) {
+                load_vec<T, VEC>(xlane + (int64_t)c * ldx, x);
+                if (vals) axpy<T, VEC>(acc, to_acc<T>(bcast_lane<T>(myval, j)), x);
+                else add_only<T, VEC>(acc, x);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CSR, one row per wave ("wide": the row of X spans >= 32 lanes).
+// grid.x = ceil(nrows / waves_per_block), grid.y = ceil(w / (64*VEC)).
+// Rows with more than long_thresh entries are left to the long-row kernels.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_csr_wide(const uint32_t *__restrict__ rowptr,
+                                                  const uint32_t *__restrict__ colind,
+                                                  const T *__restrict__ vals, const T *__restrict__ X,
+                                                  int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nrows,
+                                                  uint32_t w, uint32_t long_thresh, int accumulate) {
+    using A = typename AccOf<T>::type;
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (row >= nrows) return;
+    const uint32_t s = rfl(rowptr[row]), e = rfl(rowptr[row + 1]);
+    if (e - s > long_thresh) return;
+    const uint32_t f0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    const bool lane_on = f0 < w;
+    A acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    wave_segment<T, VEC>(acc, s, e, colind, vals, X + f0, ldx, lane_on, lane);
+    emit<T, VEC>(C + (int64_t)row * ldc, f0, w, acc, accumulate != 0);
+}
+
+// Long rows: task t = (row, s, e) -> partial[t, 0:w]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_long_segments(const uint32_t *__restrict__ tasks /* 3 per task */,
+                                                       uint32_t ntasks, const uint32_t *__restrict__ colind,
+                                                       const T *__restrict__ vals, const T *__restrict__ X,
+                                                       int64_t ldx, T *__restrict__ partial, uint32_t w) {
+    using A = typename AccOf<T>::type;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (t >= ntasks) return;
+    const uint32_t s = rfl(tasks[3 * t + 1]), e = rfl(tasks[3 * t + 2]);
+    const uint32_t f0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    const bool lane_on = f0 < w;
+    A acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    wave_segment<T, VEC>(acc, s, e, colind, vals, X + f0, ldx, lane_on, lane);
+    if (lane_on) {
+        T *p = partial + (int64_t)t * w + f0;  // partial is dense [ntasks, w], element-aligned only
+#pragma unroll
+        for (int k = 0; k < VEC; k++)
+            if (f0 + k < w) p[k] = from_acc<T>(acc[k]);
+    }
+}
+
+// Long rows: C[row] (+)= sum of its segment partials, in segment order.
+// desc = (row, first_task, n_tasks) per long row; one thread per (long row, feature).
+template <typename T>
+__global__ __launch_bounds__(256) void k_long_reduce(const uint32_t *__restrict__ desc, uint32_t nlong,
+                                                     const T *__restrict__ partial, T *__restrict__ C,
+                                                     int64_t ldc, uint32_t w, int accumulate) {
+    using A = typename AccOf<T>::type;
+    const uint32_t i = blockIdx.y;
+    if (i >= nlong) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= w) return;
+    const uint32_t row = desc[3 * i], t0 = desc[3 * i + 1], nt = desc[3 * i + 2];
+    A acc = to_acc<T>(partial[(int64_t)t0 * w + k]);
+    for (uint32_t t = 1; t < nt; t++) acc += to_acc<T>(partial[(int64_t)(t0 + t) * w + k]);
+    T *c = C + (int64_t)row * ldc + k;
+    *c = accumulate ? from_acc<T>(to_acc<T>(*c) + acc) : from_acc<T>(acc);
+}
+
+// ---------------------------------------------------------------------------
+// CSR, several rows per wave ("sub-wave": the row of X needs <= 32 lanes).
+// A lane group of 2^log_lpr lanes owns one row; groups walk their rows in
+// lock-step up to the longest row of the wave.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_csr_sub(const uint32_t *__restrict__ rowptr,
+                                                 const uint32_t *__restrict__ colind,
+                                                 const T *__restrict__ vals, const T *__restrict__ X,
+                                                 int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nrows,
+                                                 uint32_t w, uint32_t long_thresh, int accumulate, int log_lpr) {
+    using A = typename AccOf<T>::type;
+    const int lane = threadIdx.x & 63;
+    const int lpr = 1 << log_lpr;
+    const int li = lane & (lpr - 1);
+    const int gbase = lane & ~(lpr - 1);
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t row64 = (uint64_t)wave * (64 >> log_lpr) + (lane >> log_lpr);
+    const bool row_ok = row64 < nrows;
+    const uint32_t row = row_ok ? (uint32_t)row64 : 0u;
+    uint32_t s = 0, len = 0;
+    if (row_ok) {
+        s = rowptr[row];
+        len = rowptr[row + 1] - s;
+    }
+    const bool is_long = len > long_thresh;
+    if (is_long) len = 0;
+    const uint32_t f0 = li * VEC;
+    const bool lane_on = row_ok && f0 < w;
+    // longest row of the wave -> uniform trip count
+    uint32_t maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+    maxlen = rfl(maxlen);
+    A acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    const T *xlane = X + f0;
+    for (uint32_t e0 = 0; e0 < maxlen; e0 += lpr) {
+        const bool have = e0 + li < len;
+        const uint32_t mycol = have ? colind[s + e0 + li] : 0u;
+        T myval = T(1);
+        if (vals) myval = have ? vals[s + e0 + li] : T(0);
+        const int n = (len > e0) ? (int)min((uint32_t)lpr, len - e0) : 0;
+        for (int j = 0; j < lpr; j++) {
+            const uint32_t c = (uint32_t)__shfl((int)mycol, gbase + j);
+            const T v = vals ? shfl_lane<T>(myval, gbase + j) : T(1);
+            if (lane_on && j < n) {
+                T x[VEC];
+                load_vec<T, VEC>(xlane + (int64_t)c * ldx, x);
+                if (vals) axpy<T, VEC>(acc, to_acc<T>(v), x);
+                else add_only<T, VEC>(acc, x);
+            }
+        }
+    }
+    if (row_ok && !is_long) emit<T, VEC>(C + (int64_t)row * ldc, f0, w, acc, accumulate != 0);
+}
+
+// ---------------------------------------------------------------------------
+// COO, equal-nnz split (rows may straddle waves), "wide" layout.
+// Wave c owns stored entries [c*chunk, (c+1)*chunk).  Row segments closed on
+// both sides are written straight to C (C was zero-filled, or holds the running
+// sum when accumulate); a segment open to the left goes to carry[c][0], a
+// segment open only to the right goes to carry[c][1].  k_coo_fixup then adds the
+// carries of each straddling row in chunk order.  This is the reference's
+// nnz-balanced COO split (spmm_default/spmm_mul_coo.c:101-172: "rows may
+// straddle", merged by addition :434-437, 478-488), without atomics.
+// ---------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_coo_wide(const uint32_t *__restrict__ rowind,
+                                                  const uint32_t *__restrict__ colind,
+                                                  const T *__restrict__ vals, uint32_t nnz, uint32_t chunk,
+                                                  const T *__restrict__ X, int64_t ldx, T *__restrict__ C,
+                                                  int64_t ldc, uint32_t w, T *__restrict__ carry,
+                                                  int accumulate) {
+    using A = typename AccOf<T>::type;
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const uint64_t e0_64 = (uint64_t)c * chunk;
+    if (e0_64 >= nnz) return;
+    const uint32_t e0 = (uint32_t)e0_64;
+    const uint32_t e1 = (uint32_t)min((uint64_t)nnz, e0_64 + chunk);
+    const uint32_t f0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    const bool lane_on = f0 < w;
+    const T *xlane = X + f0;
+    const uint32_t first_row = rfl(rowind[e0]);
+    const uint32_t last_row = rfl(rowind[e1 - 1]);
+    const bool left_open = (e0 > 0) && (rfl(rowind[e0 - 1]) == first_row);
+    const bool right_open = (e1 < nnz) && (rfl(rowind[e1]) == last_row);
+    T *carry0 = carry + ((int64_t)c * 2) * w;
+    T *carry1 = carry0 + w;
+
+    A acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    uint32_t cur = first_row;
+    bool seg_is_first = true;
+
+    auto flush = [&](uint32_t r, bool is_first_seg, bool is_last_seg) {
+        const bool lo = is_first_seg && left_open;
+        const bool ro = is_last_seg && right_open;
+        if (lane_on) {
+            if (lo || ro) {
+                T *p = (lo ? carry0 : carry1) + f0;
+#pragma unroll
+                for (int k = 0; k < VEC; k++)
+                    if (f0 + k < w) p[k] = from_acc<T>(acc[k]);
+            } else {
+                emit<T, VEC>(C + (int64_t)r * ldc, f0, w, acc, accumulate != 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    };
+
+    for (uint32_t b = e0; b < e1; b += 64) {
+        const uint32_t n = min(64u, e1 - b);
+        const bool have = (uint32_t)lane < n;
+        const uint32_t myrow = have ? __builtin_nontemporal_load(rowind + b + lane) : 0u;
+        const uint32_t mycol = have ? __builtin_nontemporal_load(colind + b + lane) : 0u;
+        T myval = T(1);
+        if (vals) myval = have ? __builtin_nontemporal_load(vals + b + lane) : T(0);
+        constexpr int DEPTH = 8;
+        uint32_t j = 0;
+        while (j < n) {
+            // entries of the current row inside this batch: [j, jend)
+            const unsigned long long same = __ballot(have && myrow == cur) >> j;
+            // count trailing ones of `same` (entries are row-sorted, so they are contiguous)
+            const uint32_t run = (same == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~same);
+            if (run == 0) {
+                flush(cur, seg_is_first, false);
+                seg_is_first = false;
+                cur = __builtin_amdgcn_readlane(myrow, j);
+                continue;
+            }
+            const uint32_t jend = min(n, j + run);
+            for (; j + DEPTH <= jend; j += DEPTH) {
+                T x[DEPTH][VEC];
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) {
+                    const uint32_t cc = __builtin_amdgcn_readlane(mycol, j + u);
+                    if (lane_on) load_vec<T, VEC>(xlane + (int64_t)cc * ldx, x[u]);
+                }
+                if (lane_on) {
+#pragma unroll
+                    for (int u = 0; u < DEPTH; u++) {
+                        if (vals) axpy<T, VEC>(acc, to_acc<T>(bcast_lane<T>(myval, j + u)), x[u]);
+                        else add_only<T, VEC>(acc, x[u]);
+                    }
+                }
+            }
+            for (; j < jend; j++) {
+                const uint32_t cc = __builtin_amdgcn_readlane(mycol, j);
+                if (lane_on) {
+                    T x[VEC];
+                    load_vec<T, VEC>(xlane + (int64_t)cc * ldx, x);
+                    if (vals) axpy<T, VEC>(acc, to_acc<T>(bcast_lane<T>(myval, j)), x);
+                    else add_only<T, VEC>(acc, x);
+                }
+            }
+        }
+    }
+    flush(cur, seg_is_first, true);
+}
+
+// One wave per chunk; only chunks that START a straddling row do work: they add
+// their right-open carry and the left-open carries of the following chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void k_coo_fixup(const uint32_t *__restrict__ rowind, uint32_t nnz,
+                                                   uint32_t chunk, uint32_t nchunks,
+                                                   const T *__restrict__ carry, T *__restrict__ C, int64_t ldc,
+                                                   uint32_t w, int accumulate) {
+    using A = typename AccOf<T>::type;
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (c >= nchunks) return;
+    const uint64_t e0 = (uint64_t)c * chunk;
+    const uint64_t e1 = min((uint64_t)nnz, e0 + chunk);
+    const uint32_t first_row = rfl(rowind[e0]);
+    const uint32_t last_row = rfl(rowind[e1 - 1]);
+    const bool left_open = (e0 > 0) && (rfl(rowind[e0 - 1]) == first_row);
+    const bool right_open = (e1 < nnz) && (rfl(rowind[e1]) == last_row);
+    // starter: its last segment is open to the right and is not the continuation
+    // of a row that was already open on the left of this same chunk
+    if (!right_open || (left_open && first_row == last_row)) return;
+    const uint32_t row = last_row;
+    for (uint32_t k = lane; k < w; k += 64) {
+        A acc = to_acc<T>(carry[((int64_t)c * 2 + 1) * w + k]);
+        uint32_t d = c + 1;
+        while (true) {
+            acc += to_acc<T>(carry[((int64_t)d * 2) * w + k]);
+            const uint64_t d1 = min((uint64_t)nnz, ((uint64_t)d + 1) * chunk);
+            // chunk d continues the row iff it is entirely this row and open to the right
+            const bool whole = rowind[d1 - 1] == row;
+            const bool more = whole && d1 < nnz && rowind[d1] == row;
+            if (!more) break;
+            d++;
+        }
+        T *p = C + (int64_t)row * ldc + k;
+        *p = accumulate ? from_acc<T>(to_acc<T>(*p) + acc) : from_acc<T>(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// helpers run once per group (create time) or per call on narrow data
+// ---------------------------------------------------------------------------
+// flag[0] |= 1 if rowind is not non-decreasing; flag[1] |= 1 if an index is out of range
+__global__ void k_check_coo(const uint32_t *__restrict__ rowind, const uint32_t *__restrict__ colind,
+                            uint32_t nnz, uint32_t nrows, uint32_t ncols, int *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    if (i + 1 < nnz && rowind[i] > rowind[i + 1]) flag[0] = 1;
+    if (rowind[i] >= nrows || colind[i] >= ncols) flag[1] = 1;
+}
+__global__ void k_check_csr(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
+                            uint32_t nrows, uint32_t nnz, uint32_t ncols, int *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows && rowptr[i] > rowptr[i + 1]) flag[0] = 1;
+    if (i == 0 && (rowptr[0] != 0 || rowptr[nrows] != nnz)) flag[0] = 1;
+    if (i < nnz && colind[i] >= ncols) flag[1] = 1;
+}
+template <typename T> __global__ void k_check_ones(const T *__restrict__ v, uint32_t n, int *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(v[i] == T(1))) flag[0] = 1;
+}
+// COO row index -> rowptr (lower bound of each row in the sorted rowind)
+__global__ void k_coo_rowptr(const uint32_t *__restrict__ rowind, uint32_t nnz, uint32_t nrows,
+                             uint32_t *__restrict__ rowptr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nnz) return;
+    const uint32_t hi = (i < nnz) ? rowind[i] : nrows;          // rows < hi end at or before i
+    const uint32_t lo = (i == 0) ? 0u : rowind[i - 1] + 1;      // rows >= lo start at or after i
+    for (uint32_t r = lo; r <= hi && r <= nrows; r++) rowptr[r] = (uint32_t)i;
+    if (i == 0) rowptr[0] = 0;
+}
+// interleave g separate vectors x_j[n] into Xp[n, g] (SpMV path: the g right-hand
+// sides of one call become one narrow dense panel)
+template <typename T>
+__global__ void k_pack_vectors(const T *const *__restrict__ vecs, uint32_t g, uint64_t n, T *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * g) return;
+    const uint64_t r = i / g;
+    const uint32_t j = (uint32_t)(i % g);
+    out[i] = vecs[j][r];
+}
+
+}  // namespace pygim

@@ -1,0 +1,770 @@
+// pygim_hip.hip -- host runtime + C ABI (include/pygim_hip.h) of the MI355X
+// aggregation backend.  Device code lives in kernels.hpp.
+//
+// Reference boundary this file replaces, function by function:
+//   dpu_init_ranks / dpu_init_dpus / dpu_release   spmm_default/pytorch_api.cpp:154-164
+//   spmm_{csr,coo}_to_device_group                 spmm_default/pytorch_api.cpp:204-243, 286-329
+//     prepare_pim_{csr,coo} + copy_sparse_{csr,coo}  spmm_mul_csr.c:118-330, spmm_mul_coo.c:83-318
+//   spmm_{csr,coo}_run_group                       spmm_default/pytorch_api.cpp:248-280, 332-367
+//     spmm_pim_{csr,coo}                             spmm_mul_csr.c:335-561, spmm_mul_coo.c:323-592
+//   grande / spmv twins                            spmm_grande/pytorch_api.cpp:221-321,
+//                                                  spmv_sparseP/pytorch_api.cpp:184-266
+// No CPU compute fallback exists in this file: without a HIP device every entry
+// point fails with PYGIM_ERR_NO_DEVICE.
+#include "../../include/pygim_hip.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace pygim;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
+            return fail(PYGIM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+        }                                                                                      \
+    } while (0)
+
+size_t dtype_size(int dt) {
+    switch (dt) {
+        case PYGIM_INT8: return 1;
+        case PYGIM_INT16: return 2;
+        case PYGIM_INT32: return 4;
+        case PYGIM_INT64: return 8;
+        case PYGIM_FLT32: return 4;
+        case PYGIM_DBL64: return 8;
+    }
+    return 0;
+}
+
+struct Tunables {
+    int64_t long_row_threshold = 4096;  // entries per wave before a row is cut into segments
+    int64_t force_vec_bytes = 0;        // 0 = pick by alignment
+    int64_t csr_kernel = 0;             // 0 = auto, 1 = force wide, 2 = force sub-wave
+    int64_t coo_chunk = 512;            // entries per wave in the nnz-split COO kernel
+    int64_t coo_via_rowptr = 0;         // 1 = run COO groups through the CSR kernels (derived rowptr)
+} g_tune;
+
+struct Part {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    uint32_t *rowptr = nullptr;  // CSR rowptr, or derived from the COO row index
+    uint32_t *rowind = nullptr;  // COO only
+    uint32_t *colind = nullptr;
+    void *vals = nullptr;        // nullptr when all ones
+    bool own_rowptr = false, own_rowind = false, own_colind = false, own_vals = false;
+    // long-row plan (rows with more than long_row_threshold entries)
+    uint32_t n_long = 0, n_tasks = 0;
+    uint32_t *d_tasks = nullptr;  // (row, s, e) x n_tasks
+    uint32_t *d_desc = nullptr;   // (row, first_task, n_tasks) x n_long
+    uint32_t long_thresh = 0;
+    std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
+};
+
+struct Group {
+    int format = 0, dtype = 0;
+    int64_t h = 0, total_rows = 0, total_cols = 0;
+    std::vector<Part> parts;
+    bool all_ones = true;
+    // scratch (device), grown on demand
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *stage_in = nullptr;
+    size_t stage_in_bytes = 0;
+    void *stage_out = nullptr;
+    size_t stage_out_bytes = 0;
+    void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
+    size_t d_ptrs_n = 0;
+    int *d_flags = nullptr;
+    double timers[5] = {0, 0, 0, 0, 0};
+};
+
+struct Context {
+    bool inited = false;
+    int device = 0;
+    int cu_count = 0;
+    int64_t nr_ranks = 0;
+    std::set<Group *> groups;
+    std::mutex mu;
+} g_ctx;
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int ensure(void **buf, size_t *have, size_t need) {
+    if (*have >= need) return 0;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(buf, need));
+    *have = need;
+    return 0;
+}
+
+// bring an array to the device (copy if it is host memory, alias if already there)
+template <typename P> int to_device(const void *src, size_t bytes, P **dst, bool *owned, hipStream_t st) {
+    if (bytes == 0) {
+        // keep a valid non-null pointer so kernels can take it
+        HIP_TRY(hipMalloc((void **)dst, 16));
+        *owned = true;
+        return 0;
+    }
+    if (is_device_ptr(src)) {
+        *dst = (P *)const_cast<void *>(src);
+        *owned = false;
+        return 0;
+    }
+    HIP_TRY(hipMalloc((void **)dst, bytes));
+    *owned = true;
+    HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+void free_group(Group *g) {
+    for (auto &p : g->parts) {
+        if (p.own_rowptr && p.rowptr) (void)hipFree(p.rowptr);
+        if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
+        if (p.own_colind && p.colind) (void)hipFree(p.colind);
+        if (p.own_vals && p.vals) (void)hipFree(p.vals);
+        if (p.d_tasks) (void)hipFree(p.d_tasks);
+        if (p.d_desc) (void)hipFree(p.d_desc);
+    }
+    if (g->scratch) (void)hipFree(g->scratch);
+    if (g->stage_in) (void)hipFree(g->stage_in);
+    if (g->stage_out) (void)hipFree(g->stage_out);
+    if (g->d_ptrs) (void)hipFree(g->d_ptrs);
+    if (g->d_flags) (void)hipFree(g->d_flags);
+    delete g;
+}
+
+Group *lookup(int64_t handle) {
+    Group *g = reinterpret_cast<Group *>(static_cast<uintptr_t>(handle));
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    return g_ctx.groups.count(g) ? g : nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// launch plan for one block product
+// ---------------------------------------------------------------------------
+int pick_vec_bytes(size_t es, const void *X, int64_t ldx, const void *C, int64_t ldc) {
+    // widest of {16, 8, element} bytes that every row start of X and C is aligned to
+    auto ok = [&](size_t vb) {
+        return ((uintptr_t)X % vb == 0) && ((uintptr_t)C % vb == 0) && ((size_t)ldx * es % vb == 0) &&
+               ((size_t)ldc * es % vb == 0);
+    };
+    size_t cap = g_tune.force_vec_bytes > 0 ? (size_t)g_tune.force_vec_bytes : 16;
+    for (size_t vb : {(size_t)16, (size_t)8})
+        if (vb <= cap && vb > es && ok(vb)) return (int)vb;
+    return (int)es;
+}
+
+template <typename T, int VEC>
+int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate,
+                   hipStream_t st) {
+    const T *vals = (const T *)p.vals;
+    const uint32_t nrows = (uint32_t)p.nrows;
+    const uint32_t lanes_needed = (w + VEC - 1) / VEC;
+    const bool coo_native = (g->format == PYGIM_COO) && !g_tune.coo_via_rowptr && lanes_needed > 16;
+    if (coo_native) {
+        // nnz-split kernel + carry fix-up
+        if (!accumulate) HIP_TRY(hipMemset2DAsync(C, (size_t)ldc * sizeof(T), 0, (size_t)w * sizeof(T), nrows, st));
+        if (p.nnz == 0) return 0;
+        const uint32_t chunk = (uint32_t)g_tune.coo_chunk;
+        const uint32_t nchunks = (uint32_t)((p.nnz + chunk - 1) / chunk);
+        const size_t need = (size_t)nchunks * 2 * w * sizeof(T);
+        if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
+        dim3 grid((nchunks + 3) / 4, (lanes_needed + 63) / 64);
+        hipLaunchKernelGGL((k_coo_wide<T, VEC>), grid, dim3(256), 0, st, p.rowind, p.colind, vals,
+                           (uint32_t)p.nnz, chunk, X, ldx, C, ldc, w, (T *)g->scratch, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((k_coo_fixup<T>), dim3((nchunks + 3) / 4), dim3(256), 0, st, p.rowind,
+                           (uint32_t)p.nnz, chunk, nchunks, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // CSR kernels (native CSR, or COO through its derived rowptr)
+    bool wide = lanes_needed > 32;
+    if (g_tune.csr_kernel == 1) wide = true;
+    if (g_tune.csr_kernel == 2 && lanes_needed <= 32) wide = false;
+    if (nrows > 0) {
+        if (wide) {
+            dim3 grid((nrows + 3) / 4, (lanes_needed + 63) / 64);
+            hipLaunchKernelGGL((k_csr_wide<T, VEC>), grid, dim3(256), 0, st, p.rowptr, p.colind, vals, X, ldx, C,
+                               ldc, nrows, w, p.long_thresh, accumulate ? 1 : 0);
+        } else {
+            int log_lpr = 0;
+            while ((1u << log_lpr) < lanes_needed) log_lpr++;
+            const uint32_t rows_per_wave = 64u >> log_lpr;
+            const uint32_t waves = (nrows + rows_per_wave - 1) / rows_per_wave;
+            hipLaunchKernelGGL((k_csr_sub<T, VEC>), dim3((waves + 3) / 4), dim3(256), 0, st, p.rowptr, p.colind,
+                               vals, X, ldx, C, ldc, nrows, w, p.long_thresh, accumulate ? 1 : 0, log_lpr);
+        }
+    }
+    if (p.n_tasks > 0) {
+        const size_t need = (size_t)p.n_tasks * w * sizeof(T);
+        if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
+        dim3 grid((p.n_tasks + 3) / 4, (lanes_needed + 63) / 64);
+        hipLaunchKernelGGL((k_long_segments<T, VEC>), grid, dim3(256), 0, st, p.d_tasks, p.n_tasks, p.colind, vals,
+                           X, ldx, (T *)g->scratch, w);
+        hipLaunchKernelGGL((k_long_reduce<T>), dim3((w + 255) / 256, p.n_long), dim3(256), 0, st, p.d_desc,
+                           p.n_long, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
+                 hipStream_t st) {
+    const int vb = pick_vec_bytes(sizeof(T), X, ldx, C, ldc);
+    const int vec = vb / (int)sizeof(T);
+    const T *x = (const T *)X;
+    T *c = (T *)C;
+    const uint32_t ww = (uint32_t)w;
+#define CASE(V)                                                               \
+    if constexpr (V >= 1 && (size_t)V * sizeof(T) <= 16) {                    \
+        if (vec == V) return launch_block_t<T, V>(g, p, x, ldx, c, ldc, ww, accumulate, st); \
+    }
+    CASE(16) CASE(8) CASE(4) CASE(2)
+#undef CASE
+    return launch_block_t<T, 1>(g, p, x, ldx, c, ldc, ww, accumulate, st);
+}
+
+int launch_block_any(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w,
+                     bool accumulate, hipStream_t st) {
+    if (w <= 0) return 0;
+    switch (g->dtype) {
+        case PYGIM_INT8: return launch_block<int8_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
+        case PYGIM_INT16: return launch_block<int16_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
+        case PYGIM_INT32: return launch_block<int32_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
+        case PYGIM_INT64: return launch_block<int64_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
+        case PYGIM_FLT32: return launch_block<float>(g, p, X, ldx, C, ldc, w, accumulate, st);
+        case PYGIM_DBL64: return launch_block<double>(g, p, X, ldx, C, ldc, w, accumulate, st);
+    }
+    return fail(PYGIM_ERR_INVALID, "unknown dtype");
+}
+
+template <typename T> void launch_check_ones(const void *v, uint32_t n, int *flag, hipStream_t st) {
+    hipLaunchKernelGGL((k_check_ones<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const T *)v, n, flag);
+}
+
+// Long-row plan from a host copy of rowptr: rows above the threshold are cut
+// into segments of `thresh` entries.
+void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, std::vector<uint32_t> &tasks,
+                    std::vector<uint32_t> &desc) {
+    for (int64_t r = 0; r < nrows; r++) {
+        const uint32_t s = rowptr[r], e = rowptr[r + 1];
+        if (e - s <= thresh) continue;
+        const uint32_t first = (uint32_t)(tasks.size() / 3);
+        uint32_t n = 0;
+        for (uint32_t a = s; a < e; a += thresh, n++) {
+            tasks.push_back((uint32_t)r);
+            tasks.push_back(a);
+            tasks.push_back(std::min(e, a + thresh));
+        }
+        desc.push_back((uint32_t)r);
+        desc.push_back(first);
+        desc.push_back(n);
+    }
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int need_init() {
+    if (!g_ctx.inited) return fail(PYGIM_ERR_NO_DEVICE, "backend not initialised: call dpu_init_ranks / pygim_init_ranks first");
+    return 0;
+}
+
+}  // namespace
+
+template <typename T>
+static void launch_pack(const void *const *d_ptrs, uint32_t gcount, uint64_t n, void *out, hipStream_t st) {
+    const uint64_t total = n * gcount;
+    if (total == 0) return;
+    hipLaunchKernelGGL((k_pack_vectors<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const T *const *)d_ptrs, gcount, n, (T *)out);
+}
+
+
+// shared body of the three run_group flavours.
+//   windows[k]   : dense operand k (flattened over parts when per_part)
+//   ld[k]        : its row stride in elements
+//   per_part     : grande layout (each window holds only the rows of its own sparse part)
+static int run_group_common(Group *g, const void *const *windows, const int64_t *ld, bool per_part, void *out,
+                            hipStream_t st) {
+    const size_t es = dtype_size(g->dtype);
+    size_t nwin = 0;
+    if (per_part)
+        for (auto &p : g->parts) nwin += p.dense_cols.size();
+    else
+        nwin = g->parts[0].dense_cols.size();
+    if (!windows || !out) return fail(PYGIM_ERR_INVALID, "null dense operand or output");
+    for (size_t k = 0; k < nwin; k++)
+        if (!windows[k]) return fail(PYGIM_ERR_INVALID, "null dense part");
+    const bool dev_out = is_device_ptr(out);
+    bool dev_in = is_device_ptr(windows[0]);
+    for (size_t k = 1; k < nwin; k++)
+        if (is_device_ptr(windows[k]) != dev_in) return fail(PYGIM_ERR_INVALID, "dense parts mix host and device memory");
+    if (dev_in != dev_out) return fail(PYGIM_ERR_INVALID, "dense parts and output must both be host or both be device memory");
+
+    // window geometry
+    std::vector<int64_t> rows(nwin), lds(nwin), widths(nwin);
+    {
+        size_t k = 0;
+        if (per_part) {
+            for (auto &p : g->parts)
+                for (size_t j = 0; j < p.dense_cols.size(); j++, k++) {
+                    rows[k] = p.ncols;
+                    widths[k] = p.dense_cols[j];
+                    lds[k] = ld ? ld[k] : p.dense_cols[j];
+                    if (lds[k] < widths[k]) return fail(PYGIM_ERR_INVALID, "window stride smaller than its width");
+                }
+        } else {
+            for (size_t j = 0; j < nwin; j++) {
+                rows[j] = g->total_cols;
+                widths[j] = g->parts[0].dense_cols[j];
+                lds[j] = ld ? ld[j] : widths[j];
+            }
+        }
+    }
+    std::vector<const void *> dwin(nwin);
+    void *dout = out;
+    double t_in = 0, t_k = 0, t_out = 0;
+    if (!dev_in) {
+        const double t0 = now_ms();
+        size_t total = 0;
+        std::vector<size_t> off(nwin);
+        for (size_t k = 0; k < nwin; k++) {
+            off[k] = total;
+            total += (((size_t)rows[k] * lds[k] * es) + 255) & ~(size_t)255;
+        }
+        if (int rc = ensure(&g->stage_in, &g->stage_in_bytes, std::max<size_t>(total, 256))) return rc;
+        if (int rc = ensure(&g->stage_out, &g->stage_out_bytes, std::max<size_t>((size_t)g->total_rows * g->h * es, 256))) return rc;
+        for (size_t k = 0; k < nwin; k++) {
+            dwin[k] = (char *)g->stage_in + off[k];
+            const size_t bytes = (size_t)rows[k] * lds[k] * es;
+            if (bytes) HIP_TRY(hipMemcpyAsync((void *)dwin[k], windows[k], bytes, hipMemcpyHostToDevice, st));
+        }
+        dout = g->stage_out;
+        HIP_TRY(hipStreamSynchronize(st));
+        t_in = now_ms() - t0;
+    } else {
+        for (size_t k = 0; k < nwin; k++) dwin[k] = windows[k];
+    }
+    const double t1 = now_ms();
+    // block products: sum over sparse parts, concatenate over dense parts
+    int64_t brow = 0;
+    size_t kbase = 0;
+    for (size_t i = 0; i < g->parts.size(); i++) {
+        Part &p = g->parts[i];
+        int64_t acol = 0;
+        for (size_t j = 0; j < p.dense_cols.size(); j++) {
+            const size_t k = per_part ? kbase + j : j;
+            const int64_t w = widths[k];
+            const char *x = (const char *)dwin[k] + (per_part ? 0 : (size_t)brow * lds[k] * es);
+            char *c = (char *)dout + (size_t)acol * es;
+            if (int rc = launch_block_any(g, p, x, lds[k], c, g->h, w, /*accumulate=*/i > 0, st)) return rc;
+            acol += w;
+        }
+        brow += p.ncols;
+        kbase += p.dense_cols.size();
+    }
+    if (!dev_in) {
+        HIP_TRY(hipStreamSynchronize(st));
+        t_k = now_ms() - t1;
+        const double t2 = now_ms();
+        const size_t bytes = (size_t)g->total_rows * g->h * es;
+        if (bytes) HIP_TRY(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        t_out = now_ms() - t2;
+        g->timers[0] = t_in;
+        g->timers[1] = t_k;
+        g->timers[2] = t_out;
+        g->timers[3] = 0;
+    }
+    return 0;
+}
+
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char *pygim_last_error(void) { return g_err.c_str(); }
+
+int pygim_is_initialized(void) { return g_ctx.inited ? 1 : 0; }
+
+int pygim_init_ranks(int64_t nr_ranks, int64_t *units_per_rank) {
+    if (nr_ranks <= 0) return fail(PYGIM_ERR_INVALID, "nr_ranks must be positive");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(PYGIM_ERR_NO_DEVICE, "no HIP device visible (this backend has no CPU fallback)");
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g_ctx.device = dev;
+    g_ctx.cu_count = prop.multiProcessorCount;
+    g_ctx.nr_ranks = nr_ranks;
+    g_ctx.inited = true;
+    if (units_per_rank)
+        for (int64_t i = 0; i < nr_ranks; i++) units_per_rank[i] = 8;  // one feature window per XCD
+    return 0;
+}
+
+int pygim_init_units(int64_t nr_units, int64_t *units_per_rank, int64_t *nr_ranks_out) {
+    // the reference rounds a DPU count up to whole ranks of 64 (dpu_alloc); here a
+    // "unit" is a feature window and a rank holds 8 of them (one per XCD)
+    if (nr_units <= 0) return fail(PYGIM_ERR_INVALID, "nr_units must be positive");
+    const int64_t ranks = (nr_units + 7) / 8;
+    if (nr_ranks_out) *nr_ranks_out = ranks;
+    return pygim_init_ranks(ranks, units_per_rank);
+}
+
+int pygim_release(void) {
+    std::vector<Group *> gs;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        gs.assign(g_ctx.groups.begin(), g_ctx.groups.end());
+        g_ctx.groups.clear();
+    }
+    if (g_ctx.inited) (void)hipDeviceSynchronize();
+    for (Group *g : gs) free_group(g);
+    g_ctx.inited = false;
+    return 0;
+}
+
+int pygim_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(PYGIM_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int64_t pygim_set_tunable(const char *name, int64_t value) {
+    int64_t *slot = nullptr;
+    std::string n = name ? name : "";
+    if (n == "long_row_threshold") slot = &g_tune.long_row_threshold;
+    else if (n == "force_vec_bytes") slot = &g_tune.force_vec_bytes;
+    else if (n == "csr_kernel") slot = &g_tune.csr_kernel;
+    else if (n == "coo_chunk") slot = &g_tune.coo_chunk;
+    else if (n == "coo_via_rowptr") slot = &g_tune.coo_via_rowptr;
+    if (!slot) return -1;
+    const int64_t old = *slot;
+    *slot = value;
+    return old;
+}
+
+int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const *idx0,
+                       const int32_t *const *colind, const void *const *values, const int64_t *nrows,
+                       const int64_t *ncols, const int64_t *nnz, const int64_t *n_dense,
+                       const int64_t *dense_cols, int64_t h_size, int64_t *out_handle) {
+    if (int rc = need_init()) return rc;
+    if (format != PYGIM_CSR && format != PYGIM_COO) return fail(PYGIM_ERR_INVALID, "format must be CSR(0) or COO(1)");
+    const size_t es = dtype_size(dtype);
+    if (es == 0) return fail(PYGIM_ERR_INVALID, "unknown dtype");
+    if (n_parts <= 0 || !idx0 || !colind || !nrows || !ncols || !nnz || !n_dense || !dense_cols || !out_handle)
+        return fail(PYGIM_ERR_INVALID, "null argument or n_parts <= 0");
+    if (h_size <= 0) return fail(PYGIM_ERR_INVALID, "h_size must be positive");
+    const double t0 = now_ms();
+    Group *g = new Group;
+    g->format = format;
+    g->dtype = dtype;
+    g->h = h_size;
+    g->total_rows = nrows[0];
+    g->parts.resize(n_parts);
+    hipStream_t st = nullptr;
+    int rc = 0;
+    auto bail = [&](int code) {
+        (void)hipDeviceSynchronize();
+        free_group(g);
+        return code;
+    };
+    if (hipMalloc((void **)&g->d_flags, 4 * sizeof(int)) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "hipMalloc flags"));
+    if (hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), st) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "memset flags"));
+    size_t dpos = 0;
+    for (int i = 0; i < n_parts; i++) {
+        Part &p = g->parts[i];
+        p.nrows = nrows[i];
+        p.ncols = ncols[i];
+        p.nnz = nnz[i];
+        if (p.nrows != g->total_rows) return bail(fail(PYGIM_ERR_INVALID, "all sparse parts must have the same number of rows"));
+        if (p.nrows < 0 || p.ncols < 0 || p.nnz < 0 || p.nnz > 0xFFFFFFFFll || p.nrows >= 0xFFFFFFFFll ||
+            p.ncols > 0xFFFFFFFFll)
+            return bail(fail(PYGIM_ERR_INVALID, "part sizes must fit 32-bit indices (the reference's uint32 matrices)"));
+        if (n_dense[i] <= 0) return bail(fail(PYGIM_ERR_INVALID, "n_dense must be positive"));
+        int64_t sum = 0;
+        for (int64_t j = 0; j < n_dense[i]; j++) {
+            if (dense_cols[dpos + j] < 0) return bail(fail(PYGIM_ERR_INVALID, "negative dense width"));
+            p.dense_cols.push_back(dense_cols[dpos + j]);
+            sum += dense_cols[dpos + j];
+        }
+        dpos += (size_t)n_dense[i];
+        if (sum != h_size) return bail(fail(PYGIM_ERR_INVALID, "dense widths of a part must add up to h_size"));
+        g->total_cols += p.ncols;
+        if (!idx0[i] && (format == PYGIM_CSR || p.nnz > 0)) return bail(fail(PYGIM_ERR_INVALID, "null index array"));
+        if (!colind[i] && p.nnz > 0) return bail(fail(PYGIM_ERR_INVALID, "null colind"));
+
+        if ((rc = to_device<uint32_t>(colind[i], (size_t)p.nnz * 4, &p.colind, &p.own_colind, st))) return bail(rc);
+        const void *v = values ? values[i] : nullptr;
+        if (v) {
+            if ((rc = to_device<void>(v, (size_t)p.nnz * es, &p.vals, &p.own_vals, st))) return bail(rc);
+        }
+        std::vector<uint32_t> h_rowptr;
+        if (format == PYGIM_CSR) {
+            if ((rc = to_device<uint32_t>(idx0[i], (size_t)(p.nrows + 1) * 4, &p.rowptr, &p.own_rowptr, st))) return bail(rc);
+            hipLaunchKernelGGL(k_check_csr, dim3((unsigned)((std::max(p.nrows + 1, p.nnz) + 255) / 256)), dim3(256), 0,
+                               st, p.rowptr, p.colind, (uint32_t)p.nrows, (uint32_t)p.nnz, (uint32_t)p.ncols,
+                               g->d_flags);
+        } else {
+            if ((rc = to_device<uint32_t>(idx0[i], (size_t)p.nnz * 4, &p.rowind, &p.own_rowind, st))) return bail(rc);
+            if (p.nnz > 0)
+                hipLaunchKernelGGL(k_check_coo, dim3((unsigned)((p.nnz + 255) / 256)), dim3(256), 0, st, p.rowind,
+                                   p.colind, (uint32_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, g->d_flags);
+            // derived rowptr: the reference also builds a per-row histogram of a COO part at
+            // to_device time (spmm_default/pytorch_api.cpp:315-318)
+            if (hipMalloc((void **)&p.rowptr, (size_t)(p.nrows + 1) * 4) != hipSuccess)
+                return bail(fail(PYGIM_ERR_HIP, "hipMalloc rowptr"));
+            p.own_rowptr = true;
+            hipLaunchKernelGGL(k_coo_rowptr, dim3((unsigned)((p.nnz + 1 + 255) / 256)), dim3(256), 0, st, p.rowind,
+                               (uint32_t)p.nnz, (uint32_t)p.nrows, p.rowptr);
+        }
+        if (p.vals && p.nnz > 0) {
+            int *f = g->d_flags + 2;
+            switch (dtype) {
+                case PYGIM_INT8: launch_check_ones<int8_t>(p.vals, (uint32_t)p.nnz, f, st); break;
+                case PYGIM_INT16: launch_check_ones<int16_t>(p.vals, (uint32_t)p.nnz, f, st); break;
+                case PYGIM_INT32: launch_check_ones<int32_t>(p.vals, (uint32_t)p.nnz, f, st); break;
+                case PYGIM_INT64: launch_check_ones<int64_t>(p.vals, (uint32_t)p.nnz, f, st); break;
+                case PYGIM_FLT32: launch_check_ones<float>(p.vals, (uint32_t)p.nnz, f, st); break;
+                case PYGIM_DBL64: launch_check_ones<double>(p.vals, (uint32_t)p.nnz, f, st); break;
+            }
+        }
+    }
+    int flags[4] = {0, 0, 0, 0};
+    if (hipMemcpy(flags, g->d_flags, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess)
+        return bail(fail(PYGIM_ERR_HIP, std::string("group validation: ") + hipGetErrorString(hipGetLastError())));
+    if (flags[1]) return bail(fail(PYGIM_ERR_INVALID, "index out of range in a sparse part"));
+    if (flags[0]) {
+        if (format == PYGIM_COO) return bail(fail(PYGIM_ERR_UNSORTED, "COO row indices are not sorted (pass a coalesced tensor)"));
+        return bail(fail(PYGIM_ERR_INVALID, "rowptr is not a non-decreasing prefix array ending at nnz"));
+    }
+    g->all_ones = (flags[2] == 0);
+    // long-row plan needs rowptr on the host
+    for (int i = 0; i < n_parts; i++) {
+        Part &p = g->parts[i];
+        if (g->all_ones && p.vals) {
+            // unit weights: drop the value array from the hot loop (legitimate: 1*x == x exactly)
+            if (p.own_vals) (void)hipFree(p.vals);
+            p.vals = nullptr;
+            p.own_vals = false;
+        }
+        p.long_thresh = (uint32_t)std::max<int64_t>(64, g_tune.long_row_threshold);
+        std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
+        if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(fail(PYGIM_ERR_HIP, "rowptr D2H"));
+        std::vector<uint32_t> tasks, desc;
+        plan_long_rows(h_rowptr.data(), p.nrows, p.long_thresh, tasks, desc);
+        p.n_tasks = (uint32_t)(tasks.size() / 3);
+        p.n_long = (uint32_t)(desc.size() / 3);
+        if (p.n_tasks) {
+            if (hipMalloc((void **)&p.d_tasks, tasks.size() * 4) != hipSuccess ||
+                hipMalloc((void **)&p.d_desc, desc.size() * 4) != hipSuccess ||
+                hipMemcpy(p.d_tasks, tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(p.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
+        }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
+    g->timers[4] = now_ms() - t0;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        g_ctx.groups.insert(g);
+    }
+    *out_handle = (int64_t) reinterpret_cast<uintptr_t>(g);
+    return 0;
+}
+
+int pygim_group_free(int64_t handle) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        g_ctx.groups.erase(g);
+    }
+    (void)hipDeviceSynchronize();
+    free_group(g);
+    return 0;
+}
+
+int pygim_group_timers(int64_t handle, double out_ms[5]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    for (int i = 0; i < 5; i++) out_ms[i] = g->timers[i];
+    return 0;
+}
+
+int pygim_group_info(int64_t handle, int64_t out[6]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    out[0] = g->total_rows;
+    out[1] = g->total_cols;
+    out[2] = g->h;
+    out[3] = (int64_t)g->parts.size();
+    int64_t nl = 0;
+    for (auto &p : g->parts) nl += p.n_long;
+    out[4] = nl;
+    out[5] = g->all_ones ? 1 : 0;
+    return 0;
+}
+
+int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t width,
+                    int accumulate, void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if (part < 0 || part >= (int)g->parts.size()) return fail(PYGIM_ERR_INVALID, "part index out of range");
+    if (!X || !C || width <= 0 || ldx < width || ldc < width) return fail(PYGIM_ERR_INVALID, "bad X/C/width/stride");
+    if (!is_device_ptr(X) || !is_device_ptr(C)) return fail(PYGIM_ERR_INVALID, "pygim_block_run needs device pointers");
+    return launch_block_any(g, g->parts[part], X, ldx, C, ldc, width, accumulate != 0, (hipStream_t)stream);
+}
+
+int pygim_spmm_run_group(int64_t handle, const void *const *B_parts, void *out, void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    for (auto &p : g->parts)
+        if (p.dense_cols != g->parts[0].dense_cols)
+            return fail(PYGIM_ERR_INVALID, "spmm_run_group needs the same dense split for every sparse part");
+    return run_group_common(g, B_parts, nullptr, false, out, (hipStream_t)stream);
+}
+
+int pygim_grande_run_group(int64_t handle, const void *const *B_windows, const int64_t *window_ld, void *out,
+                           void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if (!window_ld) return fail(PYGIM_ERR_INVALID, "window_ld is required");
+    return run_group_common(g, B_windows, window_ld, true, out, (hipStream_t)stream);
+}
+
+int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out, void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t es = dtype_size(g->dtype);
+    const size_t nvec = g->parts[0].dense_cols.size();
+    for (auto &p : g->parts) {
+        if (p.dense_cols.size() != nvec) return fail(PYGIM_ERR_INVALID, "spmv group: dense split differs between parts");
+        for (auto wdt : p.dense_cols)
+            if (wdt != 1) return fail(PYGIM_ERR_INVALID, "spmv group: every dense part must be one column wide");
+    }
+    if (!B_vectors || !out) return fail(PYGIM_ERR_INVALID, "null vectors or output");
+    for (size_t j = 0; j < nvec; j++)
+        if (!B_vectors[j]) return fail(PYGIM_ERR_INVALID, "null vector");
+    const bool dev_in = is_device_ptr(B_vectors[0]);
+    const bool dev_out = is_device_ptr(out);
+    for (size_t j = 1; j < nvec; j++)
+        if (is_device_ptr(B_vectors[j]) != dev_in) return fail(PYGIM_ERR_INVALID, "vectors mix host and device memory");
+    if (dev_in != dev_out) return fail(PYGIM_ERR_INVALID, "vectors and output must both be host or both be device memory");
+    const uint64_t n = (uint64_t)g->total_cols;
+    // layout of stage_in: [packed panel n x nvec][raw vectors (host mode only)]
+    const size_t panel_bytes = ((size_t)n * nvec * es + 255) & ~(size_t)255;
+    const size_t vec_bytes = ((size_t)n * es + 255) & ~(size_t)255;
+    const size_t need_in = panel_bytes + (dev_in ? 0 : vec_bytes * nvec);
+    if (int rc = ensure(&g->stage_in, &g->stage_in_bytes, std::max<size_t>(need_in, 256))) return rc;
+    if (g->d_ptrs_n < nvec) {
+        if (g->d_ptrs) HIP_TRY(hipFree(g->d_ptrs));
+        g->d_ptrs = nullptr;
+        HIP_TRY(hipMalloc((void **)&g->d_ptrs, nvec * sizeof(void *)));
+        g->d_ptrs_n = nvec;
+    }
+    std::vector<const void *> src(nvec);
+    const double t0 = now_ms();
+    for (size_t j = 0; j < nvec; j++) {
+        if (dev_in) {
+            src[j] = B_vectors[j];
+        } else {
+            void *d = (char *)g->stage_in + panel_bytes + j * vec_bytes;
+            if (n) HIP_TRY(hipMemcpyAsync(d, B_vectors[j], (size_t)n * es, hipMemcpyHostToDevice, st));
+            src[j] = d;
+        }
+    }
+    // pointer table is consumed by the pack kernel before this function can be re-entered
+    // on the same group; a synchronous copy keeps the host vector alive long enough
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(g->d_ptrs, src.data(), nvec * sizeof(void *), hipMemcpyHostToDevice));
+    const double t1 = now_ms();
+    switch (es) {
+        case 1: launch_pack<int8_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 2: launch_pack<int16_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 4: launch_pack<int32_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 8: launch_pack<int64_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
+    }
+    void *dout = out;
+    if (!dev_out) {
+        if (int rc = ensure(&g->stage_out, &g->stage_out_bytes, std::max<size_t>((size_t)g->total_rows * nvec * es, 256))) return rc;
+        dout = g->stage_out;
+    }
+    int64_t brow = 0;
+    for (size_t i = 0; i < g->parts.size(); i++) {
+        Part &p = g->parts[i];
+        const char *x = (const char *)g->stage_in + (size_t)brow * nvec * es;
+        if (int rc = launch_block_any(g, p, x, (int64_t)nvec, dout, (int64_t)nvec, (int64_t)nvec, i > 0, st)) return rc;
+        brow += p.ncols;
+    }
+    if (!dev_out) {
+        HIP_TRY(hipStreamSynchronize(st));
+        const double t2 = now_ms();
+        const size_t bytes = (size_t)g->total_rows * nvec * es;
+        if (bytes) HIP_TRY(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        g->timers[0] = t1 - t0;
+        g->timers[1] = t2 - t1;
+        g->timers[2] = now_ms() - t2;
+        g->timers[3] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""Seeded synthetic graphs in the shapes BASELINE.json names (no datasets on the GPU box).
+
+Generator: out-degrees from a discretised log-normal clipped to
+[0, d_max] and adjusted so that they add up to nnz exactly; column ids uniform in [0, N)
+(or clustered around the row id), sorted inside each row, duplicates kept for CSR (the
+reference's CSR path does not coalesce, backend_pim/spmm.py:44-55).  Adjacency values are
+all ones (spmm.py:36-37, 48-49) and features follow the reference driver's generator
+``torch.randint(-8, 4, (N, h))`` (spmm_test.py:70: ``-2^6, 2^6`` is XOR in Python).
+Dataset statistics are the public PyG / OGB figures, pinned here as constants.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+# name -> (N, nnz, d_max)
+SHAPES = {
+    "cora": (2_708, 10_556, 168),
+    "reddit": (232_965, 114_615_892, 21_657),
+    "ogbn-products": (2_449_029, 123_718_280, 17_481),
+    "ogbn-papers100M": (111_059_956, 1_615_685_872, 100_000),
+    # small stand-ins with the same mean degree / skew, for tests
+    "reddit-mini": (4_096, 4_096 * 123, 1_500),
+    "products-mini": (20_000, 20_000 * 50, 4_000),
+}
+
+
+def _gen(seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
+
+
+def degrees(n, nnz, d_max, seed=0, device="cpu", sigma=1.0):
+    """int64 out-degrees, log-normal shaped, each <= d_max, summing to nnz exactly."""
+    assert nnz <= n * d_max, "d_max too small for this nnz"
+    g = _gen(seed, device)
+    z = torch.randn(n, generator=g, device=device, dtype=torch.float64)
+    w = torch.exp(sigma * z)
+    deg = torch.floor(w * (nnz / float(w.sum()))).clamp_(max=d_max).to(torch.int64)
+    order = torch.randperm(n, generator=g, device=device)
+    diff = int(nnz - int(deg.sum()))
+    while diff != 0:
+        room = (deg[order] < d_max) if diff > 0 else (deg[order] > 0)
+        cand = order[room]
+        k = min(abs(diff), int(cand.numel()))
+        deg[cand[:k]] += 1 if diff > 0 else -1
+        diff -= k if diff > 0 else -k
+    return deg
+
+
+def make_csr(n, nnz, d_max, seed=0, device="cpu", clustered=False, ncols=None, sigma=1.0):
+    """(rowptr int32 [n+1], col int32 [nnz]) of an n x ncols matrix, columns sorted per row."""
+    ncols = n if ncols is None else ncols
+    assert nnz < 2 ** 31 and n < 2 ** 31
+    deg = degrees(n, nnz, d_max, seed, device, sigma)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    g = _gen(seed + 1, device)
+    row = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
+    if clustered:
+        # neighbours within ~1% of the id range of the row (community-like locality)
+        spread = max(ncols // 100, 8)
+        off = (torch.randn(nnz, generator=g, device=device) * spread).round().to(torch.int64)
+        col = torch.remainder(row * ncols // max(n, 1) + off, ncols)
+    else:
+        col = torch.randint(0, ncols, (nnz,), generator=g, device=device, dtype=torch.int64)
+    key = row * ncols + col
+    del row
+    key, _ = torch.sort(key)
+    col = torch.remainder(key, ncols).to(torch.int32)
+    return rowptr.to(torch.int32), col
+
+
+def make_shape(name, seed=0, device="cpu", clustered=False):
+    n, nnz, d_max = SHAPES[name]
+    return make_csr(n, nnz, d_max, seed, device, clustered)
+
+
+def csr_to_coo_coalesced(rowptr, col, dtype):
+    """Row-sorted, duplicate-free (row, col, value) like torch's coalesce(): duplicates of the
+    multigraph become values > 1 (backend_pim/spmm.py:40-42)."""
+    n = rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    row = torch.repeat_interleave(torch.arange(n, device=col.device, dtype=torch.int64), deg)
+    ncols = int(col.max()) + 1 if col.numel() else 1
+    key = row * ncols + col.to(torch.int64)
+    uniq, counts = torch.unique_consecutive(key, return_counts=True)
+    return (uniq // ncols).to(torch.int32), (uniq % ncols).to(torch.int32), counts.to(dtype)
+
+
+def features(n, h, dtype, seed=0, device="cpu", kind="driver"):
+    """X of the reference driver (``randint(-8, 4)``, exact in every dtype) or uniform(-1, 1)
+    floats (``kind='uniform'``, exercises the floating-point tolerance)."""
+    g = _gen(seed + 2, device)
+    if kind == "uniform":
+        assert dtype in (torch.float32, torch.float64)
+        return torch.rand((n, h), generator=g, device=device, dtype=dtype) * 2 - 1
+    return torch.randint(-8, 4, (n, h), generator=g, device=device, dtype=torch.int64).to(dtype)
+
+
+def algorithmic_bytes(nrows, ncols, nnz, h, elem_bytes, fmt="CSR", with_values=True):
+    """Compulsory traffic of one product, every array touched once:
+    idx + nnz*sizeof(val) + ncols*h*sizeof(val) + nrows*h*sizeof(val)."""
+    idx = 4 * (nrows + 1) + 4 * nnz if fmt == "CSR" else 8 * nnz
+    vals = nnz * elem_bytes if with_values else 0
+    return idx + vals + ncols * h * elem_bytes + nrows * h * elem_bytes
+
+
+def gather_bytes(nrows, nnz, h, elem_bytes, fmt="CSR"):
+    """Gather-model traffic: every stored entry pulls one row of X through the cache hierarchy."""
+    idx = 4 * (nrows + 1) + 4 * nnz if fmt == "CSR" else 8 * nnz
+    return idx + nnz * h * elem_bytes + nrows * h * elem_bytes
+
+
+def flops(nnz, h):
+    return 2 * nnz * h
+
+
+__all__ = ["SHAPES", "degrees", "make_csr", "make_shape", "csr_to_coo_coalesced", "features",
+           "algorithmic_bytes", "gather_bytes", "flops", "math"]

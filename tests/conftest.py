@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NP_DTYPES = {
+    "INT8": np.int8, "INT16": np.int16, "INT32": np.int32, "INT64": np.int64,
+    "FLT32": np.float32, "DBL64": np.float64,
+}
+ALL_DTYPES = list(NP_DTYPES)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def random_csr(rng, nrows, ncols, avg_deg, max_deg=None, empty_frac=0.1, long_rows=()):
+    """Random multigraph CSR (duplicates allowed, columns sorted per row)."""
+    deg = rng.poisson(avg_deg, size=nrows).astype(np.int64)
+    if max_deg is not None:
+        deg = np.minimum(deg, max_deg)
+    deg[rng.random(nrows) < empty_frac] = 0
+    for r, d in long_rows:
+        deg[r] = d
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    col = rng.integers(0, ncols, size=int(rowptr[-1]), dtype=np.int64)
+    for r in range(nrows):
+        col[rowptr[r]:rowptr[r + 1]].sort()
+    return rowptr.astype(np.int32), col.astype(np.int32)
+
+
+def driver_features(rng, n, h, np_dtype):
+    """X as the reference driver draws it: randint(-8, 4) (spmm_test.py:70)."""
+    return rng.integers(-8, 4, size=(n, h)).astype(np_dtype)
+
+
+def coalesce(rowptr, col, np_dtype):
+    """(row, col, val) sorted and de-duplicated like torch's coalesce()."""
+    nrows = len(rowptr) - 1
+    row = np.repeat(np.arange(nrows, dtype=np.int64), np.diff(rowptr.astype(np.int64)))
+    ncols = int(col.max()) + 1 if len(col) else 1
+    key = row * ncols + col.astype(np.int64)
+    uniq, counts = np.unique(key, return_counts=True)
+    return (uniq // ncols).astype(np.int32), (uniq % ncols).astype(np.int32), counts.astype(np_dtype)
+
+
+@pytest.fixture
+def rng():
+    return np.random.default_rng(1234)

@@ -1,0 +1,143 @@
+"""Generates the golden vectors under tests/golden/ (run in the BUILD container).
+
+Sources of truth, in order:
+  * partition_*.npz  -- outputs of the REFERENCE's own support/partition.c compiled in place
+                        into oracle/_ref (oracle/Makefile target `ref`); needs /root/reference.
+  * spmm_*.npz       -- the reference holds no vectors for the arithmetic
+                        and its host loops cannot be compiled here (they include the UPMEM
+                        SDK's dpu.h), so expected outputs come from the oracle restatement and
+                        are accepted only when torch.sparse.mm AND scipy give the same answer
+                        (bit-exact for integers, exactly representable sums for the float cases
+                        that use the driver's integer-valued features).
+Inputs follow the reference driver: graph shapes of SURVEY.md section 8c, features
+torch.randint(-8, 4) under torch.manual_seed (spmm_test.py:70).
+Usage: python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle  # noqa: E402
+from conftest import NP_DTYPES, coalesce, random_csr  # noqa: E402
+from pygim_amd import synth  # noqa: E402
+
+TORCH_OF = {"INT8": torch.int8, "INT16": torch.int16, "INT32": torch.int32, "INT64": torch.int64,
+            "FLT32": torch.float32, "DBL64": torch.float64}
+
+
+def cross_check(fmt, rowptr, row, col, vals, x, y, exact):
+    n = y.shape[0]
+    wide = np.int64 if np.issubdtype(x.dtype, np.integer) else np.float64
+    v = np.ones(len(col), dtype=wide) if vals is None else vals.astype(wide)
+    if fmt == "CSR":
+        a = sp.csr_matrix((v, col.copy(), rowptr.copy()), shape=(n, x.shape[0]))  # abs() below de-duplicates in place
+    else:
+        a = sp.coo_matrix((v, (row, col)), shape=(n, x.shape[0])).tocsr()
+    ref = a @ x.astype(wide)
+    # floating-point bar of BASELINE.json: 1e-5 relative -- measured against the magnitude
+    # of the sum, |A| . |x| (a bound relative to the rounded result itself is meaningless
+    # where terms cancel)
+    scale = abs(a) @ np.abs(x.astype(wide))
+    if exact:
+        assert np.array_equal(y, ref.astype(x.dtype)), "oracle != scipy"
+    else:
+        assert np.all(np.abs(y - ref) <= 1e-5 * scale + 1e-30), "oracle vs scipy beyond 1e-5 relative"
+    if fmt == "COO":
+        t = torch.sparse_coo_tensor(torch.tensor(np.stack([row, col]).astype(np.int64)),
+                                    torch.from_numpy(v.astype(x.dtype)), (n, x.shape[0]))
+        yt = torch.sparse.mm(t, torch.from_numpy(x)).numpy()
+        if exact:
+            assert np.array_equal(y, yt), "oracle != torch.sparse.mm"
+        else:
+            assert np.all(np.abs(y - yt) <= 1e-5 * scale + 1e-30)
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def emit(name, fmt, rowptr, col, x, vals=None, exact=True):
+    npdt = x.dtype
+    if fmt == "CSR":
+        y = oracle.spmm_csr(rowptr, col, vals, x)
+        cross_check("CSR", rowptr, None, col, vals, x, y, exact)
+        kw = dict(fmt="CSR", rowptr=rowptr, col=col, x=x, y=y)
+        if vals is not None:
+            kw["vals"] = vals
+    else:
+        r, c, v = coalesce(rowptr, col, npdt)
+        if vals is not None:  # weighted: keep given weights on the de-duplicated pattern
+            v = (v * 0 + 1).astype(npdt) * vals[: len(v)]
+        y = oracle.spmm_coo(r, c, v, x, len(rowptr) - 1)
+        cross_check("COO", None, r, c, v, x, y, exact)
+        kw = dict(fmt="COO", row=r, col=c, vals=v, x=x, y=y, nrows=len(rowptr) - 1)
+    save(name, **kw)
+
+
+def main():
+    for f in os.listdir(HERE):
+        if f.endswith(".npz"):
+            os.remove(os.path.join(HERE, f))
+    # (1) Cora-shaped, h = 32, every dtype, driver features under torch.manual_seed
+    rowptr_t, col_t = synth.make_shape("cora", seed=0)
+    rowptr, col = rowptr_t.numpy(), col_t.numpy()
+    n = len(rowptr) - 1
+    for name, tdt in TORCH_OF.items():
+        torch.manual_seed(2708)
+        x = torch.randint(-8, 4, (n, 32)).to(tdt).numpy()  # == torch.randint(-2^6, 2^6, ...) of the driver
+        emit(f"spmm_cora_csr_{name}", "CSR", rowptr, col, x)
+        emit(f"spmm_cora_coo_{name}", "COO", rowptr, col, x)
+    rng = np.random.default_rng(7)
+    # (2) overflow: rows of degree >= 300 so int8 / int16 sums wrap
+    rowptr, col = random_csr(rng, 64, 512, 40, long_rows=[(3, 900), (40, 5000)])
+    for name in ("INT8", "INT16"):
+        x = rng.integers(-128 if name == "INT8" else -20000, 127 if name == "INT8" else 20000,
+                         size=(512, 24)).astype(NP_DTYPES[name])
+        emit(f"spmm_wrap_csr_{name}", "CSR", rowptr, col, x)
+        emit(f"spmm_wrap_coo_{name}", "COO", rowptr, col, x)
+    # (3) duplicate-heavy multigraph: COO values > 1 after coalesce, CSR keeps duplicates
+    rowptr, col = random_csr(rng, 200, 16, 12)
+    x = rng.integers(-8, 4, size=(16, 9)).astype(np.int32)
+    emit("spmm_dups_csr_INT32", "CSR", rowptr, col, x)
+    emit("spmm_dups_coo_INT32", "COO", rowptr, col, x)
+    # (4) ragged: empty rows, one 5000-entry row, odd widths
+    rowptr, col = random_csr(rng, 300, 300, 6, empty_frac=0.4, long_rows=[(17, 5000)])
+    for h in (1, 9, 32, 100, 256):
+        x = rng.integers(-8, 4, size=(300, h)).astype(np.int32)
+        emit(f"spmm_ragged_csr_h{h}_INT32", "CSR", rowptr, col, x)
+    x = rng.integers(-8, 4, size=(300, 100)).astype(np.int64)
+    emit("spmm_ragged_coo_h100_INT64", "COO", rowptr, col, x)
+    # (5) non-integer floats and real-valued weights (tolerance cases)
+    rowptr, col = random_csr(rng, 256, 256, 20, long_rows=[(9, 3000)])
+    for name in ("FLT32", "DBL64"):
+        npdt = NP_DTYPES[name]
+        x = (rng.random((256, 48)) * 2 - 1).astype(npdt)
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+        emit(f"spmm_real_csr_{name}", "CSR", rowptr, col, x, vals=vals, exact=False)
+    # partition vectors from the reference's own partition.c
+    if oracle.have_ref():
+        kw, k = {}, 0
+        for trial in range(12):
+            nrows = int(rng.integers(1, 500))
+            rp, _ = random_csr(rng, nrows, 64, float(rng.uniform(0.3, 30)), empty_frac=0.3)
+            for nparts in (2, 8, 64):
+                kw[f"rowptr_{k}"] = rp
+                kw[f"nparts_{k}"] = nparts
+                kw[f"by_nnz_{k}"] = oracle.ref_partition_by_nnz_csr(rp, nparts)
+                kw[f"by_row_{k}"] = oracle.ref_partition_by_row_csr(nrows, nparts)
+                k += 1
+        save("partition_ref", n_cases=k, **kw)
+    else:
+        print("oracle/_ref missing: partition vectors NOT regenerated")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""The CPU oracle against independent libraries, the reference's own partition.c
+(oracle/_ref) and the committed golden vectors.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import oracle
+from conftest import ALL_DTYPES, NP_DTYPES, coalesce, driver_features, random_csr
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dense_ref(rowptr, col, vals, x):
+    """exact reference through scipy in int64/float64, reduced to the element type"""
+    n = len(rowptr) - 1
+    dt = x.dtype
+    wide = np.int64 if np.issubdtype(dt, np.integer) else np.float64
+    v = np.ones(len(col), dtype=wide) if vals is None else vals.astype(wide)
+    a = sp.csr_matrix((v, col, rowptr), shape=(n, x.shape[0]))
+    y = a @ x.astype(wide)
+    return y.astype(dt) if np.issubdtype(dt, np.integer) else y
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_csr_matches_scipy_and_torch(rng, dt):
+    npdt = NP_DTYPES[dt]
+    rowptr, col = random_csr(rng, 300, 257, 9, long_rows=[(5, 700)])
+    x = driver_features(rng, 257, 32, npdt)
+    y = oracle.spmm_csr(rowptr, col, None, x)
+    ref = _dense_ref(rowptr, col, None, x)
+    if np.issubdtype(npdt, np.integer):
+        assert np.array_equal(y, ref)  # int8 / int16 wrap: row 5 has 700 entries
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1e-5)
+        # driver features are small integers -> float sums are exact
+        assert np.array_equal(y, ref.astype(npdt))
+    # torch.sparse.mm on the coalesced COO form (the only torch CPU path with int support)
+    r, c, v = coalesce(rowptr, col, npdt)
+    a = torch.sparse_coo_tensor(torch.tensor(np.stack([r, c]).astype(np.int64)), torch.from_numpy(v), (300, 257))
+    yt = torch.sparse.mm(a, torch.from_numpy(x)).numpy()
+    assert np.array_equal(y, yt)
+    # the oracle's own COO loop on the coalesced triples (values > 1 where edges repeat)
+    yc = oracle.spmm_coo(r, c, v, x, 300)
+    assert np.array_equal(y, yc)
+
+
+@pytest.mark.parametrize("dt", ["INT32", "FLT32", "DBL64", "INT8"])
+def test_valued_and_rowpar_bitwise(rng, dt):
+    npdt = NP_DTYPES[dt]
+    rowptr, col = random_csr(rng, 200, 180, 12)
+    vals = rng.integers(-3, 4, size=len(col)).astype(npdt)
+    if not np.issubdtype(npdt, np.integer):
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+        x = (rng.random((180, 17)) * 2 - 1).astype(npdt)
+    else:
+        x = driver_features(rng, 180, 17, npdt)
+    y = oracle.spmm_csr(rowptr, col, vals, x)
+    ref = _dense_ref(rowptr, col, vals, x)
+    if np.issubdtype(npdt, np.integer):
+        assert np.array_equal(y, ref)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6 if npdt == np.float32 else 1e-12)
+    for nt in (1, 3):
+        assert np.array_equal(y, oracle.spmm_csr_rowpar(rowptr, col, vals, x, nthreads=nt))
+
+
+@pytest.mark.parametrize("fmt", ["CSR", "COO"])
+@pytest.mark.parametrize("sp_parts,ds_parts", [(1, 1), (2, 1), (3, 4), (8, 3)])
+def test_group_semantics(rng, fmt, sp_parts, ds_parts):
+    """sum over column blocks, concatenation over feature blocks (ops.hpp:42-62, spmm.py:9-13,127-136)"""
+    npdt = np.int32
+    n, h = 150, 10
+    rowptr, col = random_csr(rng, n, n, 7)
+    x = driver_features(rng, n, h, npdt)
+    full = oracle.spmm_csr(rowptr, col, None, x)
+    step = (n + sp_parts - 1) // sp_parts
+    a = sp.csr_matrix((np.ones(len(col), dtype=np.int64), col, rowptr), shape=(n, n))
+    idx0, cols, vals, nrows, ncols = [], [], [], [], []
+    for i in range(sp_parts):
+        blk = a[:, i * step:min(n, (i + 1) * step)].tocsr()
+        blk.sum_duplicates()
+        blk.sort_indices()
+        if fmt == "CSR":
+            idx0.append(blk.indptr)
+        else:
+            idx0.append(blk.tocoo().row)
+        cols.append(blk.indices)
+        vals.append(blk.data.astype(npdt))
+        nrows.append(n)
+        ncols.append(blk.shape[1])
+    xs = [np.ascontiguousarray(c) for c in np.array_split(x, ds_parts, axis=1)] if ds_parts > 1 else [x]
+    xs = [c for c in xs if c.shape[1] > 0]
+    out = oracle.group(fmt == "COO", idx0, cols, vals, nrows, ncols, xs, h)
+    assert np.array_equal(out, full)
+
+
+def test_partition_restatement_matches_reference_build(rng):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    for trial in range(40):
+        nrows = int(rng.integers(1, 400))
+        rowptr, _ = random_csr(rng, nrows, 50, float(rng.uniform(0.2, 20)), empty_frac=0.3)
+        for nparts in (1, 2, 3, 7, 16, 64):
+            mine = oracle.partition_by_nnz(rowptr, nparts)
+            ref = oracle.ref_partition_by_nnz_csr(rowptr, nparts)
+            assert np.array_equal(mine, ref), (trial, nparts)
+            hist = np.diff(rowptr.astype(np.int64)).astype(np.uint32)
+            assert np.array_equal(mine, oracle.ref_partition_by_nnz_rgrn_coo(hist, nparts))
+            assert np.array_equal(oracle.partition_by_row(nrows, nparts), oracle.ref_partition_by_row_csr(nrows, nparts))
+            nnz = int(rowptr[-1])
+            assert np.array_equal(oracle.partition_equal_nnz(nnz, nparts), oracle.ref_partition_tsklt_by_nnz_coo(nnz, nparts))
+
+
+def test_golden_vectors():
+    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert files, "no golden vectors committed"
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        if f.startswith("partition"):
+            for k in range(int(z["n_cases"])):
+                rp, nparts = z[f"rowptr_{k}"], int(z[f"nparts_{k}"])
+                assert np.array_equal(oracle.partition_by_nnz(rp, nparts), z[f"by_nnz_{k}"])
+                assert np.array_equal(oracle.partition_by_row(len(rp) - 1, nparts), z[f"by_row_{k}"])
+            continue
+        vals = z["vals"] if "vals" in z.files else None
+        if str(z["fmt"]) == "CSR":
+            y = oracle.spmm_csr(z["rowptr"], z["col"], vals, z["x"])
+        else:
+            y = oracle.spmm_coo(z["row"], z["col"], vals, z["x"], int(z["nrows"]))
+        assert np.array_equal(y, z["y"]), f
