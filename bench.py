@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): SpMM GFLOP/s (+ achieved algorithmic GB/s) on a Reddit-shaped
+synthetic CSR (N = 232 965, nnz = 114 615 892, unit weights), h = 256, FLT32.
+One "step" = one pass of the hot path: C = A . X through the C ABI
+(pygim_spmm_run_group) with A, X and C resident in HBM.
+
+N = 1 : whole graph on the one GPU.
+N > 1 : strong scaling of the SAME graph: A is row-split into N nnz-balanced blocks
+        (the reference's partition_by_nnz_csr walk), X is replicated, rank r computes
+        C[rows_r, :] and the row blocks are all-gathered over RCCL so every rank ends
+        the step holding the full C (what the next GCN layer needs).
+
+Launch: python bench.py --gpus 1 --steps 20 --warmup 5
+        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def nnz_balanced_row_split(rowptr_cpu, nparts):
+    """Same greedy walk as the reference's partition_by_nnz_csr (support/partition.c:51-99):
+    close a block once its running nnz reaches floor(nnz / nparts)."""
+    n = rowptr_cpu.numel() - 1
+    if nparts == 1:
+        return [0, n]
+    rp = rowptr_cpu.to(torch.int64)
+    target = int(rp[-1]) // nparts
+    split = [0]
+    base = 0
+    for _ in range(nparts - 1):
+        # first row index r with rp[r] - rp[base] >= target
+        r = int(torch.searchsorted(rp, rp[base] + target, right=False))
+        r = min(max(r, base), n)
+        split.append(r)
+        base = r
+    split.append(n)
+    return split
+
+
+def cpu_baseline(rowptr, col, x, args):
+    """The oracle's row-parallel loop (kind 'port') on a bounded row sample of the same graph."""
+    import oracle
+
+    threads = oracle.max_threads()
+    nrows = min(args.cpu_rows, rowptr.numel() - 1)
+    rp = rowptr[: nrows + 1].cpu().numpy().astype(np.uint32)
+    nnz = int(rp[-1])
+    cl = col[:nnz].cpu().numpy().astype(np.uint32)
+    xh = x.cpu().numpy()
+    out = np.zeros((nrows, xh.shape[1]), dtype=xh.dtype)
+    oracle.spmm_csr_rowpar(rp, cl, None, xh, nthreads=threads, out=out)  # warm (page-in)
+    out[:] = 0
+    t0 = time.perf_counter()
+    oracle.spmm_csr_rowpar(rp, cl, None, xh, nthreads=threads, out=out)
+    dt = time.perf_counter() - t0
+    gflops = 2.0 * nnz * xh.shape[1] / dt / 1e9
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"rows [0,{nrows}) of the same graph ({nnz} nnz, h={xh.shape[1]}), "
+                      f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="reddit")
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--clustered", action="store_true", help="columns near the row id instead of uniform")
+    ap.add_argument("--cpu-rows", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    args = ap.parse_args()
+
+    from pygim_amd import _lib, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, nnz, d_max = synth.SHAPES[args.shape]
+    h = args.hidden
+    # every rank builds the same seeded graph and features on its own device
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered)
+    x = synth.features(n, h, torch.float32, seed=0, device=dev)
+    torch.cuda.synchronize()
+
+    _lib.init_ranks(world)
+    _lib.set_tunable("kernel_events", 1)
+    split = nnz_balanced_row_split(rowptr.cpu(), world)
+    r0, r1 = split[rank], split[rank + 1]
+    lo, hi = int(rowptr[r0]), int(rowptr[r1])
+    my_rowptr = (rowptr[r0:r1 + 1] - lo).contiguous()
+    my_col = col[lo:hi].contiguous()
+    my_rows, my_nnz = r1 - r0, hi - lo
+    handle = _lib.group_create(_lib.CSR, _lib.FLT32, [my_rowptr.data_ptr()], [my_col.data_ptr()], None,
+                               [my_rows], [n], [my_nnz], [1], [h], h)
+    max_rows = max(split[i + 1] - split[i] for i in range(world))
+    # gather buffer: world blocks of max_rows rows; rank r's block is written in place by the kernel
+    gathered = torch.empty((world, max_rows, h), dtype=torch.float32, device=dev)
+    mine = gathered[rank]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        _lib.spmm_run_group(handle, [x.data_ptr()], mine.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.group_kernel_ms(handle, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms_sum, k_count = _lib.group_kernel_ms(handle, reset=True)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = synth.flops(nnz, h)
+    gflops = total_flops / (ms_per_step * 1e-3) / 1e9
+
+    # roofline of the dominant kernel (k_csr_wide<float,4>) on THIS rank's block
+    alg_bytes = synth.algorithmic_bytes(my_rows, n, my_nnz, h, 4, "CSR", with_values=True)
+    k_ms = k_ms_sum / max(k_count, 1)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    if os.path.exists(args.traffic_json):
+        try:
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "k_csr_wide<float,4>", "kernel_ms": round(k_ms, 4), "launches": k_count,
+                "algorithmic_bytes": alg_bytes,
+                "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
+                "fp32_frac": round(synth.flops(my_nnz, h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None}
+
+    result = {
+        "metric": "SpMM GFLOP/s, Reddit-shaped CSR h=256 fp32", "value": round(gflops, 2), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
+                   "columns": "clustered" if args.clustered else "uniform",
+                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world} + RCCL all-gather of C"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, cpu_out = cpu_baseline(rowptr, col, x, args)
+        result["cpu_baseline"] = base
+        if not args.no_check:
+            got = mine[: cpu_out.shape[0]].cpu().numpy()
+            result["check"] = "bit-exact vs oracle on the sampled rows" if np.array_equal(got, cpu_out) else "MISMATCH"
+    _lib.group_free(handle)
+    if rank == 0:
+        print(f"[DATA]pim_time_spmm(ms):  {ms_per_step}", file=sys.stderr)
+        print(f"[DATA]kernel_time(ms):  {k_ms}", file=sys.stderr)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if result.get("check") == "MISMATCH":
+        raise SystemExit("bench result differs from the oracle")
+
+
+if __name__ == "__main__":
+    main()

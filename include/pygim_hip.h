@@ -138,8 +138,13 @@ int pygim_group_timers(int64_t handle, double out_ms[5]);
 /* shape / plan of a group: total_rows, total_cols, h, n_parts, n_long_rows
  * (rows split over several waves), all_ones flag.                             */
 int pygim_group_info(int64_t handle, int64_t out[6]);
+/* With tunable "kernel_events" = 1 every block product brackets its dominant kernel (the
+ * row-gather kernel, not the long-row tail kernels) with HIP events on the launch stream.
+ * This call waits for the pending pairs and returns the accumulated milliseconds and the
+ * number of launches since the last reset.                                      */
+int pygim_group_kernel_ms(int64_t handle, double *sum_ms, int64_t *count, int reset);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "force_vec_bytes",
- * "csr_kernel"}; returns the previous value.                                   */
+ * "csr_kernel", "coo_chunk", "coo_via_rowptr", "kernel_events"}; returns the previous value.                                   */
 int64_t pygim_set_tunable(const char *name, int64_t value);
 
 #ifdef __cplusplus

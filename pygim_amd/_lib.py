@@ -15,7 +15,7 @@ EXPORTS = [
     "pygim_init_ranks", "pygim_init_units", "pygim_release", "pygim_is_initialized", "pygim_last_error",
     "pygim_device_info", "pygim_group_create", "pygim_group_free", "pygim_spmm_run_group",
     "pygim_grande_run_group", "pygim_spmv_run_group", "pygim_block_run", "pygim_group_timers",
-    "pygim_group_info", "pygim_set_tunable",
+    "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -41,6 +41,10 @@ def lib():
                 f"{LIB_PATH} not found: build the HIP extension first "
                 f"(`make -C pygim_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 f"This backend has no CPU fallback.")
+        # torch ships its own libamdhip64; load it FIRST so that this library binds to the same
+        # HIP runtime (device pointers, streams and events are shared with torch tensors)
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(LIB_PATH)
         c_i64, c_int, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
         p_i64 = ctypes.POINTER(ctypes.c_int64)
@@ -57,6 +61,7 @@ def lib():
         L.pygim_block_run.argtypes = [c_i64, c_int, vp, c_i64, vp, c_i64, c_i64, c_int, vp]
         L.pygim_group_timers.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double)]
         L.pygim_group_info.argtypes = [c_i64, p_i64]
+        L.pygim_group_kernel_ms.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double), p_i64, c_int]
         L.pygim_set_tunable.argtypes = [ctypes.c_char_p, c_i64]
         L.pygim_set_tunable.restype = c_i64
         _lib = L
@@ -155,3 +160,12 @@ def group_info(handle):
 
 def set_tunable(name, value):
     return int(lib().pygim_set_tunable(name.encode(), int(value)))
+
+
+def group_kernel_ms(handle, reset=True):
+    """(sum of milliseconds, launches) of the dominant kernel since the last reset
+    (needs set_tunable('kernel_events', 1))."""
+    ms = ctypes.c_double(0)
+    n = ctypes.c_int64(0)
+    check(lib().pygim_group_kernel_ms(int(handle), ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+    return ms.value, n.value

@@ -332,6 +332,142 @@ __global__ __launch_bounds__(256) void k_csr_sub(const uint32_t *__restrict__ ro
 }
 
 // ---------------------------------------------------------------------------
+// CSR, L2-blocked ("panel") form -- the fast path for wide feature rows.
+//
+// Why: one gathered row of X is h*sizeof(T) bytes (1 KiB at h=256 f32) and X does
+// not fit the 4 MiB L2 of an XCD, so the row-per-wave kernel is bound by the
+// Infinity-Cache/HBM gather rate.  Here the work is cut twice:
+//   * features into 128-byte SLICES (one cache line per gathered row); slice s is
+//     handled by workgroups with blockIdx % nslices == s, which the dispatcher's
+//     round-robin places on one XCD when nslices == 8 -- that XCD's L2 then only
+//     ever holds its own slice of X (speed only; results do not depend on placement);
+//   * columns into PANELS sized so that panel x slice fits the L2; one launch per
+//     panel, every launch sweeps all rows restricted to that panel's columns.
+// A lane group of 2^LOG_LPR lanes (8 for 16-byte vectors) owns one (row, slice);
+// a wave carries 64>>LOG_LPR rows.  Rows are visited in degree-sorted order
+// (perm) so the rows that share a wave have similar lengths.  For panels after
+// the first the accumulator STARTS from C, and entries are added in stored order,
+// so the float result is bit-identical to one sequential pass over the row.
+// seg_begin/seg_end: first/last stored entry of (sorted row i, this panel).
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int LOG_LPR>
+__global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ perm,
+                                                   const uint32_t *__restrict__ seg_begin,
+                                                   const uint32_t *__restrict__ seg_end,
+                                                   const uint32_t *__restrict__ colind,
+                                                   const T *__restrict__ vals, const T *__restrict__ X,
+                                                   int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nrows,
+                                                   uint32_t w, uint32_t nslices, int load_c) {
+    using A = typename AccOf<T>::type;
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr int G = 64 >> LOG_LPR;  // rows per wave
+    const int lane = threadIdx.x & 63;
+    const int li = lane & (LPR - 1);
+    const int gbase = lane & ~(LPR - 1);
+    const uint32_t slice = blockIdx.x % nslices;
+    const uint32_t rb = blockIdx.x / nslices;
+    const uint64_t i64 = ((uint64_t)rb * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + (lane >> LOG_LPR);
+    const bool row_ok = i64 < nrows;
+    const uint32_t i = row_ok ? (uint32_t)i64 : 0u;
+    uint32_t s = 0, len = 0, row = 0;
+    if (row_ok) {
+        row = perm ? perm[i] : i;
+        s = seg_begin[i];
+        len = seg_end[i] - s;
+    }
+    const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
+    const bool lane_on = row_ok && f0 < w;
+    T *crow = C + (int64_t)row * ldc;
+    A acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) acc[k] = A(0);
+    if (load_c && lane_on) {
+        if (f0 + VEC <= w) {
+            T old[VEC];
+            load_vec<T, VEC>(crow + f0, old);
+#pragma unroll
+            for (int k = 0; k < VEC; k++) acc[k] = to_acc<T>(old[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; k++)
+                if (f0 + k < w) acc[k] = to_acc<T>(crow[f0 + k]);
+        }
+    }
+    uint32_t maxlen = len;
+#pragma unroll
+    for (int off = 32; off >= LPR; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+    maxlen = rfl(maxlen);
+    const T *xlane = X + f0;
+    uint32_t mycol_next = (li < len) ? __builtin_nontemporal_load(colind + s + li) : 0u;
+    T myval_next = T(1);
+    if (vals) myval_next = (li < len) ? __builtin_nontemporal_load(vals + s + li) : T(0);
+    for (uint32_t e0 = 0; e0 < maxlen; e0 += LPR) {
+        const uint32_t mycol = mycol_next;
+        const T myval = myval_next;
+        const uint32_t nx = e0 + LPR + li;
+        if (e0 + LPR < maxlen) {
+            mycol_next = (nx < len) ? __builtin_nontemporal_load(colind + s + nx) : 0u;
+            if (vals) myval_next = (nx < len) ? __builtin_nontemporal_load(vals + s + nx) : T(0);
+        }
+        T x[LPR][VEC];
+#pragma unroll
+        for (int j = 0; j < LPR; j++) {
+            const uint32_t c = (uint32_t)__shfl((int)mycol, gbase + j);
+            if (lane_on && e0 + j < len) load_vec<T, VEC>(xlane + (int64_t)c * ldx, x[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < LPR; j++) {
+            if (vals) {
+                const T v = shfl_lane<T>(myval, gbase + j);
+                if (lane_on && e0 + j < len) axpy<T, VEC>(acc, to_acc<T>(v), x[j]);
+            } else {
+                if (lane_on && e0 + j < len) add_only<T, VEC>(acc, x[j]);
+            }
+        }
+    }
+    if (lane_on) {
+        if (f0 + VEC <= w) {
+            T o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; k++) o[k] = from_acc<T>(acc[k]);
+            store_vec<T, VEC>(crow + f0, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; k++)
+                if (f0 + k < w) crow[f0 + k] = from_acc<T>(acc[k]);
+        }
+    }
+}
+
+// panel pointers: pp[p * nrows + i] = first stored entry of sorted row i whose column
+// is >= p * panel_cols (p = 0..npanels; pp[0] = row start, pp[npanels] = row end)
+__global__ void k_build_panel_ptr(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ rowptr,
+                                  const uint32_t *__restrict__ colind, uint32_t nrows, uint32_t npanels,
+                                  uint32_t panel_cols, uint32_t *__restrict__ pp) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)nrows * (npanels + 1)) return;
+    const uint32_t i = (uint32_t)(t % nrows);
+    const uint32_t p = (uint32_t)(t / nrows);
+    const uint32_t row = perm ? perm[i] : i;
+    uint32_t lo = rowptr[row], hi = rowptr[row + 1];
+    if (p == 0) {
+        pp[t] = lo;
+        return;
+    }
+    if (p == npanels) {
+        pp[t] = hi;
+        return;
+    }
+    const uint64_t bound = (uint64_t)p * panel_cols;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)colind[mid] < bound) lo = mid + 1;
+        else hi = mid;
+    }
+    pp[t] = lo;
+}
+
+// ---------------------------------------------------------------------------
 // COO, equal-nnz split (rows may straddle waves), "wide" layout.
 // Wave c owns stored entries [c*chunk, (c+1)*chunk).  Row segments closed on
 // both sides are written straight to C (C was zero-filled, or holds the running

@@ -59,6 +59,10 @@ struct Tunables {
     int64_t csr_kernel = 0;             // 0 = auto, 1 = force wide, 2 = force sub-wave
     int64_t coo_chunk = 512;            // entries per wave in the nnz-split COO kernel
     int64_t coo_via_rowptr = 0;         // 1 = run COO groups through the CSR kernels (derived rowptr)
+    int64_t panel_mode = 0;             // 0 = auto (cost rule), 1 = force the L2-blocked panel kernel, 2 = never
+    int64_t panel_bytes = 2 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
+    int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
+    int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
 
 struct Part {
@@ -73,6 +77,10 @@ struct Part {
     uint32_t *d_tasks = nullptr;  // (row, s, e) x n_tasks
     uint32_t *d_desc = nullptr;   // (row, first_task, n_tasks) x n_long
     uint32_t long_thresh = 0;
+    // L2-blocked plan: degree-sorted row order + per-panel entry ranges of every row
+    uint32_t *d_perm = nullptr;   // sorted position -> row
+    uint32_t *d_pp = nullptr;     // (npanels + 1) x nrows panel pointers, sorted order
+    uint32_t npanels = 0, panel_cols = 0;
     std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
 };
 
@@ -92,6 +100,10 @@ struct Group {
     size_t d_ptrs_n = 0;
     int *d_flags = nullptr;
     double timers[5] = {0, 0, 0, 0, 0};
+    // HIP-event pairs around the dominant kernel (tunable kernel_events), resolved on query
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    double ev_ms = 0;
+    int64_t ev_count = 0;
 };
 
 struct Context {
@@ -151,12 +163,18 @@ void free_group(Group *g) {
         if (p.own_vals && p.vals) (void)hipFree(p.vals);
         if (p.d_tasks) (void)hipFree(p.d_tasks);
         if (p.d_desc) (void)hipFree(p.d_desc);
+        if (p.d_perm) (void)hipFree(p.d_perm);
+        if (p.d_pp) (void)hipFree(p.d_pp);
     }
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
     if (g->d_flags) (void)hipFree(g->d_flags);
+    for (auto &e : g->ev_pending) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
     delete g;
 }
 
@@ -181,6 +199,24 @@ int pick_vec_bytes(size_t es, const void *X, int64_t ldx, const void *C, int64_t
     return (int)es;
 }
 
+struct KernelTimer {
+    Group *g;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(Group *g_, hipStream_t st_) : g(g_), st(st_) {
+        if (g_tune.kernel_events && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, st);
+        else
+            a = b = nullptr;
+    }
+    void stop() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        g->ev_pending.emplace_back(a, b);
+        a = b = nullptr;
+    }
+};
+
 template <typename T, int VEC>
 int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate,
                    hipStream_t st) {
@@ -197,18 +233,44 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         const size_t need = (size_t)nchunks * 2 * w * sizeof(T);
         if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
         dim3 grid((nchunks + 3) / 4, (lanes_needed + 63) / 64);
+        KernelTimer kt(g, st);
         hipLaunchKernelGGL((k_coo_wide<T, VEC>), grid, dim3(256), 0, st, p.rowind, p.colind, vals,
                            (uint32_t)p.nnz, chunk, X, ldx, C, ldc, w, (T *)g->scratch, accumulate ? 1 : 0);
+        kt.stop();
         hipLaunchKernelGGL((k_coo_fixup<T>), dim3((nchunks + 3) / 4), dim3(256), 0, st, p.rowind,
                            (uint32_t)p.nnz, chunk, nchunks, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+    // L2-blocked panel sweep (fast path for wide feature rows; see k_csr_panel)
+    if constexpr (VEC * sizeof(T) == 16) {
+        bool use_panel = p.d_pp != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
+        if (use_panel && g_tune.panel_mode == 0)
+            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
+        if (use_panel) {
+            constexpr int LOG_LPR = 3;
+            constexpr uint32_t F = VEC << LOG_LPR;            // elements per 128-byte slice
+            const uint32_t nslices = (w + F - 1) / F;
+            const uint32_t rows_per_block = 4 * (64 >> LOG_LPR);
+            const uint32_t row_blocks = (nrows + rows_per_block - 1) / rows_per_block;
+            KernelTimer kt(g, st);
+            for (uint32_t q = 0; q < p.npanels; q++) {
+                const uint32_t *sb = p.d_pp + (size_t)q * nrows;
+                hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR>), dim3(row_blocks * nslices), dim3(256), 0, st,
+                                   p.d_perm, sb, sb + nrows, p.colind, vals, X, ldx, C, ldc, nrows, w, nslices,
+                                   (q > 0 || accumulate) ? 1 : 0);
+            }
+            kt.stop();
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
     }
     // CSR kernels (native CSR, or COO through its derived rowptr)
     bool wide = lanes_needed > 32;
     if (g_tune.csr_kernel == 1) wide = true;
     if (g_tune.csr_kernel == 2 && lanes_needed <= 32) wide = false;
     if (nrows > 0) {
+        KernelTimer kt(g, st);
         if (wide) {
             dim3 grid((nrows + 3) / 4, (lanes_needed + 63) / 64);
             hipLaunchKernelGGL((k_csr_wide<T, VEC>), grid, dim3(256), 0, st, p.rowptr, p.colind, vals, X, ldx, C,
@@ -221,6 +283,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             hipLaunchKernelGGL((k_csr_sub<T, VEC>), dim3((waves + 3) / 4), dim3(256), 0, st, p.rowptr, p.colind,
                                vals, X, ldx, C, ldc, nrows, w, p.long_thresh, accumulate ? 1 : 0, log_lpr);
         }
+        kt.stop();
     }
     if (p.n_tasks > 0) {
         const size_t need = (size_t)p.n_tasks * w * sizeof(T);
@@ -488,6 +551,10 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "csr_kernel") slot = &g_tune.csr_kernel;
     else if (n == "coo_chunk") slot = &g_tune.coo_chunk;
     else if (n == "coo_via_rowptr") slot = &g_tune.coo_via_rowptr;
+    else if (n == "kernel_events") slot = &g_tune.kernel_events;
+    else if (n == "panel_mode") slot = &g_tune.panel_mode;
+    else if (n == "panel_bytes") slot = &g_tune.panel_bytes;
+    else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
     if (!slot) return -1;
     const int64_t old = *slot;
     *slot = value;
@@ -613,6 +680,31 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                 hipMemcpy(p.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
         }
+        // L2-blocked plan (CSR groups): rows sorted by degree, columns cut into panels whose
+        // 128-byte feature slice fits the L2 budget
+        if (format == PYGIM_CSR && g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
+            const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
+            const uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
+            const bool worth = g_tune.panel_mode == 1 || npan == 1 ||
+                               (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
+            if (worth) {
+                std::vector<uint32_t> perm((size_t)p.nrows);
+                for (int64_t r = 0; r < p.nrows; r++) perm[(size_t)r] = (uint32_t)r;
+                const uint32_t *rp = h_rowptr.data();
+                std::stable_sort(perm.begin(), perm.end(), [rp](uint32_t a, uint32_t b) {
+                    return (rp[a + 1] - rp[a]) > (rp[b + 1] - rp[b]);
+                });
+                p.npanels = npan;
+                p.panel_cols = (uint32_t)((p.ncols + npan - 1) / npan);
+                const size_t pp_elems = (size_t)(npan + 1) * (size_t)p.nrows;
+                if (hipMalloc((void **)&p.d_perm, perm.size() * 4) != hipSuccess ||
+                    hipMalloc((void **)&p.d_pp, pp_elems * 4) != hipSuccess ||
+                    hipMemcpy(p.d_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail(PYGIM_ERR_HIP, "panel plan upload"));
+                hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
+                                   p.d_perm, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, p.d_pp);
+            }
+        }
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;
@@ -640,6 +732,28 @@ int pygim_group_timers(int64_t handle, double out_ms[5]) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     for (int i = 0; i < 5; i++) out_ms[i] = g->timers[i];
+    return 0;
+}
+
+int pygim_group_kernel_ms(int64_t handle, double *sum_ms, int64_t *count, int reset) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    for (auto &e : g->ev_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+            g->ev_ms += ms;
+            g->ev_count++;
+        }
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    g->ev_pending.clear();
+    if (sum_ms) *sum_ms = g->ev_ms;
+    if (count) *count = g->ev_count;
+    if (reset) {
+        g->ev_ms = 0;
+        g->ev_count = 0;
+    }
     return 0;
 }
 

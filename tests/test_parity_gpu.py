@@ -1,0 +1,256 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (include/pygim_hip.h).
+
+Run on the GPU box: python -m pytest tests -m gpu.  Bit-exact for the integer types;
+floats: bit-exact wherever one wave sums a row in stored order, and within
+BASELINE.json's 1e-5 relative bound (relative to |A|.|x|) when rows are cut.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import oracle
+from conftest import ALL_DTYPES, NP_DTYPES, coalesce, driver_features, random_csr
+from pygim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CODE = {"INT8": _lib.INT8, "INT16": _lib.INT16, "INT32": _lib.INT32, "INT64": _lib.INT64,
+        "FLT32": _lib.FLT32, "DBL64": _lib.DBL64}
+CODE_OF_NP = {np.dtype(NP_DTYPES[k]): v for k, v in CODE.items()}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def backend():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.init_ranks(1)
+    yield
+    _lib.release()
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else 0
+
+
+def run_group_host(fmt, idx0s, cols, vals, nrows, ncols, xs, h, kind="spmm", n_dense=None, dense_cols=None,
+                   lds=None):
+    """create -> run -> free with HOST (numpy) pointers; returns out[nrows[0], h]"""
+    dt = xs[0].dtype
+    idx0s = [np.ascontiguousarray(a, dtype=np.int32) for a in idx0s]
+    cols = [np.ascontiguousarray(a, dtype=np.int32) for a in cols]
+    vals = None if vals is None else [np.ascontiguousarray(v, dtype=dt) for v in vals]
+    xs = [np.ascontiguousarray(x) for x in xs]
+    n = len(cols)
+    if n_dense is None:
+        n_dense = [len(xs)] * n
+        dense_cols = [x.shape[1] if x.ndim == 2 else 1 for x in xs] * n
+    handle = _lib.group_create(_lib.COO if fmt == "COO" else _lib.CSR, CODE_OF_NP[np.dtype(dt)],
+                               [_ptr(a) for a in idx0s], [_ptr(a) for a in cols],
+                               None if vals is None else [_ptr(v) for v in vals], nrows, ncols,
+                               [len(c) for c in cols], n_dense, dense_cols, h)
+    try:
+        out = np.full((nrows[0], h if kind != "spmv" else len(xs)), 77, dtype=dt)
+        if kind == "spmm":
+            _lib.spmm_run_group(handle, [_ptr(x) for x in xs], _ptr(out))
+        elif kind == "grande":
+            _lib.grande_run_group(handle, [_ptr(x) for x in xs], lds, _ptr(out))
+        else:
+            _lib.spmv_run_group(handle, [_ptr(x) for x in xs], _ptr(out))
+        info = _lib.group_info(handle)
+    finally:
+        _lib.group_free(handle)
+    return out, info
+
+
+def abs_scale(rowptr, col, vals, x):
+    n = len(rowptr) - 1
+    v = np.ones(len(col)) if vals is None else np.abs(vals.astype(np.float64))
+    a = sp.csr_matrix((v, col.copy(), rowptr.copy()), shape=(n, x.shape[0]))
+    return a @ np.abs(x.astype(np.float64))
+
+
+def test_golden_vectors_on_gpu():
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("spmm_") and f.endswith(".npz"))
+    assert len(files) >= 20
+    for f in files:
+        z = np.load(os.path.join(GOLDEN, f))
+        fmt = str(z["fmt"])
+        x, y = z["x"], z["y"]
+        vals = z["vals"] if "vals" in z.files else None
+        idx0 = z["rowptr"] if fmt == "CSR" else z["row"]
+        nrows = y.shape[0]
+        out, _ = run_group_host(fmt, [idx0], [z["col"]], None if vals is None else [vals], [nrows], [x.shape[0]],
+                                [x], x.shape[1])
+        if "real" in f:
+            rp = z["rowptr"]
+            assert np.all(np.abs(out.astype(np.float64) - y) <= 1e-5 * abs_scale(rp, z["col"], vals, x) + 1e-30), f
+        else:
+            assert np.array_equal(out, y), f
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+@pytest.mark.parametrize("fmt", ["CSR", "COO"])
+def test_widths_and_long_rows(rng, dt, fmt):
+    """every element type x format over odd / tiny / wide feature counts, with rows long enough
+    to be cut into segments (threshold lowered so the long-row kernels run)"""
+    npdt = NP_DTYPES[dt]
+    old = _lib.set_tunable("long_row_threshold", 256)
+    try:
+        rowptr, col = random_csr(rng, 500, 400, 11, empty_frac=0.2, long_rows=[(0, 3000), (77, 257), (499, 1200)])
+        for h in (1, 3, 9, 32, 100, 256, 300):
+            x = driver_features(rng, 400, h, npdt)
+            if fmt == "CSR":
+                ref = oracle.spmm_csr(rowptr, col, None, x)
+                out, info = run_group_host("CSR", [rowptr], [col], None, [500], [400], [x], h)
+                assert info["n_long_rows"] == 3
+            else:
+                r, c, v = coalesce(rowptr, col, npdt)
+                ref = oracle.spmm_coo(r, c, v, x, 500)
+                out, info = run_group_host("COO", [r], [c], [v], [500], [400], [x], h)
+            # driver features are small integers: float sums are exact in any order too
+            assert np.array_equal(out, ref), (dt, fmt, h)
+    finally:
+        _lib.set_tunable("long_row_threshold", old)
+
+
+@pytest.mark.parametrize("dt", ["INT8", "INT32", "FLT32", "DBL64"])
+def test_valued_entries(rng, dt):
+    npdt = NP_DTYPES[dt]
+    rowptr, col = random_csr(rng, 300, 300, 25)
+    if np.issubdtype(npdt, np.integer):
+        vals = rng.integers(-5, 6, size=len(col)).astype(npdt)
+        x = driver_features(rng, 300, 64, npdt)
+    else:
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+        x = (rng.random((300, 64)) * 2 - 1).astype(npdt)
+    ref = oracle.spmm_csr(rowptr, col, vals, x)
+    out, info = run_group_host("CSR", [rowptr], [col], [vals], [300], [300], [x], 64)
+    assert info["all_ones"] == 0
+    # one wave per row, stored order, separate multiply and add: identical to the CPU loop
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("fmt", ["CSR", "COO"])
+@pytest.mark.parametrize("sp_parts,ds_parts", [(1, 1), (2, 1), (3, 4), (8, 3), (1, 8)])
+def test_group_partitions(rng, fmt, sp_parts, ds_parts):
+    npdt = np.int32
+    n, h = 333, 100
+    rowptr, col = random_csr(rng, n, n, 9)
+    x = driver_features(rng, n, h, npdt)
+    a = sp.csr_matrix((np.ones(len(col), dtype=np.int64), col.copy(), rowptr.copy()), shape=(n, n))
+    step = (n + sp_parts - 1) // sp_parts
+    idx0, cols, vals, nrows, ncols = [], [], [], [], []
+    for i in range(sp_parts):
+        blk = a[:, i * step:min(n, (i + 1) * step)].tocsr()
+        blk.sum_duplicates()
+        blk.sort_indices()
+        idx0.append(blk.indptr if fmt == "CSR" else blk.tocoo().row)
+        cols.append(blk.indices)
+        vals.append(blk.data.astype(npdt))
+        nrows.append(n)
+        ncols.append(blk.shape[1])
+    xs = [np.ascontiguousarray(t.numpy()) for t in torch.chunk(torch.from_numpy(x), ds_parts, 1)] if ds_parts > 1 else [x]
+    ref = oracle.group(fmt == "COO", idx0, cols, vals, nrows, ncols, xs, h)
+    out, _ = run_group_host(fmt, idx0, cols, vals, nrows, ncols, xs, h)
+    assert np.array_equal(out, ref)
+
+
+def test_device_pointers_and_block_run(rng):
+    """device-resident operands: no staging, result stays in HBM"""
+    npdt = np.float32
+    rowptr, col = random_csr(rng, 1000, 1000, 30, long_rows=[(5, 6000)])
+    x = (rng.random((1000, 256)) * 2 - 1).astype(npdt)
+    ref = oracle.spmm_csr(rowptr, col, None, x)
+    d = lambda a: torch.from_numpy(a).cuda()
+    drp, dcol, dx = d(rowptr), d(col), d(x)
+    handle = _lib.group_create(_lib.CSR, _lib.FLT32, [drp.data_ptr()], [dcol.data_ptr()], None, [1000], [1000],
+                               [len(col)], [1], [256], 256)
+    out = torch.empty((1000, 256), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.spmm_run_group(handle, [dx.data_ptr()], out.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    scale = abs_scale(rowptr, col, None, x)
+    assert np.all(np.abs(got.astype(np.float64) - ref) <= 1e-5 * scale)
+    short = np.diff(rowptr) <= 4096
+    assert np.array_equal(got[short], ref[short])  # single-wave rows: bit-identical
+    # accumulate form of the block product: C += A.X
+    out2 = out.clone()
+    _lib.block_run(handle, 0, dx.data_ptr(), 256, out2.data_ptr(), 256, 256, True, st)
+    torch.cuda.synchronize()
+    assert np.all(np.abs(out2.cpu().numpy().astype(np.float64) - 2 * ref.astype(np.float64)) <= 2e-5 * scale)
+    _lib.group_free(handle)
+
+
+def test_error_behaviour(rng):
+    rowptr, col = random_csr(rng, 50, 50, 5)
+    x = driver_features(rng, 50, 8, np.int32)
+    r, c, v = coalesce(rowptr, col, np.int32)
+    with pytest.raises(_lib.PygimError) as e:  # unsorted COO
+        run_group_host("COO", [r[::-1].copy()], [c], [v], [50], [50], [x], 8)
+    assert e.value.code == _lib.ERR_UNSORTED
+    bad = col.copy()
+    bad[0] = 50
+    with pytest.raises(_lib.PygimError):  # column id out of range
+        run_group_host("CSR", [rowptr], [bad], None, [50], [50], [x], 8)
+    with pytest.raises(_lib.PygimError):  # dense widths do not add up to h
+        run_group_host("CSR", [rowptr], [col], None, [50], [50], [x], 9)
+    with pytest.raises(_lib.PygimError):
+        _lib.spmm_run_group(12345, [x.ctypes.data], x.ctypes.data)
+    # empty matrix: output must be all zeros
+    out, _ = run_group_host("CSR", [np.zeros(51, np.int32)], [np.zeros(0, np.int32)], None, [50], [50], [x], 8)
+    assert not out.any()
+    out, _ = run_group_host("COO", [np.zeros(0, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0, np.int32)], [50],
+                            [50], [x], 8)
+    assert not out.any()
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_panel_kernel_all_types(rng, dt):
+    """the L2-blocked panel sweep (forced, with tiny panels so every row crosses many of them)"""
+    npdt = NP_DTYPES[dt]
+    old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 40)]
+    try:
+        rowptr, col = random_csr(rng, 700, 500, 14, empty_frac=0.15, long_rows=[(3, 2500), (699, 900)])
+        for h in (16, 32, 100, 256, 300):
+            x = driver_features(rng, 500, h, npdt)
+            ref = oracle.spmm_csr(rowptr, col, None, x)
+            out, _ = run_group_host("CSR", [rowptr], [col], None, [700], [500], [x], h)
+            assert np.array_equal(out, ref), (dt, h)
+    finally:
+        _lib.set_tunable("panel_mode", old[0])
+        _lib.set_tunable("panel_bytes", old[1])
+
+
+@pytest.mark.parametrize("dt", ["FLT32", "DBL64"])
+def test_panel_kernel_keeps_stored_order(rng, dt):
+    """real-valued features and weights: the panel sweep continues each row's running sum from C,
+    so the result is bit-identical to the sequential CPU loop (no tolerance needed)"""
+    npdt = NP_DTYPES[dt]
+    old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 64)]
+    try:
+        rowptr, col = random_csr(rng, 400, 600, 40, long_rows=[(11, 5000)])
+        x = (rng.random((600, 64)) * 2 - 1).astype(npdt)
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+        for v in (None, vals):
+            ref = oracle.spmm_csr(rowptr, col, v, x)
+            out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [400], [600], [x], 64)
+            assert np.array_equal(out, ref)
+        # sp_parts = 2 with panels: second part accumulates onto the first
+        half = 300
+        a = sp.csr_matrix((np.ones(len(col)), col.copy(), rowptr.copy()), shape=(400, 600))
+        parts = [a[:, :half].tocsr(), a[:, half:].tocsr()]
+        for b in parts:
+            b.sort_indices()
+        xs = [x]
+        ref = oracle.group(False, [b.indptr for b in parts], [b.indices for b in parts],
+                           [b.data.astype(npdt) for b in parts], [400, 400], [half, 600 - half], xs, 64)
+        out, _ = run_group_host("CSR", [b.indptr for b in parts], [b.indices for b in parts],
+                                [b.data.astype(npdt) for b in parts], [400, 400], [half, 600 - half], xs, 64)
+        scale = abs_scale(rowptr, col, None, x)
+        assert np.all(np.abs(out.astype(np.float64) - ref) <= 1e-5 * scale)
+    finally:
+        _lib.set_tunable("panel_mode", old[0])
+        _lib.set_tunable("panel_bytes", old[1])
