@@ -112,6 +112,32 @@ __device__ __forceinline__ void store_vec(T *p, const T (&in)[VEC]) {
     }
 }
 
+// streaming (non-temporal) forms: C rows and index arrays are touched once per sweep and must
+// not displace the X panel from the L2
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec_nt(const T *p, T (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = __builtin_nontemporal_load(p);
+    } else {
+        using V = typename VecOf<T, VEC>::type;
+        V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+#pragma unroll
+        for (int k = 0; k < VEC; k++) out[k] = v[k];
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec_nt(T *p, const T (&in)[VEC]) {
+    if constexpr (VEC == 1) {
+        __builtin_nontemporal_store(in[0], p);
+    } else {
+        using V = typename VecOf<T, VEC>::type;
+        V v;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) v[k] = in[k];
+        __builtin_nontemporal_store(v, reinterpret_cast<V *>(p));
+    }
+}
+
 // acc[k] += a * x[k] in val_dt arithmetic.  Floats: separate multiply and add
 // (the file is built with -ffp-contract=off) so that the rounding matches a
 // CPU loop compiled without FMA contraction.
@@ -350,33 +376,86 @@ __global__ __launch_bounds__(256) void k_csr_sub(const uint32_t *__restrict__ ro
 // so the float result is bit-identical to one sequential pass over the row.
 // seg_begin/seg_end: first/last stored entry of (sorted row i, this panel).
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int LOG_LPR>
-__global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ perm,
-                                                   const uint32_t *__restrict__ seg_begin,
-                                                   const uint32_t *__restrict__ seg_end,
+// broadcast lane j of every 8-lane group to the whole group with two DPP moves (no LDS
+// crossbar, no lgkmcnt wait): quad broadcast, then the mirrored half for the other quad.
+template <int J> __device__ __forceinline__ uint32_t bcast8(uint32_t v) {
+    constexpr int q = J & 3;
+    constexpr int quad = q | (q << 2) | (q << 4) | (q << 6);  // quad_perm:[q,q,q,q]
+    // t: lanes 0-3 of a group hold v[q], lanes 4-7 hold v[4+q]
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, quad, 0xF, 0xF, false);
+    // row_half_mirror (0x141): lane i <- lane 7-i inside each group of 8
+    if constexpr (J < 4) {
+        // want v[q] everywhere: lanes 4-7 (banks 1,3) take the mirror of lanes 0-3
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x141, 0xF, 0xA, false);
+    } else {
+        // want v[4+q] everywhere: lanes 0-3 (banks 0,2) take the mirror of lanes 4-7
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x141, 0xF, 0x5, false);
+    }
+}
+template <typename T, int J> __device__ __forceinline__ T bcast8_t(T v) {
+    if constexpr (sizeof(T) == 8) {
+        union { T t; uint32_t u[2]; } in, out;
+        in.t = v;
+        out.u[0] = bcast8<J>(in.u[0]);
+        out.u[1] = bcast8<J>(in.u[1]);
+        return out.t;
+    } else if constexpr (sizeof(T) == 4) {
+        union { T t; uint32_t u; } in, out;
+        in.t = v;
+        out.u = bcast8<J>(in.u);
+        return out.t;
+    } else {
+        return (T)(int32_t)bcast8<J>((uint32_t)(int32_t)v);
+    }
+}
+
+template <typename T, int VEC, bool OFF32>
+__device__ __forceinline__ void gather_vec(const T *__restrict__ xlane, uint32_t c, int64_t ldx, uint32_t row_bytes,
+                                           T (&out)[VEC]) {
+    if constexpr (OFF32) {
+        // X spans < 4 GiB: 32-bit byte offset on a uniform base -> global_load with saddr
+        const uint32_t off = c * row_bytes;
+        load_vec<T, VEC>(reinterpret_cast<const T *>(reinterpret_cast<const char *>(xlane) + off), out);
+    } else {
+        load_vec<T, VEC>(xlane + (int64_t)c * ldx, out);
+    }
+}
+
+template <typename T, int VEC, int LOG_LPR, bool OFF32>
+__global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
+                                                   const uint32_t *__restrict__ item_begin,
+                                                   const uint32_t *__restrict__ item_len,
                                                    const uint32_t *__restrict__ colind,
                                                    const T *__restrict__ vals, const T *__restrict__ X,
-                                                   int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nrows,
-                                                   uint32_t w, uint32_t nslices, int load_c) {
+                                                   int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nitems,
+                                                   uint32_t w, uint32_t nslices, int accumulate) {
     using A = typename AccOf<T>::type;
+    static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int G = 64 >> LOG_LPR;  // rows per wave
     const int lane = threadIdx.x & 63;
     const int li = lane & (LPR - 1);
-    const int gbase = lane & ~(LPR - 1);
     const uint32_t slice = blockIdx.x % nslices;
     const uint32_t rb = blockIdx.x / nslices;
     const uint64_t i64 = ((uint64_t)rb * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + (lane >> LOG_LPR);
-    const bool row_ok = i64 < nrows;
+    const bool row_ok = i64 < nitems;
     const uint32_t i = row_ok ? (uint32_t)i64 : 0u;
+    // work item = (row, first entry, length | FIRST flag): the part of one row that falls into
+    // this launch's column panel; FIRST = no earlier panel holds entries of the row
     uint32_t s = 0, len = 0, row = 0;
+    bool load_c = false;
     if (row_ok) {
-        row = perm ? perm[i] : i;
-        s = seg_begin[i];
-        len = seg_end[i] - s;
+        row = item_row[i];
+        s = item_begin[i];
+        const uint32_t lf = item_len[i];
+        len = lf & 0x7FFFFFFFu;
+        load_c = accumulate || !(lf >> 31);
     }
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
     const bool lane_on = row_ok && f0 < w;
+    // lanes past the width (last slice of an odd h) gather the row start instead: in bounds, discarded
+    const T *xlane = X + (f0 < w ? f0 : 0u);
+    const uint32_t row_bytes = (uint32_t)(ldx * (int64_t)sizeof(T));
     T *crow = C + (int64_t)row * ldc;
     A acc[VEC];
 #pragma unroll
@@ -384,7 +463,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     if (load_c && lane_on) {
         if (f0 + VEC <= w) {
             T old[VEC];
-            load_vec<T, VEC>(crow + f0, old);
+            load_vec_nt<T, VEC>(crow + f0, old);
 #pragma unroll
             for (int k = 0; k < VEC; k++) acc[k] = to_acc<T>(old[k]);
         } else {
@@ -393,44 +472,63 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                 if (f0 + k < w) acc[k] = to_acc<T>(crow[f0 + k]);
         }
     }
-    uint32_t maxlen = len;
+    uint32_t maxlen = len, minlen = len;
 #pragma unroll
-    for (int off = 32; off >= LPR; off >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+    for (int off = 32; off >= LPR; off >>= 1) {
+        maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+        minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, off));
+    }
     maxlen = rfl(maxlen);
-    const T *xlane = X + f0;
+    minlen = rfl(minlen);
+    const uint32_t full_end = minlen & ~(uint32_t)(LPR - 1);  // batches every group fills completely
+
     uint32_t mycol_next = (li < len) ? __builtin_nontemporal_load(colind + s + li) : 0u;
     T myval_next = T(1);
     if (vals) myval_next = (li < len) ? __builtin_nontemporal_load(vals + s + li) : T(0);
-    for (uint32_t e0 = 0; e0 < maxlen; e0 += LPR) {
-        const uint32_t mycol = mycol_next;
-        const T myval = myval_next;
-        const uint32_t nx = e0 + LPR + li;
-        if (e0 + LPR < maxlen) {
-            mycol_next = (nx < len) ? __builtin_nontemporal_load(colind + s + nx) : 0u;
-            if (vals) myval_next = (nx < len) ? __builtin_nontemporal_load(vals + s + nx) : T(0);
-        }
-        T x[LPR][VEC];
-#pragma unroll
-        for (int j = 0; j < LPR; j++) {
-            const uint32_t c = (uint32_t)__shfl((int)mycol, gbase + j);
-            if (lane_on && e0 + j < len) load_vec<T, VEC>(xlane + (int64_t)c * ldx, x[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < LPR; j++) {
-            if (vals) {
-                const T v = shfl_lane<T>(myval, gbase + j);
-                if (lane_on && e0 + j < len) axpy<T, VEC>(acc, to_acc<T>(v), x[j]);
-            } else {
-                if (lane_on && e0 + j < len) add_only<T, VEC>(acc, x[j]);
-            }
-        }
+
+#define PYGIM_PANEL_BATCH(MASKED)                                                                        \
+    {                                                                                                    \
+        const uint32_t mycol = mycol_next;                                                               \
+        const T myval = myval_next;                                                                      \
+        const uint32_t nx = e0 + LPR + li;                                                               \
+        if (e0 + LPR < maxlen) {                                                                         \
+            mycol_next = (nx < len) ? __builtin_nontemporal_load(colind + s + nx) : 0u;                  \
+            if (vals) myval_next = (nx < len) ? __builtin_nontemporal_load(vals + s + nx) : T(0);        \
+        }                                                                                                \
+        uint32_t cj[LPR];                                                                                \
+        cj[0] = bcast8<0>(mycol); cj[1] = bcast8<1>(mycol); cj[2] = bcast8<2>(mycol);                    \
+        cj[3] = bcast8<3>(mycol); cj[4] = bcast8<4>(mycol); cj[5] = bcast8<5>(mycol);                    \
+        cj[6] = bcast8<6>(mycol); cj[7] = bcast8<7>(mycol);                                              \
+        T x[LPR][VEC];                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < LPR; j++)                                                  \
+            gather_vec<T, VEC, OFF32>(xlane, cj[j], ldx, row_bytes, x[j]);                               \
+        if (vals) {                                                                                      \
+            T vj[LPR];                                                                                   \
+            vj[0] = bcast8_t<T, 0>(myval); vj[1] = bcast8_t<T, 1>(myval); vj[2] = bcast8_t<T, 2>(myval); \
+            vj[3] = bcast8_t<T, 3>(myval); vj[4] = bcast8_t<T, 4>(myval); vj[5] = bcast8_t<T, 5>(myval); \
+            vj[6] = bcast8_t<T, 6>(myval); vj[7] = bcast8_t<T, 7>(myval);                                \
+            _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                            \
+                if (!MASKED || e0 + j < len) axpy<T, VEC>(acc, to_acc<T>(vj[j]), x[j]);                  \
+            }                                                                                            \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                            \
+                if (!MASKED || e0 + j < len) add_only<T, VEC>(acc, x[j]);                                \
+            }                                                                                            \
+        }                                                                                                \
     }
+
+    // entries past a row's end carry column 0 (a valid row of X): gathered, then masked out
+    uint32_t e0 = 0;
+    for (; e0 < full_end; e0 += LPR) PYGIM_PANEL_BATCH(false)
+    for (; e0 < maxlen; e0 += LPR) PYGIM_PANEL_BATCH(true)
+#undef PYGIM_PANEL_BATCH
+
     if (lane_on) {
         if (f0 + VEC <= w) {
             T o[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; k++) o[k] = from_acc<T>(acc[k]);
-            store_vec<T, VEC>(crow + f0, o);
+            store_vec_nt<T, VEC>(crow + f0, o);
         } else {
 #pragma unroll
             for (int k = 0; k < VEC; k++)

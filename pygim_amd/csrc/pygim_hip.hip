@@ -60,7 +60,7 @@ struct Tunables {
     int64_t coo_chunk = 512;            // entries per wave in the nnz-split COO kernel
     int64_t coo_via_rowptr = 0;         // 1 = run COO groups through the CSR kernels (derived rowptr)
     int64_t panel_mode = 0;             // 0 = auto (cost rule), 1 = force the L2-blocked panel kernel, 2 = never
-    int64_t panel_bytes = 2 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
+    int64_t panel_bytes = 4 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
     int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
@@ -78,8 +78,11 @@ struct Part {
     uint32_t *d_desc = nullptr;   // (row, first_task, n_tasks) x n_long
     uint32_t long_thresh = 0;
     // L2-blocked plan: degree-sorted row order + per-panel entry ranges of every row
-    uint32_t *d_perm = nullptr;   // sorted position -> row
-    uint32_t *d_pp = nullptr;     // (npanels + 1) x nrows panel pointers, sorted order
+    // L2-blocked plan: per column panel, the list of (row, first entry, length|FIRST) work items
+    // sorted by length (rows without entries in a panel do not appear in its list)
+    uint32_t *d_items = nullptr;            // [3][n_items]: rows | begins | lens
+    size_t n_items = 0;
+    std::vector<size_t> panel_off;          // npanels + 1 offsets into the item arrays
     uint32_t npanels = 0, panel_cols = 0;
     std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
 };
@@ -99,6 +102,9 @@ struct Group {
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
     size_t d_ptrs_n = 0;
     int *d_flags = nullptr;
+    // long rows run beside the main sweep on a forked stream (fork/join with events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double timers[5] = {0, 0, 0, 0, 0};
     // HIP-event pairs around the dominant kernel (tunable kernel_events), resolved on query
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
@@ -163,14 +169,16 @@ void free_group(Group *g) {
         if (p.own_vals && p.vals) (void)hipFree(p.vals);
         if (p.d_tasks) (void)hipFree(p.d_tasks);
         if (p.d_desc) (void)hipFree(p.d_desc);
-        if (p.d_perm) (void)hipFree(p.d_perm);
-        if (p.d_pp) (void)hipFree(p.d_pp);
+        if (p.d_items) (void)hipFree(p.d_items);
     }
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
     if (g->d_flags) (void)hipFree(g->d_flags);
+    if (g->side) (void)hipStreamDestroy(g->side);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     for (auto &e : g->ev_pending) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -242,9 +250,30 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    // long rows (more than long_thresh entries): fixed-size segments on a forked stream, so
+    // that their few, long-running waves overlap the main sweep instead of trailing it
+    bool forked = false;
+    if (p.n_tasks > 0) {
+        const size_t need = (size_t)p.n_tasks * w * sizeof(T);
+        if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
+        HIP_TRY(hipEventRecord(g->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+        dim3 grid((p.n_tasks + 3) / 4, (lanes_needed + 63) / 64);
+        hipLaunchKernelGGL((k_long_segments<T, VEC>), grid, dim3(256), 0, g->side, p.d_tasks, p.n_tasks, p.colind,
+                           vals, X, ldx, (T *)g->scratch, w);
+        hipLaunchKernelGGL((k_long_reduce<T>), dim3((w + 255) / 256, p.n_long), dim3(256), 0, g->side, p.d_desc,
+                           p.n_long, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
+        HIP_TRY(hipEventRecord(g->ev_join, g->side));
+        forked = true;
+    }
+    auto join = [&]() -> int {
+        if (forked) HIP_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
     // L2-blocked panel sweep (fast path for wide feature rows; see k_csr_panel)
     if constexpr (VEC * sizeof(T) == 16) {
-        bool use_panel = p.d_pp != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
+        bool use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
         if (use_panel && g_tune.panel_mode == 0)
             use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
         if (use_panel) {
@@ -252,17 +281,26 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             constexpr uint32_t F = VEC << LOG_LPR;            // elements per 128-byte slice
             const uint32_t nslices = (w + F - 1) / F;
             const uint32_t rows_per_block = 4 * (64 >> LOG_LPR);
-            const uint32_t row_blocks = (nrows + rows_per_block - 1) / rows_per_block;
+            // 32-bit gather offsets when every gathered byte of X sits below 4 GiB
+            const bool off32 = ((uint64_t)p.ncols * (uint64_t)ldx + w) * sizeof(T) < (1ull << 32);
             KernelTimer kt(g, st);
             for (uint32_t q = 0; q < p.npanels; q++) {
-                const uint32_t *sb = p.d_pp + (size_t)q * nrows;
-                hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR>), dim3(row_blocks * nslices), dim3(256), 0, st,
-                                   p.d_perm, sb, sb + nrows, p.colind, vals, X, ldx, C, ldc, nrows, w, nslices,
-                                   (q > 0 || accumulate) ? 1 : 0);
+                const size_t o = p.panel_off[q];
+                const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
+                if (cnt == 0) continue;
+                const uint32_t row_blocks = (cnt + rows_per_block - 1) / rows_per_block;
+                const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
+                if (off32)
+                    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, true>), dim3(row_blocks * nslices), dim3(256), 0,
+                                       st, ir, ib, il, p.colind, vals, X, ldx, C, ldc, cnt, w, nslices,
+                                       accumulate ? 1 : 0);
+                else
+                    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, false>), dim3(row_blocks * nslices), dim3(256), 0,
+                                       st, ir, ib, il, p.colind, vals, X, ldx, C, ldc, cnt, w, nslices,
+                                       accumulate ? 1 : 0);
             }
             kt.stop();
-            HIP_TRY(hipGetLastError());
-            return 0;
+            return join();
         }
     }
     // CSR kernels (native CSR, or COO through its derived rowptr)
@@ -285,17 +323,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         }
         kt.stop();
     }
-    if (p.n_tasks > 0) {
-        const size_t need = (size_t)p.n_tasks * w * sizeof(T);
-        if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
-        dim3 grid((p.n_tasks + 3) / 4, (lanes_needed + 63) / 64);
-        hipLaunchKernelGGL((k_long_segments<T, VEC>), grid, dim3(256), 0, st, p.d_tasks, p.n_tasks, p.colind, vals,
-                           X, ldx, (T *)g->scratch, w);
-        hipLaunchKernelGGL((k_long_reduce<T>), dim3((w + 255) / 256, p.n_long), dim3(256), 0, st, p.d_desc,
-                           p.n_long, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return join();
 }
 
 template <typename T>
@@ -588,6 +616,10 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
     };
     if (hipMalloc((void **)&g->d_flags, 4 * sizeof(int)) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "hipMalloc flags"));
     if (hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), st) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "memset flags"));
+    if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(PYGIM_ERR_HIP, "side stream / events"));
     size_t dpos = 0;
     for (int i = 0; i < n_parts; i++) {
         Part &p = g->parts[i];
@@ -688,21 +720,49 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             const bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                                (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
             if (worth) {
-                std::vector<uint32_t> perm((size_t)p.nrows);
-                for (int64_t r = 0; r < p.nrows; r++) perm[(size_t)r] = (uint32_t)r;
-                const uint32_t *rp = h_rowptr.data();
-                std::stable_sort(perm.begin(), perm.end(), [rp](uint32_t a, uint32_t b) {
-                    return (rp[a + 1] - rp[a]) > (rp[b + 1] - rp[b]);
-                });
                 p.npanels = npan;
                 p.panel_cols = (uint32_t)((p.ncols + npan - 1) / npan);
+                // panel pointers of every row (device binary searches), then the lists on the host
                 const size_t pp_elems = (size_t)(npan + 1) * (size_t)p.nrows;
-                if (hipMalloc((void **)&p.d_perm, perm.size() * 4) != hipSuccess ||
-                    hipMalloc((void **)&p.d_pp, pp_elems * 4) != hipSuccess ||
-                    hipMemcpy(p.d_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-                    return bail(fail(PYGIM_ERR_HIP, "panel plan upload"));
+                uint32_t *d_pp = nullptr;
+                if (hipMalloc((void **)&d_pp, pp_elems * 4) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers"));
                 hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
-                                   p.d_perm, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, p.d_pp);
+                                   (const uint32_t *)nullptr, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, d_pp);
+                std::vector<uint32_t> pp(pp_elems);
+                const hipError_t ce = hipMemcpy(pp.data(), d_pp, pp_elems * 4, hipMemcpyDeviceToHost);
+                (void)hipFree(d_pp);
+                if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
+                const uint32_t *rp = h_rowptr.data();
+                const size_t nr = (size_t)p.nrows;
+                std::vector<uint32_t> rows_v, beg_v, len_v, order;
+                p.panel_off.assign(1, 0);
+                for (uint32_t q = 0; q < npan; q++) {
+                    const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
+                    order.clear();
+                    for (size_t r = 0; r < nr; r++) {
+                        const uint32_t deg = rp[r + 1] - rp[r];
+                        if (deg > p.long_thresh) continue;               // long rows: segment kernels
+                        if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
+                    }
+                    std::stable_sort(order.begin(), order.end(), [lo, hi](uint32_t a, uint32_t b) {
+                        return (hi[a] - lo[a]) > (hi[b] - lo[b]);
+                    });
+                    for (uint32_t r : order) {
+                        rows_v.push_back(r);
+                        beg_v.push_back(lo[r]);
+                        const uint32_t first = (lo[r] == rp[r]) ? 0x80000000u : 0u;  // no entries in earlier panels
+                        len_v.push_back((hi[r] - lo[r]) | first);
+                    }
+                    p.panel_off.push_back(rows_v.size());
+                }
+                p.n_items = rows_v.size();
+                if (p.n_items > 0) {
+                    if (hipMalloc((void **)&p.d_items, 3 * p.n_items * 4) != hipSuccess ||
+                        hipMemcpy(p.d_items, rows_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(p.d_items + p.n_items, beg_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(p.d_items + 2 * p.n_items, len_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
+                        return bail(fail(PYGIM_ERR_HIP, "panel plan upload"));
+                }
             }
         }
     }

@@ -37,14 +37,17 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--clustered", action="store_true")
     ap.add_argument("--budgets", default="1,1.5,2,3,4,6")
+    ap.add_argument("--long-ab", action="store_true")
+    ap.add_argument("--ncols", type=int, default=0, help="restrict column ids to [0, ncols) (cache-residency probe)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     tdt, code = {"f32": (torch.float32, _lib.FLT32), "i32": (torch.int32, _lib.INT32),
                  "i8": (torch.int8, _lib.INT8), "f64": (torch.float64, _lib.DBL64)}[args.dtype]
     n, nnz, d_max = synth.SHAPES[args.shape]
     h = args.hidden
-    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered)
-    x = synth.features(n, h, tdt, seed=0, device=dev)
+    ncols = args.ncols or n
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered, ncols=ncols)
+    x = synth.features(ncols, h, tdt, seed=0, device=dev)
     out = torch.empty((n, h), dtype=tdt, device=dev)
     _lib.init_ranks(1)
     flops = synth.flops(nnz, h)
@@ -56,7 +59,7 @@ def main():
         for k, v in tun.items():
             _lib.set_tunable(k, v)
         t0 = time.perf_counter()
-        hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+        hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [ncols], [nnz], [1], [h], h)
         tc = time.perf_counter() - t0
         best, med = timeit(hd, x, out)
         ref_sum = out.to(torch.float64).sum().item()
@@ -65,6 +68,10 @@ def main():
               f"gather-model {gb / best / 1e9:7.2f} TB/s  create {tc:.2f}s  checksum {ref_sum:.6e}", flush=True)
 
     variant("row-per-wave (panel off)", 2)
+    if args.long_ab:
+        variant("panel 4 MiB, no long-row split", 1, 4, long_row_threshold=1 << 30)
+        variant("panel 4 MiB, long rows > 2048 split", 1, 4, long_row_threshold=2048)
+        _lib.set_tunable("long_row_threshold", 4096)
     for b in [float(v) for v in args.budgets.split(",")]:
         variant(f"panel sweep, L2 budget {b} MiB", 1, b)
     _lib.release()

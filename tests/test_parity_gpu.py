@@ -230,6 +230,7 @@ def test_panel_kernel_keeps_stored_order(rng, dt):
     so the result is bit-identical to the sequential CPU loop (no tolerance needed)"""
     npdt = NP_DTYPES[dt]
     old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 64)]
+    old_long = _lib.set_tunable("long_row_threshold", 1 << 20)  # keep every row in one ordered sweep
     try:
         rowptr, col = random_csr(rng, 400, 600, 40, long_rows=[(11, 5000)])
         x = (rng.random((600, 64)) * 2 - 1).astype(npdt)
@@ -251,6 +252,33 @@ def test_panel_kernel_keeps_stored_order(rng, dt):
                                 [b.data.astype(npdt) for b in parts], [400, 400], [half, 600 - half], xs, 64)
         scale = abs_scale(rowptr, col, None, x)
         assert np.all(np.abs(out.astype(np.float64) - ref) <= 1e-5 * scale)
+    finally:
+        _lib.set_tunable("panel_mode", old[0])
+        _lib.set_tunable("panel_bytes", old[1])
+        _lib.set_tunable("long_row_threshold", old_long)
+
+
+def test_panel_kernel_banded_rows(rng):
+    """rows whose entries sit in one or two column panels only (community-like graphs): a row
+    appears in the work list of a panel only when it has entries there; empty rows give zeros"""
+    npdt = np.float32
+    n, ncols, h = 900, 4000, 96
+    deg = rng.integers(0, 60, size=n)
+    deg[::7] = 0
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.empty(int(rowptr[-1]), dtype=np.int64)
+    for r in range(n):
+        centre = int(r * ncols / n)
+        c = np.clip(centre + rng.integers(-150, 150, size=deg[r]), 0, ncols - 1)
+        col[rowptr[r]:rowptr[r + 1]] = np.sort(c)
+    rowptr, col = rowptr.astype(np.int32), col.astype(np.int32)
+    x = (rng.random((ncols, h)) * 2 - 1).astype(npdt)
+    ref = oracle.spmm_csr(rowptr, col, None, x)
+    old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 256)]
+    try:
+        out, _ = run_group_host("CSR", [rowptr], [col], None, [n], [ncols], [x], h)
+        assert np.array_equal(out, ref)
     finally:
         _lib.set_tunable("panel_mode", old[0])
         _lib.set_tunable("panel_bytes", old[1])
