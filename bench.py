@@ -155,19 +155,25 @@ def main():
     total_flops = synth.flops(nnz, h)
     gflops = total_flops / (ms_per_step * 1e-3) / 1e9
 
-    # roofline of the dominant kernel (k_csr_wide<float,4>) on THIS rank's block
+    # roofline of the dominant kernel on THIS rank's block: HIP events (on the launch stream) bracket
+    # the panel launches of each product; kernel_ms = their sum per product
     alg_bytes = synth.algorithmic_bytes(my_rows, n, my_nnz, h, 4, "CSR", with_values=True)
     k_ms = k_ms_sum / max(k_count, 1)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic = None
     if os.path.exists(args.traffic_json):
         try:
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_product")
         except Exception:
             traffic = None
+    info = _lib.group_info(handle)
+    n_panels = int(info["n_panels"])
+    kname = (f"k_csr_panel<float,4,3,true> ({n_panels} panel launches per product)" if n_panels
+             else "k_csr_wide<float,4>")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "k_csr_wide<float,4>", "kernel_ms": round(k_ms, 4), "launches": k_count,
+                "kernel": kname, "kernel_ms": round(k_ms, 4), "products_timed": k_count,
+                "launches_per_product": max(n_panels, 1),
                 "algorithmic_bytes": alg_bytes,
                 "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
                 "fp32_frac": round(synth.flops(my_nnz, h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None}

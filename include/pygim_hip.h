@@ -135,9 +135,10 @@ int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *
  * [0] load_dense (H2D)  [1] kernel  [2] retrieve (D2H)  [3] merge (always 0: no
  * host merge here)  [4] one-time sparse upload + analysis of the group.       */
 int pygim_group_timers(int64_t handle, double out_ms[5]);
-/* shape / plan of a group: total_rows, total_cols, h, n_parts, n_long_rows
- * (rows split over several waves), all_ones flag.                             */
-int pygim_group_info(int64_t handle, int64_t out[6]);
+/* shape / plan of a group: total_rows, total_cols, h, n_parts, n_long_rows (rows cut into
+ * segments over several waves), all_ones flag, column panels of part 0's L2-blocked plan
+ * (0 = no plan), work items of that plan.                                       */
+int pygim_group_info(int64_t handle, int64_t out[8]);
 /* With tunable "kernel_events" = 1 every block product brackets its dominant kernel (the
  * row-gather kernel, not the long-row tail kernels) with HIP events on the launch stream.
  * This call waits for the pending pairs and returns the accumulated milliseconds and the

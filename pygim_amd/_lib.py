@@ -152,9 +152,9 @@ def group_timers(handle):
 
 
 def group_info(handle):
-    out = (ctypes.c_int64 * 6)()
+    out = (ctypes.c_int64 * 8)()
     check(lib().pygim_group_info(int(handle), out))
-    keys = ["total_rows", "total_cols", "h", "n_parts", "n_long_rows", "all_ones"]
+    keys = ["total_rows", "total_cols", "h", "n_parts", "n_long_rows", "all_ones", "n_panels", "n_items"]
     return dict(zip(keys, list(out)))
 
 

@@ -427,8 +427,9 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ item_len,
                                                    const uint32_t *__restrict__ colind,
                                                    const T *__restrict__ vals, const T *__restrict__ X,
-                                                   int64_t ldx, T *__restrict__ C, int64_t ldc, uint32_t nitems,
-                                                   uint32_t w, uint32_t nslices, int accumulate) {
+                                                   int64_t ldx, int64_t slice_stride, T *__restrict__ C,
+                                                   int64_t ldc, uint32_t nitems, uint32_t w, uint32_t nslices,
+                                                   int accumulate) {
     using A = typename AccOf<T>::type;
     static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     constexpr int LPR = 1 << LOG_LPR;
@@ -454,7 +455,9 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
     const bool lane_on = row_ok && f0 < w;
     // lanes past the width (last slice of an odd h) gather the row start instead: in bounds, discarded
-    const T *xlane = X + (f0 < w ? f0 : 0u);
+    // X is either the caller's row-major matrix (slice_stride = slice width) or the slice-major
+    // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width)
+    const T *xlane = X + (f0 < w ? (int64_t)slice * slice_stride + li * VEC : 0);
     const uint32_t row_bytes = (uint32_t)(ldx * (int64_t)sizeof(T));
     T *crow = C + (int64_t)row * ldc;
     A acc[VEC];
@@ -535,6 +538,33 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                 if (f0 + k < w) crow[f0 + k] = from_acc<T>(acc[k]);
         }
     }
+}
+
+// Slice-major copy of X for the panel sweep: Xs[s][j][0:F] = X[j][s*F : (s+1)*F] (zero padded past
+// the width).  Why: with row-major X the 128-byte slice an XCD gathers sits at a fixed offset inside
+// every row (stride = row bytes, 1 KiB at h = 256 f32); those addresses share their low bits and land
+// in a fraction of the L2's sets/channels, so the XCD's panel is evicted long before the L2 is full.
+// In the slice-major copy a panel of one slice is one contiguous range.
+template <typename T, int VEC, int LOG_LPR>
+__global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrows, uint32_t w, uint32_t nslices,
+                             T *__restrict__ Xs) {
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr uint32_t F = LPR * VEC;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_row = (uint64_t)nslices * LPR;
+    const uint64_t j = t / per_row;
+    if (j >= nrows) return;
+    const uint32_t rem = (uint32_t)(t % per_row);
+    const uint32_t sl = rem >> LOG_LPR, li = rem & (LPR - 1);
+    const uint32_t f0 = sl * F + li * VEC;
+    T v[VEC];
+    if (f0 + VEC <= w) {
+        load_vec_nt<T, VEC>(X + (int64_t)j * ldx + f0, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? X[(int64_t)j * ldx + f0 + k] : T(0);
+    }
+    store_vec<T, VEC>(Xs + ((int64_t)sl * nrows + j) * F + li * VEC, v);
 }
 
 // panel pointers: pp[p * nrows + i] = first stored entry of sorted row i whose column

@@ -62,6 +62,7 @@ struct Tunables {
     int64_t panel_mode = 0;             // 0 = auto (cost rule), 1 = force the L2-blocked panel kernel, 2 = never
     int64_t panel_bytes = 4 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
     int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
+    int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
 
@@ -99,6 +100,8 @@ struct Group {
     size_t stage_in_bytes = 0;
     void *stage_out = nullptr;
     size_t stage_out_bytes = 0;
+    void *xs = nullptr;       // slice-major copy of X for the panel sweep
+    size_t xs_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
     size_t d_ptrs_n = 0;
     int *d_flags = nullptr;
@@ -174,6 +177,7 @@ void free_group(Group *g) {
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
+    if (g->xs) (void)hipFree(g->xs);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->side) (void)hipStreamDestroy(g->side);
@@ -281,9 +285,23 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             constexpr uint32_t F = VEC << LOG_LPR;            // elements per 128-byte slice
             const uint32_t nslices = (w + F - 1) / F;
             const uint32_t rows_per_block = 4 * (64 >> LOG_LPR);
-            // 32-bit gather offsets when every gathered byte of X sits below 4 GiB
-            const bool off32 = ((uint64_t)p.ncols * (uint64_t)ldx + w) * sizeof(T) < (1ull << 32);
+            // gather source: slice-major copy (default) or the caller's row-major X
+            const T *Xg = X;
+            int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st);
+            if (g_tune.panel_pack) {
+                const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
+                if (int rc = ensure(&g->xs, &g->xs_bytes, std::max<size_t>(need, 256))) return rc;
+                const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
+                if (threads > 0)
+                    hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                                       0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)g->xs);
+                Xg = (const T *)g->xs;
+                ldg = F;
+                slice_stride = (int64_t)p.ncols * F;
+            }
+            // 32-bit gather offsets when every gathered byte of a slice sits below 4 GiB of its base
+            const bool off32 = ((uint64_t)p.ncols * (uint64_t)ldg + F) * sizeof(T) < (1ull << 32);
             for (uint32_t q = 0; q < p.npanels; q++) {
                 const size_t o = p.panel_off[q];
                 const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
@@ -292,11 +310,11 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
                 if (off32)
                     hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, true>), dim3(row_blocks * nslices), dim3(256), 0,
-                                       st, ir, ib, il, p.colind, vals, X, ldx, C, ldc, cnt, w, nslices,
+                                       st, ir, ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices,
                                        accumulate ? 1 : 0);
                 else
                     hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, false>), dim3(row_blocks * nslices), dim3(256), 0,
-                                       st, ir, ib, il, p.colind, vals, X, ldx, C, ldc, cnt, w, nslices,
+                                       st, ir, ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices,
                                        accumulate ? 1 : 0);
             }
             kt.stop();
@@ -583,6 +601,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_mode") slot = &g_tune.panel_mode;
     else if (n == "panel_bytes") slot = &g_tune.panel_bytes;
     else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
+    else if (n == "panel_pack") slot = &g_tune.panel_pack;
     if (!slot) return -1;
     const int64_t old = *slot;
     *slot = value;
@@ -817,7 +836,7 @@ int pygim_group_kernel_ms(int64_t handle, double *sum_ms, int64_t *count, int re
     return 0;
 }
 
-int pygim_group_info(int64_t handle, int64_t out[6]) {
+int pygim_group_info(int64_t handle, int64_t out[8]) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     out[0] = g->total_rows;
@@ -828,6 +847,8 @@ int pygim_group_info(int64_t handle, int64_t out[6]) {
     for (auto &p : g->parts) nl += p.n_long;
     out[4] = nl;
     out[5] = g->all_ones ? 1 : 0;
+    out[6] = g->parts[0].d_items ? (int64_t)g->parts[0].npanels : 0;
+    out[7] = (int64_t)g->parts[0].n_items;
     return 0;
 }
 

@@ -1,0 +1,156 @@
+"""sp_parts / ds_parts across the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference spreads its partitions over UPMEM ranks and merges on the host
+(spmm_mul_csr.c:481-551).  Here a partition is a GPU and the merge is an RCCL collective
+over xGMI (backend "nccl"); on CPU the same code runs over "gloo" (tests).
+
+  RowSplitSpMM      sp_parts = world as a ROW split of A (BASELINE config 4; the reference's
+                    row_split is `assert False`, spmm.py:124-125).  X replicated, rank r owns an
+                    nnz-balanced block of rows (partition_by_nnz walk) and produces C[rows_r, :].
+                    Collective: all-gather of the row blocks (only when the full C is needed).
+                    Bit-exact for every dtype: one GPU sums each output row in stored order.
+  ColSplitSpMM      sp_parts = world as the reference's COLUMN split (spmm.py:127-136): rank r
+                    holds A[:, cols_r] (local column ids) and X[cols_r, :], produces a full-size
+                    partial C; collective: sum all-reduce (or reduce-scatter).  Integers exact,
+                    floats reorder (within the 1e-5 bound).
+  FeatureSplitSpMM  ds_parts = world (BASELINE config 5): A replicated, rank r owns the feature
+                    block X[:, f_r] (widths as spmm.py:62-72) and produces C[:, f_r]; no collective
+                    inside the product; all-gather along features re-assembles C.
+
+The local product goes through an *engine*: HipEngine (the C ABI, device tensors) by default.
+Tests inject an engine built on the CPU oracle to exercise the partition/collective logic with
+world_size 2 over gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import partition
+
+
+class HipEngine:
+    """Local block product on this rank's GPU through the C ABI."""
+
+    def __init__(self):
+        from . import _lib, pim_ops
+
+        self._lib = _lib
+        self._code = pim_ops.DTYPE_CODE
+        if not _lib.is_initialized():
+            _lib.init_ranks(dist.get_world_size() if dist.is_initialized() else 1)
+
+    def create(self, rowptr, col, values, nrows, ncols, dtype, h):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.keep = [rowptr.to(dev, torch.int32).contiguous(), col.to(dev, torch.int32).contiguous()]
+        vptr = None
+        if values is not None:
+            self.keep.append(values.to(dev, dtype).contiguous())
+            vptr = [self.keep[2].data_ptr()]
+        self.dtype, self.nrows, self.h = dtype, nrows, h
+        self.handle = self._lib.group_create(self._lib.CSR, self._code[dtype], [self.keep[0].data_ptr()],
+                                             [self.keep[1].data_ptr()], vptr, [nrows], [ncols],
+                                             [self.keep[1].numel()], [1], [h], h)
+        return self
+
+    def run(self, x, out=None):
+        assert x.is_cuda and x.dtype == self.dtype and x.is_contiguous()
+        if out is None:
+            out = torch.empty((self.nrows, self.h), dtype=self.dtype, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        self._lib.spmm_run_group(self.handle, [x.data_ptr()], out.data_ptr(), st)
+        return out
+
+    def free(self):
+        self._lib.group_free(self.handle)
+
+
+def _world(group):
+    if not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+class RowSplitSpMM:
+    def __init__(self, rowptr, col, values, ncols, dtype, h, group=None, balance="nnz", engine_factory=HipEngine):
+        self.group = group
+        self.world, self.rank = _world(group)
+        n = rowptr.numel() - 1
+        self.nrows_total, self.h, self.dtype = n, h, dtype
+        self.split = (partition.partition_by_nnz(rowptr, self.world) if balance == "nnz"
+                      else partition.partition_by_row(n, self.world))
+        r0, r1 = self.split[self.rank], self.split[self.rank + 1]
+        lo, hi = int(rowptr[r0]), int(rowptr[r1])
+        self.r0, self.r1 = r0, r1
+        self.max_rows = max(self.split[i + 1] - self.split[i] for i in range(self.world))
+        self.engine = engine_factory().create((rowptr[r0:r1 + 1] - lo), col[lo:hi],
+                                              None if values is None else values[lo:hi], r1 - r0, ncols, dtype, h)
+
+    def mul_local(self, x_full: torch.Tensor, out=None) -> torch.Tensor:
+        """C[rows_r, :] for this rank (X replicated on every rank)."""
+        return self.engine.run(x_full, out)
+
+    def mul(self, x_full: torch.Tensor) -> torch.Tensor:
+        """Full C on every rank: local product written straight into this rank's slot of the
+        gather buffer, then one all-gather of equal-sized (padded) row blocks."""
+        buf = torch.empty((self.world, self.max_rows, self.h), dtype=self.dtype, device=x_full.device)
+        mine = buf[self.rank]
+        self.engine.run(x_full, mine[: self.r1 - self.r0])
+        if self.world > 1:
+            dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self.group)
+        if all(self.split[i + 1] - self.split[i] == self.max_rows for i in range(self.world)):
+            return buf.view(self.world * self.max_rows, self.h)
+        return torch.cat([buf[i, : self.split[i + 1] - self.split[i]] for i in range(self.world)], dim=0)
+
+
+class ColSplitSpMM:
+    def __init__(self, local_rowptr, local_col, local_values, nrows, local_ncols, dtype, h, group=None,
+                 engine_factory=HipEngine):
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.engine = engine_factory().create(local_rowptr, local_col, local_values, nrows, local_ncols, dtype, h)
+
+    def mul(self, x_local_rows: torch.Tensor, reduce_scatter: bool = False) -> torch.Tensor:
+        """partial = A[:, cols_r] . X[cols_r, :]; summed over ranks (spmm_mul_csr.c:491-502)."""
+        part = self.engine.run(x_local_rows)
+        if self.world == 1:
+            return part
+        if reduce_scatter and part.size(0) % self.world == 0:
+            out = torch.empty((part.size(0) // self.world, part.size(1)), dtype=part.dtype, device=part.device)
+            dist.reduce_scatter_tensor(out, part, op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        return part
+
+
+class FeatureSplitSpMM:
+    def __init__(self, rowptr, col, values, ncols, dtype, h_total, group=None, engine_factory=HipEngine):
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.widths: List[int] = partition.split_widths(h_total, self.world)
+        self.h_total = h_total
+        self.f0 = sum(self.widths[: self.rank])
+        self.nrows = rowptr.numel() - 1
+        self.dtype = dtype
+        self.engine = engine_factory().create(rowptr, col, values, self.nrows, ncols, dtype, self.widths[self.rank])
+
+    def local_features(self, x_full: torch.Tensor) -> torch.Tensor:
+        return x_full[:, self.f0:self.f0 + self.widths[self.rank]].contiguous()
+
+    def mul_local(self, x_block: torch.Tensor) -> torch.Tensor:
+        """C[:, f_r]: no collective (the reference concatenates ds_parts, spmm_mul_csr.c:483,504)."""
+        return self.engine.run(x_block)
+
+    def gather(self, c_block: torch.Tensor) -> torch.Tensor:
+        """Full C on every rank: all-gather of the feature blocks (staged [world, N, wmax], then
+        laid side by side)."""
+        if self.world == 1:
+            return c_block
+        wmax = max(self.widths)
+        stage = torch.zeros((self.world, self.nrows, wmax), dtype=c_block.dtype, device=c_block.device)
+        mine = stage[self.rank]
+        mine[:, : c_block.size(1)] = c_block
+        dist.all_gather_into_tensor(stage.view(-1), mine.reshape(-1).clone(), group=self.group)
+        return torch.cat([stage[i, :, : self.widths[i]] for i in range(self.world)], dim=1)

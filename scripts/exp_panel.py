@@ -73,7 +73,8 @@ def main():
         variant("panel 4 MiB, long rows > 2048 split", 1, 4, long_row_threshold=2048)
         _lib.set_tunable("long_row_threshold", 4096)
     for b in [float(v) for v in args.budgets.split(",")]:
-        variant(f"panel sweep, L2 budget {b} MiB", 1, b)
+        variant(f"panel {b} MiB, row-major X", 1, b, panel_pack=0)
+        variant(f"panel {b} MiB, slice-major X", 1, b, panel_pack=1)
     _lib.release()
 
 

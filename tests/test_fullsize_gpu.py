@@ -1,0 +1,107 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
+properties (the oracle cannot run 58 GFLOP in seconds): column-count checksum, linearity,
+idempotence of repeated runs, and a sampled-rows comparison with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pygim_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def backend():
+    assert torch.cuda.is_available()
+    _lib.init_ranks(1)
+    yield
+    _lib.release()
+
+
+def run(handle, x, n, h):
+    out = torch.empty((n, h), dtype=x.dtype, device=x.device)
+    _lib.spmm_run_group(handle, [x.data_ptr()], out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out
+
+
+def sample_rows_vs_oracle(rowptr, col, vals, x, out, rows):
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    xh = x.cpu().numpy()
+    for r0, r1 in rows:
+        lo, hi = rp[r0], rp[r1]
+        sub_rp = (rp[r0:r1 + 1] - lo).astype(np.int32)
+        sub_col = col[lo:hi].cpu().numpy()
+        sub_val = None if vals is None else vals[lo:hi].cpu().numpy()
+        ref = oracle.spmm_csr(sub_rp, sub_col, sub_val, xh)
+        assert np.array_equal(out[r0:r1].cpu().numpy(), ref), (r0, r1)
+
+
+def test_reddit_csr_f32_h256():
+    """configs[1]: Reddit-shaped CSR, h = 256, FLT32 (the benchmark workload)"""
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["reddit"]
+    h = 256
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    x1 = synth.features(n, h, torch.float32, seed=0, device=dev)
+    x2 = synth.features(n, h, torch.float32, seed=5, device=dev)
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+    try:
+        info = _lib.group_info(hd)
+        assert info["n_panels"] >= 2 and info["n_long_rows"] > 0  # both the panel sweep and the long-row path run
+        c1 = run(hd, x1, n, h)
+        # checksum: sum_i C[i, :] = sum_j colcount[j] * X[j, :]   (small integers: exact in f64)
+        colcount = torch.bincount(col.long(), minlength=n).double()
+        assert torch.equal(c1.double().sum(0), colcount @ x1.double())
+        # linearity (exact: every partial sum is a small integer)
+        c2 = run(hd, x2, n, h)
+        c12 = run(hd, x1 + x2, n, h)
+        assert torch.equal(c12, c1 + c2)
+        # idempotence / determinism
+        assert torch.equal(run(hd, x1, n, h), c1)
+        # real-valued features: deterministic, and within 1e-5 of an f64 evaluation of sampled rows
+        xr = synth.features(n, h, torch.float32, seed=1, device=dev, kind="uniform")
+        cr = run(hd, xr, n, h)
+        assert torch.equal(run(hd, xr, n, h), cr)
+        deg = (rowptr[1:] - rowptr[:-1]).long()
+        longest = int(torch.argmax(deg))
+        sample_rows_vs_oracle(rowptr, col, None, x1, c1, [(0, 300), (n - 200, n), (longest, longest + 1)])
+        rows = torch.tensor([1, 1234, longest, n - 1], device=dev)
+        for r in rows.tolist():
+            cols = col[int(rowptr[r]):int(rowptr[r + 1])].long()
+            ref = xr[cols].double().sum(0)
+            scale = xr[cols].double().abs().sum(0)
+            assert torch.all((cr[r].double() - ref).abs() <= 1e-5 * scale + 1e-30)
+    finally:
+        _lib.group_free(hd)
+
+
+def test_products_coo_i32_h256():
+    """configs[2]: ogbn-products-shaped COO, h = 256, INT32, bit-exact"""
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["ogbn-products"]
+    h = 256
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    row, ccol, val = synth.csr_to_coo_coalesced(rowptr, col, torch.int32)
+    del col
+    m = row.numel()
+    x = synth.features(n, h, torch.int32, seed=0, device=dev)
+    hd = _lib.group_create(_lib.COO, _lib.INT32, [row.data_ptr()], [ccol.data_ptr()], [val.data_ptr()], [n], [n], [m],
+                           [1], [h], h)
+    try:
+        c = run(hd, x, n, h)
+        # checksum modulo 2^32 == exact in int64 here (|sums| stay far below 2^31)
+        w = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, ccol.long(), val.double())
+        assert torch.equal(c.double().sum(0), w @ x.double())
+        assert torch.equal(run(hd, x, n, h), c)
+        # sampled rows against the oracle's COO loop
+        rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.cumsum(torch.bincount(row.long(), minlength=n), 0)
+        xh = x.cpu().numpy()
+        for r0, r1 in ((0, 400), (n - 300, n)):
+            lo, hi = int(rp[r0]), int(rp[r1])
+            ref = oracle.spmm_coo((row[lo:hi] - r0).cpu().numpy(), ccol[lo:hi].cpu().numpy(), val[lo:hi].cpu().numpy(), xh, r1 - r0)
+            assert np.array_equal(c[r0:r1].cpu().numpy(), ref)
+    finally:
+        _lib.group_free(hd)
