@@ -85,6 +85,9 @@ template <typename T> __device__ __forceinline__ T shfl_lane(T v, int src) {
     }
 }
 
+// 16-byte vector of column ids that is only 4-byte aligned (segment starts are arbitrary)
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
 template <typename T> struct VecOf<T, 1> { typedef T type; };
 
@@ -483,48 +486,70 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     }
     maxlen = rfl(maxlen);
     minlen = rfl(minlen);
-    const uint32_t full_end = minlen & ~(uint32_t)(LPR - 1);  // batches every group fills completely
-
-    uint32_t mycol_next = (li < len) ? __builtin_nontemporal_load(colind + s + li) : 0u;
-    T myval_next = T(1);
-    if (vals) myval_next = (li < len) ? __builtin_nontemporal_load(vals + s + li) : T(0);
-
-#define PYGIM_PANEL_BATCH(MASKED)                                                                        \
-    {                                                                                                    \
-        const uint32_t mycol = mycol_next;                                                               \
-        const T myval = myval_next;                                                                      \
-        const uint32_t nx = e0 + LPR + li;                                                               \
-        if (e0 + LPR < maxlen) {                                                                         \
-            mycol_next = (nx < len) ? __builtin_nontemporal_load(colind + s + nx) : 0u;                  \
-            if (vals) myval_next = (nx < len) ? __builtin_nontemporal_load(vals + s + nx) : T(0);        \
-        }                                                                                                \
-        uint32_t cj[LPR];                                                                                \
-        cj[0] = bcast8<0>(mycol); cj[1] = bcast8<1>(mycol); cj[2] = bcast8<2>(mycol);                    \
-        cj[3] = bcast8<3>(mycol); cj[4] = bcast8<4>(mycol); cj[5] = bcast8<5>(mycol);                    \
-        cj[6] = bcast8<6>(mycol); cj[7] = bcast8<7>(mycol);                                              \
-        T x[LPR][VEC];                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < LPR; j++)                                                  \
-            gather_vec<T, VEC, OFF32>(xlane, cj[j], ldx, row_bytes, x[j]);                               \
-        if (vals) {                                                                                      \
-            T vj[LPR];                                                                                   \
-            vj[0] = bcast8_t<T, 0>(myval); vj[1] = bcast8_t<T, 1>(myval); vj[2] = bcast8_t<T, 2>(myval); \
-            vj[3] = bcast8_t<T, 3>(myval); vj[4] = bcast8_t<T, 4>(myval); vj[5] = bcast8_t<T, 5>(myval); \
-            vj[6] = bcast8_t<T, 6>(myval); vj[7] = bcast8_t<T, 7>(myval);                                \
-            _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                            \
-                if (!MASKED || e0 + j < len) axpy<T, VEC>(acc, to_acc<T>(vj[j]), x[j]);                  \
-            }                                                                                            \
-        } else {                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                            \
-                if (!MASKED || e0 + j < len) add_only<T, VEC>(acc, x[j]);                                \
-            }                                                                                            \
-        }                                                                                                \
-    }
-
-    // entries past a row's end carry column 0 (a valid row of X): gathered, then masked out
-    uint32_t e0 = 0;
-    for (; e0 < full_end; e0 += LPR) PYGIM_PANEL_BATCH(false)
-    for (; e0 < maxlen; e0 += LPR) PYGIM_PANEL_BATCH(true)
+    // Column ids are fetched 32 per lane group at a time (lane li holds ids 4*li .. 4*li+3 of the
+    // chunk: one 128-byte request per group instead of four 32-byte ones), then consumed in four
+    // batches of 8 gathers.  The next chunk is requested before the current one is gathered.
+    constexpr uint32_t CH = 4 * LPR;
+    uint32_t c4[4], c4n[4];
+    T v4[4], v4n[4];
+    auto load_chunk = [&](uint32_t e0, uint32_t (&cc)[4], T (&vv)[4]) {
+        const uint32_t base = e0 + 4u * (uint32_t)li;
+        if (base + 4u <= len) {
+            const u32x4_u q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(colind + s + base));
+            cc[0] = q[0]; cc[1] = q[1]; cc[2] = q[2]; cc[3] = q[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) cc[k] = (base + k < len) ? __builtin_nontemporal_load(colind + s + base + k) : 0u;
+        }
+        if (vals) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(vals + s + base + k) : T(0);
+        }
+    };
+    if (maxlen > 0) load_chunk(0, c4n, v4n);
+    for (uint32_t e0 = 0; e0 < maxlen; e0 += CH) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c4[k] = c4n[k];
+            v4[k] = v4n[k];
+        }
+        if (e0 + CH < maxlen) load_chunk(e0 + CH, c4n, v4n);
+        // entries past a row's end carry column 0 (a valid row of X): gathered, then masked out
+#define PYGIM_PANEL_BATCH(B)                                                                               \
+        if (e0 + 8u * B < maxlen) {                                                                        \
+            const uint32_t eb = e0 + 8u * B;                                                               \
+            const bool full = eb + 8u <= minlen; /* every group of the wave has all 8 entries */           \
+            uint32_t cj[LPR];                                                                              \
+            cj[0] = bcast8<2 * B>(c4[0]); cj[1] = bcast8<2 * B>(c4[1]);                                    \
+            cj[2] = bcast8<2 * B>(c4[2]); cj[3] = bcast8<2 * B>(c4[3]);                                    \
+            cj[4] = bcast8<2 * B + 1>(c4[0]); cj[5] = bcast8<2 * B + 1>(c4[1]);                            \
+            cj[6] = bcast8<2 * B + 1>(c4[2]); cj[7] = bcast8<2 * B + 1>(c4[3]);                            \
+            T x[LPR][VEC];                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < LPR; j++)                                                \
+                gather_vec<T, VEC, OFF32>(xlane, cj[j], ldx, row_bytes, x[j]);                             \
+            if (vals) {                                                                                    \
+                T vj[LPR];                                                                                 \
+                vj[0] = bcast8_t<T, 2 * B>(v4[0]); vj[1] = bcast8_t<T, 2 * B>(v4[1]);                      \
+                vj[2] = bcast8_t<T, 2 * B>(v4[2]); vj[3] = bcast8_t<T, 2 * B>(v4[3]);                      \
+                vj[4] = bcast8_t<T, 2 * B + 1>(v4[0]); vj[5] = bcast8_t<T, 2 * B + 1>(v4[1]);              \
+                vj[6] = bcast8_t<T, 2 * B + 1>(v4[2]); vj[7] = bcast8_t<T, 2 * B + 1>(v4[3]);              \
+                _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                          \
+                    if (full || eb + j < len) axpy<T, VEC>(acc, to_acc<T>(vj[j]), x[j]);                   \
+                }                                                                                          \
+            } else if (full) {                                                                             \
+                _Pragma("unroll") for (int j = 0; j < LPR; j++) add_only<T, VEC>(acc, x[j]);               \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                          \
+                    if (eb + j < len) add_only<T, VEC>(acc, x[j]);                                         \
+                }                                                                                          \
+            }                                                                                              \
+        }
+        PYGIM_PANEL_BATCH(0)
+        PYGIM_PANEL_BATCH(1)
+        PYGIM_PANEL_BATCH(2)
+        PYGIM_PANEL_BATCH(3)
 #undef PYGIM_PANEL_BATCH
+    }
 
     if (lane_on) {
         if (f0 + VEC <= w) {
