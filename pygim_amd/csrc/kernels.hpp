@@ -424,7 +424,7 @@ __device__ __forceinline__ void gather_vec(const T *__restrict__ xlane, uint32_t
     }
 }
 
-template <typename T, int VEC, int LOG_LPR, bool OFF32>
+template <typename T, int VEC, int LOG_LPR, bool OFF32, bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
                                                    const uint32_t *__restrict__ item_begin,
                                                    const uint32_t *__restrict__ item_len,
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 4; k++) cc[k] = (base + k < len) ? __builtin_nontemporal_load(colind + s + base + k) : 0u;
         }
-        if (vals) {
+        if constexpr (HAS_VALS) {
 #pragma unroll
             for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(vals + s + base + k) : T(0);
         }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             c4[k] = c4n[k];
-            v4[k] = v4n[k];
+            if constexpr (HAS_VALS) v4[k] = v4n[k];
         }
         if (e0 + CH < maxlen) load_chunk(e0 + CH, c4n, v4n);
         // entries past a row's end carry column 0 (a valid row of X): gathered, then masked out
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
             T x[LPR][VEC];                                                                                 \
             _Pragma("unroll") for (int j = 0; j < LPR; j++)                                                \
                 gather_vec<T, VEC, OFF32>(xlane, cj[j], ldx, row_bytes, x[j]);                             \
-            if (vals) {                                                                                    \
+            if constexpr (HAS_VALS) {                                                                      \
                 T vj[LPR];                                                                                 \
                 vj[0] = bcast8_t<T, 2 * B>(v4[0]); vj[1] = bcast8_t<T, 2 * B>(v4[1]);                      \
                 vj[2] = bcast8_t<T, 2 * B>(v4[2]); vj[3] = bcast8_t<T, 2 * B>(v4[3]);                      \

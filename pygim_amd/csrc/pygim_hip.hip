@@ -54,7 +54,8 @@ size_t dtype_size(int dt) {
 }
 
 struct Tunables {
-    int64_t long_row_threshold = 4096;  // entries per wave before a row is cut into segments
+    int64_t long_row_threshold = 4096;  // rows with more entries are cut into segments
+    int64_t long_segment = 512;         // entries per segment (one wave each) of such a row
     int64_t force_vec_bytes = 0;        // 0 = pick by alignment
     int64_t csr_kernel = 0;             // 0 = auto, 1 = force wide, 2 = force sub-wave
     int64_t coo_chunk = 512;            // entries per wave in the nnz-split COO kernel
@@ -66,6 +67,12 @@ struct Tunables {
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
 
+struct LongPlan {
+    uint32_t n_long = 0, n_tasks = 0, thresh = 0;
+    uint32_t *d_tasks = nullptr;  // (row, s, e) x n_tasks
+    uint32_t *d_desc = nullptr;   // (row, first_task, n_tasks) x n_long
+};
+
 struct Part {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     uint32_t *rowptr = nullptr;  // CSR rowptr, or derived from the COO row index
@@ -74,10 +81,10 @@ struct Part {
     void *vals = nullptr;        // nullptr when all ones
     bool own_rowptr = false, own_rowind = false, own_colind = false, own_vals = false;
     // long-row plan (rows with more than long_row_threshold entries)
-    uint32_t n_long = 0, n_tasks = 0;
-    uint32_t *d_tasks = nullptr;  // (row, s, e) x n_tasks
-    uint32_t *d_desc = nullptr;   // (row, first_task, n_tasks) x n_long
-    uint32_t long_thresh = 0;
+    // lp_base: used by the row-per-wave kernels; lp_panel: used with the panel sweep, where a row is
+    // only "long" when its share of ONE panel would be (threshold x npanels): segment kernels gather
+    // whole rows of X past the L2 blocking, so the panel sweep keeps as many rows as it can
+    LongPlan lp_base, lp_panel;
     // L2-blocked plan: degree-sorted row order + per-panel entry ranges of every row
     // L2-blocked plan: per column panel, the list of (row, first entry, length|FIRST) work items
     // sorted by length (rows without entries in a panel do not appear in its list)
@@ -170,8 +177,10 @@ void free_group(Group *g) {
         if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
         if (p.own_colind && p.colind) (void)hipFree(p.colind);
         if (p.own_vals && p.vals) (void)hipFree(p.vals);
-        if (p.d_tasks) (void)hipFree(p.d_tasks);
-        if (p.d_desc) (void)hipFree(p.d_desc);
+        for (LongPlan *lp : {&p.lp_base, &p.lp_panel}) {
+            if (lp->d_tasks) (void)hipFree(lp->d_tasks);
+            if (lp->d_desc) (void)hipFree(lp->d_desc);
+        }
         if (p.d_items) (void)hipFree(p.d_items);
     }
     if (g->scratch) (void)hipFree(g->scratch);
@@ -254,19 +263,27 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    // long rows (more than long_thresh entries): fixed-size segments on a forked stream, so
-    // that their few, long-running waves overlap the main sweep instead of trailing it
+    // L2-blocked panel sweep or row-per-wave kernels?
+    bool use_panel = false;
+    if constexpr (VEC * sizeof(T) == 16) {
+        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
+        if (use_panel && g_tune.panel_mode == 0)
+            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
+    }
+    const LongPlan &lp = use_panel ? p.lp_panel : p.lp_base;
+    // long rows: fixed-size segments on a forked stream, so that their few, long-running waves
+    // overlap the main sweep instead of trailing it
     bool forked = false;
-    if (p.n_tasks > 0) {
-        const size_t need = (size_t)p.n_tasks * w * sizeof(T);
+    if (lp.n_tasks > 0) {
+        const size_t need = (size_t)lp.n_tasks * w * sizeof(T);
         if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
         HIP_TRY(hipEventRecord(g->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
-        dim3 grid((p.n_tasks + 3) / 4, (lanes_needed + 63) / 64);
-        hipLaunchKernelGGL((k_long_segments<T, VEC>), grid, dim3(256), 0, g->side, p.d_tasks, p.n_tasks, p.colind,
+        dim3 grid((lp.n_tasks + 3) / 4, (lanes_needed + 63) / 64);
+        hipLaunchKernelGGL((k_long_segments<T, VEC>), grid, dim3(256), 0, g->side, lp.d_tasks, lp.n_tasks, p.colind,
                            vals, X, ldx, (T *)g->scratch, w);
-        hipLaunchKernelGGL((k_long_reduce<T>), dim3((w + 255) / 256, p.n_long), dim3(256), 0, g->side, p.d_desc,
-                           p.n_long, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
+        hipLaunchKernelGGL((k_long_reduce<T>), dim3((w + 255) / 256, lp.n_long), dim3(256), 0, g->side, lp.d_desc,
+                           lp.n_long, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
         HIP_TRY(hipEventRecord(g->ev_join, g->side));
         forked = true;
     }
@@ -277,9 +294,6 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     };
     // L2-blocked panel sweep (fast path for wide feature rows; see k_csr_panel)
     if constexpr (VEC * sizeof(T) == 16) {
-        bool use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
-        if (use_panel && g_tune.panel_mode == 0)
-            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
         if (use_panel) {
             constexpr int LOG_LPR = 3;
             constexpr uint32_t F = VEC << LOG_LPR;            // elements per 128-byte slice
@@ -308,14 +322,14 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 if (cnt == 0) continue;
                 const uint32_t row_blocks = (cnt + rows_per_block - 1) / rows_per_block;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
-                if (off32)
-                    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, true>), dim3(row_blocks * nslices), dim3(256), 0,
-                                       st, ir, ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices,
-                                       accumulate ? 1 : 0);
-                else
-                    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, false>), dim3(row_blocks * nslices), dim3(256), 0,
-                                       st, ir, ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices,
-                                       accumulate ? 1 : 0);
+#define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(row_blocks * nslices), dim3(256), 0, st, ir, \
+                       ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices, accumulate ? 1 : 0)
+                if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
+                else if (off32) PYGIM_LAUNCH_PANEL(true, false);
+                else if (vals) PYGIM_LAUNCH_PANEL(false, true);
+                else PYGIM_LAUNCH_PANEL(false, false);
+#undef PYGIM_LAUNCH_PANEL
             }
             kt.stop();
             return join();
@@ -330,14 +344,14 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         if (wide) {
             dim3 grid((nrows + 3) / 4, (lanes_needed + 63) / 64);
             hipLaunchKernelGGL((k_csr_wide<T, VEC>), grid, dim3(256), 0, st, p.rowptr, p.colind, vals, X, ldx, C,
-                               ldc, nrows, w, p.long_thresh, accumulate ? 1 : 0);
+                               ldc, nrows, w, lp.thresh, accumulate ? 1 : 0);
         } else {
             int log_lpr = 0;
             while ((1u << log_lpr) < lanes_needed) log_lpr++;
             const uint32_t rows_per_wave = 64u >> log_lpr;
             const uint32_t waves = (nrows + rows_per_wave - 1) / rows_per_wave;
             hipLaunchKernelGGL((k_csr_sub<T, VEC>), dim3((waves + 3) / 4), dim3(256), 0, st, p.rowptr, p.colind,
-                               vals, X, ldx, C, ldc, nrows, w, p.long_thresh, accumulate ? 1 : 0, log_lpr);
+                               vals, X, ldx, C, ldc, nrows, w, lp.thresh, accumulate ? 1 : 0, log_lpr);
         }
         kt.stop();
     }
@@ -381,17 +395,19 @@ template <typename T> void launch_check_ones(const void *v, uint32_t n, int *fla
 
 // Long-row plan from a host copy of rowptr: rows above the threshold are cut
 // into segments of `thresh` entries.
-void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, std::vector<uint32_t> &tasks,
-                    std::vector<uint32_t> &desc) {
+void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint32_t seg, const std::vector<char> *flags,
+                    std::vector<uint32_t> &tasks, std::vector<uint32_t> &desc) {
+    // a row is long when it has more than `thresh` entries, or -- when flags are given -- when flagged
     for (int64_t r = 0; r < nrows; r++) {
         const uint32_t s = rowptr[r], e = rowptr[r + 1];
-        if (e - s <= thresh) continue;
+        const bool is_long = flags ? (*flags)[(size_t)r] != 0 : (e - s > thresh);
+        if (!is_long || e == s) continue;
         const uint32_t first = (uint32_t)(tasks.size() / 3);
         uint32_t n = 0;
-        for (uint32_t a = s; a < e; a += thresh, n++) {
+        for (uint32_t a = s; a < e; a += seg, n++) {
             tasks.push_back((uint32_t)r);
             tasks.push_back(a);
-            tasks.push_back(std::min(e, a + thresh));
+            tasks.push_back(std::min(e, a + seg));
         }
         desc.push_back((uint32_t)r);
         desc.push_back(first);
@@ -593,6 +609,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     int64_t *slot = nullptr;
     std::string n = name ? name : "";
     if (n == "long_row_threshold") slot = &g_tune.long_row_threshold;
+    else if (n == "long_segment") slot = &g_tune.long_segment;
     else if (n == "force_vec_bytes") slot = &g_tune.force_vec_bytes;
     else if (n == "csr_kernel") slot = &g_tune.csr_kernel;
     else if (n == "coo_chunk") slot = &g_tune.coo_chunk;
@@ -716,21 +733,24 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.vals = nullptr;
             p.own_vals = false;
         }
-        p.long_thresh = (uint32_t)std::max<int64_t>(64, g_tune.long_row_threshold);
         std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
         if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
             return bail(fail(PYGIM_ERR_HIP, "rowptr D2H"));
-        std::vector<uint32_t> tasks, desc;
-        plan_long_rows(h_rowptr.data(), p.nrows, p.long_thresh, tasks, desc);
-        p.n_tasks = (uint32_t)(tasks.size() / 3);
-        p.n_long = (uint32_t)(desc.size() / 3);
-        if (p.n_tasks) {
-            if (hipMalloc((void **)&p.d_tasks, tasks.size() * 4) != hipSuccess ||
-                hipMalloc((void **)&p.d_desc, desc.size() * 4) != hipSuccess ||
-                hipMemcpy(p.d_tasks, tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(p.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-                return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
-        }
+        auto build_long = [&](LongPlan &lp, uint32_t thresh, const std::vector<char> *flags) -> bool {
+            lp.thresh = thresh;
+            std::vector<uint32_t> tasks, desc;
+            const uint32_t seg = (uint32_t)std::min<int64_t>(thresh, std::max<int64_t>(64, g_tune.long_segment));
+            plan_long_rows(h_rowptr.data(), p.nrows, thresh, seg, flags, tasks, desc);
+            lp.n_tasks = (uint32_t)(tasks.size() / 3);
+            lp.n_long = (uint32_t)(desc.size() / 3);
+            if (!lp.n_tasks) return true;
+            return hipMalloc((void **)&lp.d_tasks, tasks.size() * 4) == hipSuccess &&
+                   hipMalloc((void **)&lp.d_desc, desc.size() * 4) == hipSuccess &&
+                   hipMemcpy(lp.d_tasks, tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                   hipMemcpy(lp.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        };
+        const uint32_t base_thresh = (uint32_t)std::min<int64_t>(0x7FFFFFFF, std::max<int64_t>(64, g_tune.long_row_threshold));
+        if (!build_long(p.lp_base, base_thresh, nullptr)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
         // L2-blocked plan (CSR groups): rows sorted by degree, columns cut into panels whose
         // 128-byte feature slice fits the L2 budget
         if (format == PYGIM_CSR && g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
@@ -753,6 +773,15 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                 if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
                 const uint32_t *rp = h_rowptr.data();
                 const size_t nr = (size_t)p.nrows;
+                // rows whose share of ONE panel exceeds the threshold leave the sweep (a lane group walks
+                // an item serially; the segment kernels cut such rows over many waves instead)
+                std::vector<char> heavy(nr, 0);
+                for (uint32_t q = 0; q < npan; q++) {
+                    const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
+                    for (size_t r = 0; r < nr; r++)
+                        if (hi[r] - lo[r] > base_thresh) heavy[r] = 1;
+                }
+                if (!build_long(p.lp_panel, base_thresh, &heavy)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
                 std::vector<uint32_t> rows_v, beg_v, len_v, order;
                 p.panel_off.assign(1, 0);
                 for (uint32_t q = 0; q < npan; q++) {
@@ -760,7 +789,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                     order.clear();
                     for (size_t r = 0; r < nr; r++) {
                         const uint32_t deg = rp[r + 1] - rp[r];
-                        if (deg > p.long_thresh) continue;               // long rows: segment kernels
+                        if (heavy[r]) continue;                          // segment kernels
                         if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
                     }
                     std::stable_sort(order.begin(), order.end(), [lo, hi](uint32_t a, uint32_t b) {
@@ -844,7 +873,7 @@ int pygim_group_info(int64_t handle, int64_t out[8]) {
     out[2] = g->h;
     out[3] = (int64_t)g->parts.size();
     int64_t nl = 0;
-    for (auto &p : g->parts) nl += p.n_long;
+    for (auto &p : g->parts) nl += p.lp_base.n_long;
     out[4] = nl;
     out[5] = g->all_ones ? 1 : 0;
     out[6] = g->parts[0].d_items ? (int64_t)g->parts[0].npanels : 0;
