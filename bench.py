@@ -168,7 +168,7 @@ def main():
             traffic = None
     info = _lib.group_info(handle)
     n_panels = int(info["n_panels"])
-    kname = (f"k_csr_panel<float,4,3,true> ({n_panels} panel launches per product)" if n_panels
+    kname = (f"k_slice_pack + k_csr_panel<float,4,3,true,false> x {n_panels} panel launches per product" if n_panels
              else "k_csr_wide<float,4>")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
