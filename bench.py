@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU, 2 otherwise)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
 
@@ -97,12 +98,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (PYGIM_BENCH_BACKEND=gloo with several ranks on one GPU is a logic check of the N>1 path only)
+    backend = os.environ.get("PYGIM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n, nnz, d_max = synth.SHAPES[args.shape]
     h = args.hidden
@@ -113,24 +120,47 @@ def main():
 
     _lib.init_ranks(world)
     _lib.set_tunable("kernel_events", 1)
-    split = nnz_balanced_row_split(rowptr.cpu(), world)
-    r0, r1 = split[rank], split[rank + 1]
-    lo, hi = int(rowptr[r0]), int(rowptr[r1])
-    my_rowptr = (rowptr[r0:r1 + 1] - lo).contiguous()
-    my_col = col[lo:hi].contiguous()
-    my_rows, my_nnz = r1 - r0, hi - lo
-    handle = _lib.group_create(_lib.CSR, _lib.FLT32, [my_rowptr.data_ptr()], [my_col.data_ptr()], None,
-                               [my_rows], [n], [my_nnz], [1], [h], h)
-    max_rows = max(split[i + 1] - split[i] for i in range(world))
-    # gather buffer: world blocks of max_rows rows; rank r's block is written in place by the kernel
-    gathered = torch.empty((world, max_rows, h), dtype=torch.float32, device=dev)
-    mine = gathered[rank]
+    rowptr_cpu = rowptr.cpu()
+    split = nnz_balanced_row_split(rowptr_cpu, world)
+    # each rank's row block is cut again into `chunks` nnz-balanced pieces so that the all-gather of
+    # piece k (RCCL's stream) overlaps the product of piece k+1 (this stream)
+    K = max(1, args.chunks if args.chunks > 0 else (2 if world > 1 else 1))
+
+    def chunk_bounds(r):
+        a, bnd = split[r], split[r + 1]
+        sub = nnz_balanced_row_split(rowptr_cpu[a:bnd + 1] - rowptr_cpu[a], K)
+        return [a + v for v in sub]
+
+    bounds = [chunk_bounds(r) for r in range(world)]
+    mine_b = bounds[rank]
+    handles, outs, gathers = [], [], []
+    my_rows = my_nnz = 0
+    keep = []
+    for c in range(K):
+        c0, c1 = mine_b[c], mine_b[c + 1]
+        lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
+        rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
+        col_c = col[lo:hi].contiguous()
+        keep += [rp_c, col_c]
+        handles.append(_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None,
+                                         [c1 - c0], [n], [hi - lo], [1], [h], h))
+        pad_rows = max(bounds[r][c + 1] - bounds[r][c] for r in range(world))
+        # gather buffer of piece c: world blocks of pad_rows rows; this rank's block is written in place
+        g = torch.empty((world, max(pad_rows, 1), h), dtype=torch.float32, device=dev)
+        gathers.append(g)
+        outs.append(g[rank])
+        my_rows += c1 - c0
+        my_nnz += hi - lo
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        _lib.spmm_run_group(handle, [x.data_ptr()], mine.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1))
+        pending = []
+        for c in range(K):
+            _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
+            if world > 1:
+                pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
+        for wk in pending:
+            wk.wait()  # stream-level wait, the host does not block
 
     def fence():
         if world > 1:
@@ -140,13 +170,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    _lib.group_kernel_ms(handle, reset=True)
+    for hd in handles:
+        _lib.group_kernel_ms(hd, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k_ms_sum, k_count = _lib.group_kernel_ms(handle, reset=True)
+    k_ms_sum, k_count = 0.0, 0
+    for hd in handles:
+        ms_c, cnt_c = _lib.group_kernel_ms(hd, reset=True)
+        k_ms_sum += ms_c
+        k_count = max(k_count, cnt_c)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,12 +196,12 @@ def main():
     k_ms = k_ms_sum / max(k_count, 1)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic = None
-    if os.path.exists(args.traffic_json):
+    if world == 1 and K == 1 and os.path.exists(args.traffic_json):
         try:
             traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_product")
         except Exception:
             traffic = None
-    info = _lib.group_info(handle)
+    info = _lib.group_info(handles[0])
     n_panels = int(info["n_panels"])
     kname = (f"k_slice_pack + k_csr_panel<float,4,3,true,false> x {n_panels} panel launches per product" if n_panels
              else "k_csr_wide<float,4>")
@@ -184,7 +219,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
                    "columns": "clustered" if args.clustered else "uniform",
-                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world} + RCCL all-gather of C"},
+                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world}, {K} pieces per rank, RCCL all-gather of C overlapped with the next piece"},
         "roofline": roofline,
     }
 
@@ -192,9 +227,18 @@ def main():
         base, cpu_out = cpu_baseline(rowptr, col, x, args)
         result["cpu_baseline"] = base
         if not args.no_check:
-            got = mine[: cpu_out.shape[0]].cpu().numpy()
+            got = torch.cat([outs[c][: mine_b[c + 1] - mine_b[c]] for c in range(K)])[: cpu_out.shape[0]].cpu().numpy()
             result["check"] = "bit-exact vs oracle on the sampled rows" if np.array_equal(got, cpu_out) else "MISMATCH"
-    _lib.group_free(handle)
+    if world > 1:
+        # every rank now holds every block: column-count checksum of the assembled C (exact: small integers)
+        full = torch.cat([gathers[c][r, : bounds[r][c + 1] - bounds[r][c]] for r in range(world) for c in range(K)])
+        colcount = torch.bincount(col.long(), minlength=n).double()
+        ok = full.shape[0] == n and torch.equal(full.double().sum(0), colcount @ x.double())
+        flag = torch.tensor([0 if ok else 1], device=dev)
+        dist.all_reduce(flag)
+        result["check"] = "column-count checksum of the gathered C exact on every rank" if int(flag.item()) == 0 else "MISMATCH"
+    for hd in handles:
+        _lib.group_free(hd)
     if rank == 0:
         print(f"[DATA]pim_time_spmm(ms):  {ms_per_step}", file=sys.stderr)
         print(f"[DATA]kernel_time(ms):  {k_ms}", file=sys.stderr)
