@@ -88,6 +88,9 @@ template <typename T> __device__ __forceinline__ T shfl_lane(T v, int src) {
 // 16-byte vector of column ids that is only 4-byte aligned (segment starts are arbitrary)
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
+// four values of T that are only element-aligned
+template <typename T> struct Vec4U { typedef T type __attribute__((ext_vector_type(4), aligned(sizeof(T)))); };
+
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
 template <typename T> struct VecOf<T, 1> { typedef T type; };
 
@@ -439,8 +442,19 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     constexpr int G = 64 >> LOG_LPR;  // rows per wave
     const int lane = threadIdx.x & 63;
     const int li = lane & (LPR - 1);
-    const uint32_t slice = blockIdx.x % nslices;
-    const uint32_t rb = blockIdx.x / nslices;
+    // Block -> (feature slice, item block), XCD-aware for ANY slice count.  Blocks b and b + 8 share an
+    // XCD (round-robin dispatch; speed only, never correctness).  The item blocks of every slice are dealt
+    // into 8 interleaved strands (rb = j, j + 8, ...: each strand sees the whole length spectrum); the
+    // 8 * nslices strands are taken slice-major, nslices per XCD, and an XCD walks its strands one after
+    // the other.  So an XCD's L2 holds one slice panel at a time, whatever nslices is (8 slices: XCD x =
+    // slice x; 4 slices: two XCDs share a slice; 16 slices: an XCD does two slices in turn).
+    const uint32_t item_blocks = (nitems + 4 * G - 1) / (4 * G);
+    const uint32_t strand_len = (item_blocks + 7) >> 3;
+    const uint32_t xcd = blockIdx.x & 7u, kseq = blockIdx.x >> 3;
+    const uint32_t strand = xcd * nslices + kseq / strand_len;
+    const uint32_t slice = strand >> 3;
+    const uint32_t rb = (strand & 7u) + 8u * (kseq % strand_len);
+    if (rb >= item_blocks) return;
     const uint64_t i64 = ((uint64_t)rb * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + (lane >> LOG_LPR);
     const bool row_ok = i64 < nitems;
     const uint32_t i = row_ok ? (uint32_t)i64 : 0u;
@@ -457,10 +471,10 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     }
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
     const bool lane_on = row_ok && f0 < w;
-    // lanes past the width (last slice of an odd h) gather the row start instead: in bounds, discarded
     // X is either the caller's row-major matrix (slice_stride = slice width) or the slice-major
     // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width)
-    const T *xlane = X + (f0 < w ? (int64_t)slice * slice_stride + li * VEC : 0);
+    // lanes past the width re-read the first piece of their own slice (same cache line as lane 0)
+    const T *xlane = X + (int64_t)slice * slice_stride + (f0 < w ? li * VEC : 0);
     const uint32_t row_bytes = (uint32_t)(ldx * (int64_t)sizeof(T));
     T *crow = C + (int64_t)row * ldc;
     A acc[VEC];
@@ -502,8 +516,14 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
             for (int k = 0; k < 4; k++) cc[k] = (base + k < len) ? __builtin_nontemporal_load(colind + s + base + k) : 0u;
         }
         if constexpr (HAS_VALS) {
+            if (base + 4u <= len) {
+                using V4 = typename Vec4U<T>::type;
+                const V4 q = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(vals + s + base));
+                vv[0] = q[0]; vv[1] = q[1]; vv[2] = q[2]; vv[3] = q[3];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(vals + s + base + k) : T(0);
+                for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(vals + s + base + k) : T(0);
+            }
         }
     };
     if (maxlen > 0) load_chunk(0, c4n, v4n);

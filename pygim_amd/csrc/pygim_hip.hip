@@ -244,7 +244,16 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     const T *vals = (const T *)p.vals;
     const uint32_t nrows = (uint32_t)p.nrows;
     const uint32_t lanes_needed = (w + VEC - 1) / VEC;
-    const bool coo_native = (g->format == PYGIM_COO) && !g_tune.coo_via_rowptr && lanes_needed > 16;
+    // L2-blocked panel sweep or row-per-wave kernels?
+    bool use_panel = false;
+    if constexpr (VEC * sizeof(T) == 16) {
+        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
+        if (use_panel && g_tune.panel_mode == 0)
+            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
+    }
+    // COO groups: the panel sweep (through the row pointers derived at create time) when it pays,
+    // else the native equal-nnz kernel
+    const bool coo_native = (g->format == PYGIM_COO) && !use_panel && !g_tune.coo_via_rowptr && lanes_needed > 16;
     if (coo_native) {
         // nnz-split kernel + carry fix-up
         if (!accumulate) HIP_TRY(hipMemset2DAsync(C, (size_t)ldc * sizeof(T), 0, (size_t)w * sizeof(T), nrows, st));
@@ -262,13 +271,6 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                            (uint32_t)p.nnz, chunk, nchunks, (const T *)g->scratch, C, ldc, w, accumulate ? 1 : 0);
         HIP_TRY(hipGetLastError());
         return 0;
-    }
-    // L2-blocked panel sweep or row-per-wave kernels?
-    bool use_panel = false;
-    if constexpr (VEC * sizeof(T) == 16) {
-        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
-        if (use_panel && g_tune.panel_mode == 0)
-            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
     }
     const LongPlan &lp = use_panel ? p.lp_panel : p.lp_base;
     // long rows: fixed-size segments on a forked stream, so that their few, long-running waves
@@ -323,7 +325,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t row_blocks = (cnt + rows_per_block - 1) / rows_per_block;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(row_blocks * nslices), dim3(256), 0, st, ir, \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(8u * nslices * ((row_blocks + 7) / 8)), dim3(256), 0, st, ir, \
                        ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices, accumulate ? 1 : 0)
                 if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
                 else if (off32) PYGIM_LAUNCH_PANEL(true, false);
@@ -753,7 +755,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         if (!build_long(p.lp_base, base_thresh, nullptr)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
         // L2-blocked plan (CSR groups): rows sorted by degree, columns cut into panels whose
         // 128-byte feature slice fits the L2 budget
-        if (format == PYGIM_CSR && g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
+        if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
             const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
             const uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
             const bool worth = g_tune.panel_mode == 1 || npan == 1 ||
