@@ -1,0 +1,214 @@
+// pim_ops_torch.cpp -- TORCH_LIBRARY(pim_ops) shim over the C ABI (include/pygim_hip.h), so that the
+// reference's `torch.ops.load_library(args.lib_path)` (spmm_test.py:111, inference.py:134) works
+// verbatim.  One shared object per variant, like the reference (its schemas differ per variant):
+//   -DPYGIM_VARIANT=0  spmm_default  (spmm_default/pytorch_api.cpp:372-389)
+//   -DPYGIM_VARIANT=1  spmm_grande   (spmm_grande/pytorch_api.cpp:326-343)
+//   -DPYGIM_VARIANT=2  spmv_sparseP  (spmv_sparseP/pytorch_api.cpp:271-287)
+// No arithmetic here: tensors in, raw pointers to the HIP library, tensor out.
+#include <torch/library.h>
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pygim_hip.h"
+
+#ifndef PYGIM_VARIANT
+#define PYGIM_VARIANT 0
+#endif
+
+namespace {
+
+struct Meta {
+    at::ScalarType dtype;
+    int64_t rows, cols, h;
+    std::vector<int64_t> n_dense, dense_cols;
+    std::vector<at::Tensor> keep;  // device arrays are used in place by the library
+};
+std::unordered_map<int64_t, Meta> g_meta;
+
+void chk(int rc) { TORCH_CHECK(rc == 0, "pygim_hip error ", rc, ": ", pygim_last_error()); }
+
+int dt_code(at::ScalarType t) {
+    switch (t) {
+        case at::kChar: return PYGIM_INT8;
+        case at::kShort: return PYGIM_INT16;
+        case at::kInt: return PYGIM_INT32;
+        case at::kLong: return PYGIM_INT64;
+        case at::kFloat: return PYGIM_FLT32;
+        case at::kDouble: return PYGIM_DBL64;
+        default: TORCH_CHECK(false, "unsupported value dtype ", t);
+    }
+    return -1;
+}
+
+void *stream_of(const at::Tensor &t) {
+    return t.is_cuda() ? (void *)c10::hip::getCurrentHIPStream(t.get_device()).stream() : nullptr;
+}
+
+int64_t to_device_group(int format, std::vector<at::Tensor> idx0, std::vector<at::Tensor> colind,
+                        std::vector<at::Tensor> values, std::vector<int64_t> nrows, std::vector<int64_t> ncols,
+                        std::vector<int64_t> n_dense, std::vector<int64_t> dense_cols, int64_t h_size) {
+    const size_t n = ncols.size();
+    TORCH_CHECK(n > 0 && idx0.size() == n && colind.size() == n && values.size() == n && nrows.size() == n,
+                "part lists differ in length");
+    Meta m;
+    m.dtype = values[0].scalar_type();
+    std::vector<const int32_t *> a(n), b(n);
+    std::vector<const void *> v(n);
+    std::vector<int64_t> nnz(n);
+    for (size_t i = 0; i < n; i++) {
+        // the reference reinterprets int32 tensors (pytorch_api.cpp:230-231); data_ptr<int32_t>() throws otherwise
+        idx0[i] = idx0[i].contiguous();
+        colind[i] = colind[i].contiguous();
+        values[i] = values[i].contiguous();
+        TORCH_CHECK(values[i].scalar_type() == m.dtype, "expected scalar type ", m.dtype, " but found ",
+                    values[i].scalar_type());
+        a[i] = idx0[i].data_ptr<int32_t>();
+        b[i] = colind[i].data_ptr<int32_t>();
+        v[i] = values[i].data_ptr();
+        nnz[i] = values[i].numel();
+        if (values[i].is_cuda()) {
+            m.keep.push_back(idx0[i]);
+            m.keep.push_back(colind[i]);
+            m.keep.push_back(values[i]);
+        }
+    }
+    int64_t handle = 0;
+    chk(pygim_group_create(format, dt_code(m.dtype), (int)n, a.data(), b.data(), v.data(), nrows.data(), ncols.data(),
+                           nnz.data(), n_dense.data(), dense_cols.data(), h_size, &handle));
+    m.rows = nrows[0];
+    m.cols = 0;
+    for (auto c : ncols) m.cols += c;
+    m.h = h_size;
+    m.n_dense = n_dense;
+    m.dense_cols = dense_cols;
+    g_meta[handle] = std::move(m);
+    return handle;
+}
+
+const Meta &meta(int64_t handle) {
+    auto it = g_meta.find(handle);
+    TORCH_CHECK(it != g_meta.end(), "unknown sparse group handle ", handle);
+    return it->second;
+}
+
+std::vector<int64_t> repeat(const std::vector<int64_t> &v, size_t n) {
+    std::vector<int64_t> out;
+    for (size_t i = 0; i < n; i++) out.insert(out.end(), v.begin(), v.end());
+    return out;
+}
+
+void dpu_release() {
+    g_meta.clear();
+    chk(pygim_release());
+}
+void spmm_free_group(int64_t handle) {
+    g_meta.erase(handle);
+    chk(pygim_group_free(handle));
+}
+
+at::Tensor run_common(int64_t handle, std::vector<at::Tensor> &parts, int kind) {
+    const Meta &m = meta(handle);
+    TORCH_CHECK(!parts.empty(), "no dense parts");
+    std::vector<const void *> ptrs;
+    std::vector<int64_t> lds;
+    for (auto &p : parts) {
+        TORCH_CHECK(p.scalar_type() == m.dtype, "expected scalar type ", m.dtype, " but found ", p.scalar_type());
+        p = p.contiguous();
+        ptrs.push_back(p.data_ptr());
+        lds.push_back(p.dim() == 2 ? p.size(1) : 1);
+    }
+    const int64_t out_cols = kind == 2 ? (int64_t)parts.size() : m.h;
+    at::Tensor out = at::empty({m.rows, out_cols}, parts[0].options());
+    void *st = stream_of(out);
+    if (kind == 0) chk(pygim_spmm_run_group(handle, ptrs.data(), out.data_ptr(), st));
+    else if (kind == 1) chk(pygim_grande_run_group(handle, ptrs.data(), lds.data(), out.data_ptr(), st));
+    else chk(pygim_spmv_run_group(handle, ptrs.data(), out.data_ptr(), st));
+    return out;
+}
+
+#if PYGIM_VARIANT == 1
+// ---- grande --------------------------------------------------------------------------------
+std::vector<int64_t> dpu_init_ranks(int64_t nr_ranks) {
+    std::vector<int64_t> units((size_t)std::max<int64_t>(nr_ranks, 1));
+    chk(pygim_init_ranks(nr_ranks, units.data()));
+    units.resize((size_t)nr_ranks);
+    return units;
+}
+std::vector<int64_t> dpu_init_dpus(int64_t nr_dpus) {
+    std::vector<int64_t> units((size_t)(nr_dpus + 7) / 8 + 1);
+    int64_t ranks = 0;
+    chk(pygim_init_units(nr_dpus, units.data(), &ranks));
+    units.resize((size_t)ranks);
+    return units;
+}
+int64_t spmm_csr_to_device_group(std::vector<at::Tensor> row_indices, std::vector<at::Tensor> col_indices,
+                                 std::vector<at::Tensor> values, std::vector<int64_t> nrows,
+                                 std::vector<int64_t> ncols, std::vector<at::Tensor> dense_cols, int64_t h_size) {
+    std::vector<int64_t> n_dense, flat;
+    for (auto &t : dense_cols) {
+        auto c = t.to(at::kCPU).contiguous();
+        const int32_t *p = c.data_ptr<int32_t>();
+        n_dense.push_back(c.numel());
+        for (int64_t k = 0; k < c.numel(); k++) flat.push_back(p[k]);
+    }
+    return to_device_group(PYGIM_CSR, row_indices, col_indices, values, nrows, ncols, n_dense, flat, h_size);
+}
+at::Tensor spmm_csr_run_group(int64_t handle, std::vector<at::Tensor> B_parts) { return run_common(handle, B_parts, 1); }
+#else
+// ---- default / spmv --------------------------------------------------------------------------
+void dpu_init_ranks(int64_t nr_ranks) { chk(pygim_init_ranks(nr_ranks, nullptr)); }
+void dpu_init_dpus(int64_t nr_dpus) { chk(pygim_init_units(nr_dpus, nullptr, nullptr)); }
+#if PYGIM_VARIANT == 0
+int64_t spmm_csr_to_device_group(std::vector<at::Tensor> row_indices, std::vector<at::Tensor> col_indices,
+                                 std::vector<at::Tensor> values, std::vector<int64_t> nrows,
+                                 std::vector<int64_t> ncols, std::vector<int64_t> dense_cols, int64_t h_size) {
+    const size_t n = ncols.size();
+    return to_device_group(PYGIM_CSR, row_indices, col_indices, values, nrows, ncols,
+                           std::vector<int64_t>(n, (int64_t)dense_cols.size()), repeat(dense_cols, n), h_size);
+}
+int64_t spmm_coo_to_device_group(std::vector<at::Tensor> row_indices, std::vector<at::Tensor> col_indices,
+                                 std::vector<at::Tensor> values, std::vector<int64_t> nrows,
+                                 std::vector<int64_t> ncols, std::vector<int64_t> dense_cols, int64_t h_size) {
+    const size_t n = ncols.size();
+    return to_device_group(PYGIM_COO, row_indices, col_indices, values, nrows, ncols,
+                           std::vector<int64_t>(n, (int64_t)dense_cols.size()), repeat(dense_cols, n), h_size);
+}
+at::Tensor spmm_csr_run_group(int64_t handle, std::vector<at::Tensor> B_parts) { return run_common(handle, B_parts, 0); }
+at::Tensor spmm_coo_run_group(int64_t handle, std::vector<at::Tensor> B_parts) { return run_common(handle, B_parts, 0); }
+#else
+int64_t spmv_coo_to_device_group(std::vector<at::Tensor> row_indices, std::vector<at::Tensor> col_indices,
+                                 std::vector<at::Tensor> values, std::vector<int64_t> nrows,
+                                 std::vector<int64_t> ncols, std::vector<int64_t> dense_cols, int64_t h_size,
+                                 int64_t ranks_per_spmv) {
+    TORCH_CHECK(ranks_per_spmv >= 1, "ranks_per_spmv must be >= 1");
+    const size_t n = ncols.size();
+    return to_device_group(PYGIM_COO, row_indices, col_indices, values, nrows, ncols,
+                           std::vector<int64_t>(n, (int64_t)dense_cols.size()), repeat(dense_cols, n), h_size);
+}
+at::Tensor spmv_coo_run_group(int64_t handle, std::vector<at::Tensor> B_parts) { return run_common(handle, B_parts, 2); }
+#endif
+#endif
+
+}  // namespace
+
+TORCH_LIBRARY(pim_ops, m) {
+    m.def("dpu_init_ranks", &dpu_init_ranks);
+    m.def("dpu_init_dpus", &dpu_init_dpus);
+    m.def("dpu_release", &dpu_release);
+    m.def("spmm_free_group", &spmm_free_group);
+#if PYGIM_VARIANT == 2
+    m.def("spmv_coo_to_device_group(Tensor[] row_indices, Tensor[] col_indices, Tensor[] values, int[] nrows, "
+          "int[] ncols, int[] dense_cols, int h_size, int ranks_per_spmv=1) -> int", &spmv_coo_to_device_group);
+    m.def("spmv_coo_run_group", &spmv_coo_run_group);
+#else
+    m.def("spmm_csr_to_device_group", &spmm_csr_to_device_group);
+    m.def("spmm_csr_run_group", &spmm_csr_run_group);
+#if PYGIM_VARIANT == 0
+    m.def("spmm_coo_to_device_group", &spmm_coo_to_device_group);
+    m.def("spmm_coo_run_group", &spmm_coo_run_group);
+#endif
+#endif
+}
