@@ -129,6 +129,14 @@ int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out
 int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc,
                     int64_t width, int accumulate, void *stream);
 
+/* ---- quantise -> aggregate -> dequantise (the step either side of the product in every conv layer,
+ * models/pyg_gcn_conv.py:130-137 with models/quantize.py:20-42), on device in one call:
+ *   scale = max|X| * 2 / 2^k (k = 5 / 10 / 20 for INT8 / INT16 / INT32 groups; 20 for FLT32),
+ *   X_q = round_half_even(X / scale) in the group's type, out_q = A . X_q, out = float(out_q) * scale.
+ * X: float32 [total_cols, h] (row stride ldx), out: float32 [nrows, h]; device pointers.
+ * scale_out (device float, may be NULL) receives the scale.                     */
+int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, void *stream);
+
 /* ---- introspection -----------------------------------------------------------
  * Milliseconds of the last host-pointer run, in the reference's Timer buckets
  * (support/timer.h; printed as [DATA] lines, spmm_mul_csr.c:563-580):

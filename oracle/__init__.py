@@ -206,3 +206,23 @@ def ref_partition_tsklt_by_nnz_coo(nnz, nparts):
     split = np.zeros(nparts + 2, dtype=np.uint32)
     ref.partition_tsklt_by_nnz_coo(ctypes.c_uint32(nnz), _p(split), ctypes.c_int(nparts))
     return split[: nparts + 1]
+
+
+# --------------------------------------------------------------------------- #
+# quantiser of the conv layers (reference models/quantize.py:20-42), numpy     #
+# restatement: float32 arithmetic, round half to even, C cast to the type.     #
+# "parity unpinned": quantize.py imports torch_sparse at module level and so   #
+# cannot be imported here; the statement below follows it line by line.        #
+# --------------------------------------------------------------------------- #
+def symmetric_quantize(v, np_dtype):
+    v = np.asarray(v, dtype=np.float32)
+    abs_max = np.float32(np.max(np.abs(v)))
+    bits = {np.dtype(np.int8): 5, np.dtype(np.int16): 10, np.dtype(np.int32): 20}.get(np.dtype(np_dtype), 20)
+    scale = np.float32(np.float32(abs_max * np.float32(2)) / np.float32(2 ** bits))
+    q = np.rint(v / scale)  # float32 division, half to even
+    target = np_dtype if np.dtype(np_dtype) in (np.dtype(np.int8), np.dtype(np.int16), np.dtype(np.int32)) else np.float32
+    return scale, q.astype(target)
+
+
+def symmetric_dequantize(out_q, scale_edge, scale_x):
+    return out_q.astype(np.float32) * np.float32(np.float32(scale_edge) * scale_x)

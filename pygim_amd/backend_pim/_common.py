@@ -101,3 +101,17 @@ class SparseGroupBase:
         self.col_indices = [c.indices()[1].int().contiguous() for c in self.coo]
         self.values = [c.values() for c in self.coo]
         return [c.size(0) for c in self.coo], [c.size(1) for c in self.coo]
+
+    # -- quantise -> aggregate -> dequantise in one device call (pygim_amd/quantize.py) ---------------
+    def mul_quantized(self, x: torch.Tensor):
+        """``dequantize(self.mul(quantize(x)))`` with models/quantize.py's arithmetic, on device.
+        x: float32 CUDA tensor [ncols, hidden_size].  Returns (out float32 [nrows, hidden_size], scale)."""
+        from .. import _lib
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) == self.hidden_size
+        x = x.contiguous()
+        out = torch.empty((self.raw.size(0), self.hidden_size), dtype=torch.float32, device=x.device)
+        scale = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.quant_spmm_run(self.sp_info_ptr, x.data_ptr(), x.size(1), out.data_ptr(), scale.data_ptr(),
+                            torch.cuda.current_stream(x.device).cuda_stream)
+        return out, scale

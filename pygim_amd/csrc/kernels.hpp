@@ -828,4 +828,45 @@ __global__ void k_pack_vectors(const T *const *__restrict__ vecs, uint32_t g, ui
     out[i] = vecs[j][r];
 }
 
+
+// ---------------------------------------------------------------------------
+// quantise -> aggregate -> dequantise around the product: the arithmetic of the
+// reference's models/quantize.py:20-42 as the conv layers use it (pyg_gcn_conv.py:130-137), on device.
+//   scale = max|x| * 2 / 2^k   (k = 5 / 10 / 20 for int8 / int16 / int32; 20 and a float "quantised"
+//   type otherwise);  x_q = round_half_even(x / scale) cast to the type;  out = float(out_q) * scale.
+// ---------------------------------------------------------------------------
+// max |x| as the bit pattern of a non-negative float (orders like an unsigned integer)
+__global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w, uint32_t *out) {
+    const uint64_t total = rows * w;
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = x[(i / w) * ld + (i % w)];
+        m = max(m, __float_as_uint(fabsf(v)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__device__ __forceinline__ float quant_scale(uint32_t absmax_bits, int log2_range) {
+    return __uint_as_float(absmax_bits) * 2.0f / (float)(1u << log2_range);
+}
+template <typename T>
+__global__ void k_quantize(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w,
+                           const uint32_t *__restrict__ absmax_bits, int log2_range, T *__restrict__ xq,
+                           float *__restrict__ scale_out) {
+    const float scale = quant_scale(*absmax_bits, log2_range);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && scale_out) *scale_out = scale;
+    if (i >= rows * w) return;
+    const float q = rintf(x[(i / w) * ld + (i % w)] / scale);  // torch.round: half to even
+    xq[i] = (T)q;
+}
+template <typename T>
+__global__ void k_dequantize(const T *__restrict__ q, uint64_t n, const uint32_t *__restrict__ absmax_bits,
+                             int log2_range, float *__restrict__ out) {
+    const float scale = 1.0f * quant_scale(*absmax_bits, log2_range);  // scale_edge (1.) * scale_x
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)q[i] * scale;
+}
+
 }  // namespace pygim

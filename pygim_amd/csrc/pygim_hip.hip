@@ -107,6 +107,10 @@ struct Group {
     size_t stage_in_bytes = 0;
     void *stage_out = nullptr;
     size_t stage_out_bytes = 0;
+    void *xq = nullptr;       // quantised features / integer result of pygim_quant_spmm_run
+    size_t xq_bytes = 0;
+    void *oq = nullptr;
+    size_t oq_bytes = 0;
     void *xs = nullptr;       // slice-major copy of X for the panel sweep
     size_t xs_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
@@ -187,6 +191,8 @@ void free_group(Group *g) {
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
     if (g->xs) (void)hipFree(g->xs);
+    if (g->xq) (void)hipFree(g->xq);
+    if (g->oq) (void)hipFree(g->oq);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->side) (void)hipStreamDestroy(g->side);
@@ -538,6 +544,40 @@ static int run_group_common(Group *g, const void *const *windows, const int64_t 
 }
 
 
+
+template <typename T>
+static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float *scale_out, int log2_range, hipStream_t st) {
+    const uint64_t rows = (uint64_t)g->total_cols, orows = (uint64_t)g->total_rows;
+    const uint32_t h = (uint32_t)g->h;
+    if (int rc = ensure(&g->xq, &g->xq_bytes, std::max<size_t>(rows * h * sizeof(T), 256))) return rc;
+    if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
+    uint32_t *amax = (uint32_t *)(g->d_flags + 3);
+    HIP_TRY(hipMemsetAsync(amax, 0, sizeof(uint32_t), st));
+    const uint64_t total = rows * h;
+    if (total) {
+        hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, X,
+                           ldx, rows, h, amax);
+        hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, ldx, rows, h, amax,
+                           log2_range, (T *)g->xq, scale_out);
+    }
+    // the group's own dense split, as windows into the row-major quantised matrix
+    const size_t nd = g->parts[0].dense_cols.size();
+    std::vector<const void *> win(nd);
+    std::vector<int64_t> lds(nd, (int64_t)h);
+    int64_t off = 0;
+    for (size_t j = 0; j < nd; j++) {
+        win[j] = (const char *)g->xq + (size_t)off * sizeof(T);
+        off += g->parts[0].dense_cols[j];
+    }
+    if (int rc = run_group_common(g, win.data(), lds.data(), false, g->oq, st)) return rc;
+    const uint64_t on = orows * h;
+    if (on)
+        hipLaunchKernelGGL((k_dequantize<T>), dim3((unsigned)((on + 255) / 256)), dim3(256), 0, st, (const T *)g->oq, on, amax,
+                           log2_range, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -652,8 +692,8 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         free_group(g);
         return code;
     };
-    if (hipMalloc((void **)&g->d_flags, 4 * sizeof(int)) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "hipMalloc flags"));
-    if (hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), st) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "memset flags"));
+    if (hipMalloc((void **)&g->d_flags, 8 * sizeof(int)) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "hipMalloc flags"));
+    if (hipMemsetAsync(g->d_flags, 0, 8 * sizeof(int), st) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "memset flags"));
     if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -836,6 +876,25 @@ int pygim_group_free(int64_t handle) {
     (void)hipDeviceSynchronize();
     free_group(g);
     return 0;
+}
+
+int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if (!X || !out || ldx < g->h) return fail(PYGIM_ERR_INVALID, "bad X / out / ldx");
+    if (!is_device_ptr(X) || !is_device_ptr(out) || (scale_out && !is_device_ptr(scale_out)))
+        return fail(PYGIM_ERR_INVALID, "pygim_quant_spmm_run needs device pointers");
+    for (auto &p : g->parts)
+        if (p.dense_cols != g->parts[0].dense_cols) return fail(PYGIM_ERR_INVALID, "needs one dense split for all parts");
+    hipStream_t st = (hipStream_t)stream;
+    switch (g->dtype) {  // ranges of models/quantize.py:22-30
+        case PYGIM_INT8: return quant_run_t<int8_t>(g, X, ldx, out, scale_out, 5, st);
+        case PYGIM_INT16: return quant_run_t<int16_t>(g, X, ldx, out, scale_out, 10, st);
+        case PYGIM_INT32: return quant_run_t<int32_t>(g, X, ldx, out, scale_out, 20, st);
+        case PYGIM_FLT32: return quant_run_t<float>(g, X, ldx, out, scale_out, 20, st);
+        default: return fail(PYGIM_ERR_INVALID, "quantised run: group type must be INT8/INT16/INT32/FLT32");
+    }
 }
 
 int pygim_group_timers(int64_t handle, double out_ms[5]) {

@@ -141,3 +141,21 @@ def test_variant_schemas(fake):
     assert pim_ops.current_variant() == "grande" and list(torch.ops.pim_ops.dpu_init_ranks(2)) == [8, 8]
     pim_ops.load_library("./backend_pim/spmv_sparseP/build/libbackend_pim.so")
     assert pim_ops.current_variant() == "spmv" and hasattr(torch.ops.pim_ops, "spmv_coo_run_group")
+
+
+def test_quantiser_matches_oracle_restatement(rng):
+    """pygim_amd.quantize (torch) vs the oracle's numpy restatement of models/quantize.py:20-42"""
+    from pygim_amd import quantize as qz
+
+    x = torch.from_numpy(rng.standard_normal((300, 40)).astype(np.float32))
+    for tdt, npdt in ((torch.int8, np.int8), (torch.int16, np.int16), (torch.int32, np.int32), (torch.float32, np.float32)):
+        scale, xq = qz.symmetric_quantize(x, dtype=tdt)
+        s_ref, q_ref = oracle.symmetric_quantize(x.numpy(), npdt)
+        assert np.float32(scale.item()) == s_ref and np.array_equal(xq.numpy(), q_ref)
+    # the cpu path hands the quantiser SparseTensor.dtype (a bound method): float branch
+    adj, rowptr, col = make_adj(rng)
+    scale, xq = qz.symmetric_quantize(x[:150], dtype=adj.dtype)
+    assert xq.dtype == torch.float32
+    out = qz.message_and_aggregate(adj, x[:150])
+    ref = oracle.symmetric_dequantize(oracle.spmm_csr(rowptr, col, None, xq.numpy()), 1.0, np.float32(scale.item()))
+    assert np.allclose(out.numpy(), ref, rtol=1e-6, atol=1e-6)

@@ -103,3 +103,33 @@ def test_conv_layer_call_pattern(rng):
         assert torch.allclose(out.double(), dense, atol=float(scale) * 6000)
     finally:
         torch.ops.pim_ops.dpu_release()
+
+
+@pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "FLT32"])
+def test_fused_quantise_aggregate_dequantise(rng, dt):
+    """one device call == the three reference steps (quantize.py:20-42 around adj_t.mul), bit for bit"""
+    from pygim_amd import quantize as qz
+
+    pim_ops.load("spmm")
+    tdt = TORCH_OF[dt]
+    adj, rowptr, col = make_adj(rng)
+    torch.ops.pim_ops.dpu_init_ranks(2)
+    try:
+        A = spmm_mod.prepare_pim_spmm(adj.to("cuda"), ns(data_type=tdt, sp_format="CSR", sp_parts=2, ds_parts=1, hidden_size=64))
+        x = torch.randn(600, 64)
+        out, scale = A.mul_quantized(x.cuda())
+        # oracle: numpy restatement of the quantiser + the SpMM oracle
+        s_ref, xq_ref = oracle.symmetric_quantize(x.numpy(), np.dtype(np.float32) if dt == "FLT32" else NP_OF[dt])
+        outq_ref = oracle.spmm_csr(rowptr, col, None, xq_ref)
+        ref = oracle.symmetric_dequantize(outq_ref, 1.0, s_ref)
+        assert np.float32(scale.item()) == s_ref
+        assert np.array_equal(out.cpu().numpy(), ref)
+        # and the unfused torch path of this package gives the same tensor
+        unfused = qz.message_and_aggregate(A, x.cuda(), fused=False)
+        assert torch.equal(unfused.cpu(), out.cpu())
+        assert torch.equal(qz.message_and_aggregate(A, x.cuda()).cpu(), out.cpu())
+    finally:
+        torch.ops.pim_ops.dpu_release()
+
+
+NP_OF = {"INT8": np.int8, "INT16": np.int16, "INT32": np.int32}
