@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU, 2 otherwise)")
+    ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU, 4 otherwise)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
 
@@ -124,7 +124,7 @@ def main():
     split = nnz_balanced_row_split(rowptr_cpu, world)
     # each rank's row block is cut again into `chunks` nnz-balanced pieces so that the all-gather of
     # piece k (RCCL's stream) overlaps the product of piece k+1 (this stream)
-    K = max(1, args.chunks if args.chunks > 0 else (2 if world > 1 else 1))
+    K = max(1, args.chunks if args.chunks > 0 else (4 if world > 1 else 1))
 
     def chunk_bounds(r):
         a, bnd = split[r], split[r + 1]
@@ -156,6 +156,9 @@ def main():
     def step():
         pending = []
         for c in range(K):
+            # X is re-laid slice-major by the first piece of every step; the other pieces of the same
+            # step reuse that copy (same X, same step)
+            _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
             _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
             if world > 1:
                 pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))

@@ -85,6 +85,22 @@ template <typename T> __device__ __forceinline__ T shfl_lane(T v, int src) {
     }
 }
 
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int mask) {
+    if constexpr (sizeof(T) == 8) {
+        union { T t; int u[2]; } in, out;
+        in.t = v;
+        out.u[0] = __shfl_xor(in.u[0], mask);
+        out.u[1] = __shfl_xor(in.u[1], mask);
+        return out.t;
+    } else {
+        union { T t; int u; } in, out;
+        in.t = v;
+        out.u = __shfl_xor(in.u, mask);
+        return out.t;
+    }
+}
+
 // 16-byte vector of column ids that is only 4-byte aligned (segment starts are arbitrary)
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -427,35 +443,42 @@ __device__ __forceinline__ void gather_vec(const T *__restrict__ xlane, uint32_t
     }
 }
 
-template <typename T, int VEC, int LOG_LPR, bool OFF32, bool HAS_VALS>
-__global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
-                                                   const uint32_t *__restrict__ item_begin,
-                                                   const uint32_t *__restrict__ item_len,
-                                                   const uint32_t *__restrict__ colind,
-                                                   const T *__restrict__ vals, const T *__restrict__ X,
-                                                   int64_t ldx, int64_t slice_stride, T *__restrict__ C,
-                                                   int64_t ldc, uint32_t nitems, uint32_t w, uint32_t nslices,
-                                                   int accumulate) {
+// One sweep body, two modes.
+//   COOP = false: an 8-lane group owns one work item (row x panel) and walks it alone; a wave carries 8 items.
+//   COOP = true : the 8 groups of a wave share ONE long item: group g takes the 32-entry chunks g, g+8, ...
+//                 and the partial sums are added across the groups at the end (integers: exact; floats:
+//                 a different summation order, inside the 1e-5 bound).  Keeps long rows inside the L2-blocked
+//                 sweep instead of leaving one lane group with a serial chain of thousands of gathers.
+template <typename T, int VEC, bool OFF32, bool HAS_VALS, bool COOP>
+__device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__restrict__ item_row,
+                                            const uint32_t *__restrict__ item_begin,
+                                            const uint32_t *__restrict__ item_len, uint32_t nitems,
+                                            const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+                                            const T *__restrict__ X, int64_t ldx, int64_t slice_stride,
+                                            T *__restrict__ C, int64_t ldc, uint32_t w, uint32_t nslices,
+                                            int accumulate) {
     using A = typename AccOf<T>::type;
-    static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
-    constexpr int LPR = 1 << LOG_LPR;
-    constexpr int G = 64 >> LOG_LPR;  // rows per wave
+    constexpr int LPR = 8;   // lanes per 128-byte slice of a row
+    constexpr int G = 8;     // lane groups per wave
     const int lane = threadIdx.x & 63;
     const int li = lane & (LPR - 1);
+    const uint32_t grp = (uint32_t)lane >> 3;
     // Block -> (feature slice, item block), XCD-aware for ANY slice count.  Blocks b and b + 8 share an
     // XCD (round-robin dispatch; speed only, never correctness).  The item blocks of every slice are dealt
     // into 8 interleaved strands (rb = j, j + 8, ...: each strand sees the whole length spectrum); the
     // 8 * nslices strands are taken slice-major, nslices per XCD, and an XCD walks its strands one after
     // the other.  So an XCD's L2 holds one slice panel at a time, whatever nslices is (8 slices: XCD x =
     // slice x; 4 slices: two XCDs share a slice; 16 slices: an XCD does two slices in turn).
-    const uint32_t item_blocks = (nitems + 4 * G - 1) / (4 * G);
+    constexpr uint32_t ITEMS_PER_BLOCK = COOP ? 4u : 4u * G;  // 4 waves per block
+    const uint32_t item_blocks = (nitems + ITEMS_PER_BLOCK - 1) / ITEMS_PER_BLOCK;
     const uint32_t strand_len = (item_blocks + 7) >> 3;
-    const uint32_t xcd = blockIdx.x & 7u, kseq = blockIdx.x >> 3;
+    const uint32_t xcd = blk & 7u, kseq = blk >> 3;
     const uint32_t strand = xcd * nslices + kseq / strand_len;
     const uint32_t slice = strand >> 3;
     const uint32_t rb = (strand & 7u) + 8u * (kseq % strand_len);
     if (rb >= item_blocks) return;
-    const uint64_t i64 = ((uint64_t)rb * (blockDim.x >> 6) + (threadIdx.x >> 6)) * G + (lane >> LOG_LPR);
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint64_t i64 = COOP ? ((uint64_t)rb * 4 + wv) : (((uint64_t)rb * 4 + wv) * G + grp);
     const bool row_ok = i64 < nitems;
     const uint32_t i = row_ok ? (uint32_t)i64 : 0u;
     // work item = (row, first entry, length | FIRST flag): the part of one row that falls into
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
     const bool lane_on = row_ok && f0 < w;
     // X is either the caller's row-major matrix (slice_stride = slice width) or the slice-major
-    // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width)
+    // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width);
     // lanes past the width re-read the first piece of their own slice (same cache line as lane 0)
     const T *xlane = X + (int64_t)slice * slice_stride + (f0 < w ? li * VEC : 0);
     const uint32_t row_bytes = (uint32_t)(ldx * (int64_t)sizeof(T));
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
     A acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; k++) acc[k] = A(0);
-    if (load_c && lane_on) {
+    if (load_c && lane_on && (!COOP || grp == 0)) {
         if (f0 + VEC <= w) {
             T old[VEC];
             load_vec_nt<T, VEC>(crow + f0, old);
@@ -492,22 +515,29 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                 if (f0 + k < w) acc[k] = to_acc<T>(crow[f0 + k]);
         }
     }
+    // chunk geometry: this group's t-th chunk of 32 entries starts at first + t * stride
+    constexpr uint32_t CH = 4 * LPR;
+    const uint32_t first = COOP ? CH * grp : 0u;
+    constexpr uint32_t STRIDE = COOP ? CH * G : CH;
     uint32_t maxlen = len, minlen = len;
+    if constexpr (!COOP) {
 #pragma unroll
-    for (int off = 32; off >= LPR; off >>= 1) {
-        maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
-        minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, off));
+        for (int off = 32; off >= LPR; off >>= 1) {
+            maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, off));
+            minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, off));
+        }
     }
-    maxlen = rfl(maxlen);
+    maxlen = rfl(maxlen);  // COOP: every lane of the wave holds the same item
     minlen = rfl(minlen);
+    const uint32_t nsteps = (maxlen + STRIDE - 1) / STRIDE;
+
     // Column ids are fetched 32 per lane group at a time (lane li holds ids 4*li .. 4*li+3 of the
     // chunk: one 128-byte request per group instead of four 32-byte ones), then consumed in four
     // batches of 8 gathers.  The next chunk is requested before the current one is gathered.
-    constexpr uint32_t CH = 4 * LPR;
     uint32_t c4[4], c4n[4];
     T v4[4], v4n[4];
-    auto load_chunk = [&](uint32_t e0, uint32_t (&cc)[4], T (&vv)[4]) {
-        const uint32_t base = e0 + 4u * (uint32_t)li;
+    auto load_chunk = [&](uint32_t cbase, uint32_t (&cc)[4], T (&vv)[4]) {
+        const uint32_t base = cbase + 4u * (uint32_t)li;
         if (base + 4u <= len) {
             const u32x4_u q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(colind + s + base));
             cc[0] = q[0]; cc[1] = q[1]; cc[2] = q[2]; cc[3] = q[3];
@@ -526,19 +556,22 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
             }
         }
     };
-    if (maxlen > 0) load_chunk(0, c4n, v4n);
-    for (uint32_t e0 = 0; e0 < maxlen; e0 += CH) {
+    if (nsteps > 0) load_chunk(first, c4n, v4n);
+    for (uint32_t t = 0; t < nsteps; t++) {
+        const uint32_t cbase = first + t * STRIDE;  // this group's chunk
+        const uint32_t wbase = t * STRIDE;          // lowest chunk start in the wave
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             c4[k] = c4n[k];
             if constexpr (HAS_VALS) v4[k] = v4n[k];
         }
-        if (e0 + CH < maxlen) load_chunk(e0 + CH, c4n, v4n);
+        if (t + 1 < nsteps) load_chunk(cbase + STRIDE, c4n, v4n);
         // entries past a row's end carry column 0 (a valid row of X): gathered, then masked out
 #define PYGIM_PANEL_BATCH(B)                                                                               \
-        if (e0 + 8u * B < maxlen) {                                                                        \
-            const uint32_t eb = e0 + 8u * B;                                                               \
-            const bool full = eb + 8u <= minlen; /* every group of the wave has all 8 entries */           \
+        if (wbase + 8u * B < maxlen) {                                                                     \
+            const uint32_t eb = cbase + 8u * B;                                                            \
+            /* every group of the wave has all 8 entries of this batch? */                                 \
+            const bool full = COOP ? (wbase + (STRIDE - CH) + 8u * B + 8u <= maxlen) : (eb + 8u <= minlen); \
             uint32_t cj[LPR];                                                                              \
             cj[0] = bcast8<2 * B>(c4[0]); cj[1] = bcast8<2 * B>(c4[1]);                                    \
             cj[2] = bcast8<2 * B>(c4[2]); cj[3] = bcast8<2 * B>(c4[3]);                                    \
@@ -571,7 +604,15 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
 #undef PYGIM_PANEL_BATCH
     }
 
-    if (lane_on) {
+    if constexpr (COOP) {
+        // add the 8 groups' partial sums (same feature lanes, lane ^ 8, ^ 16, ^ 32)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) acc[k] += shfl_xor_t<A>(acc[k], off);
+        }
+    }
+    if (lane_on && (!COOP || grp == 0)) {
         if (f0 + VEC <= w) {
             T o[VEC];
 #pragma unroll
@@ -583,6 +624,28 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                 if (f0 + k < w) crow[f0 + k] = from_acc<T>(acc[k]);
         }
     }
+}
+
+// One launch per column panel: the first coop_grid blocks take the panel's LONG items (one wave each,
+// dispatched first), the rest the ordinary items (one lane group each).
+template <typename T, int VEC, int LOG_LPR, bool OFF32, bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
+                                                   const uint32_t *__restrict__ item_begin,
+                                                   const uint32_t *__restrict__ item_len, uint32_t nitems,
+                                                   const uint32_t *__restrict__ coop_row,
+                                                   const uint32_t *__restrict__ coop_begin,
+                                                   const uint32_t *__restrict__ coop_len, uint32_t ncoop,
+                                                   uint32_t coop_grid, const uint32_t *__restrict__ colind,
+                                                   const T *__restrict__ vals, const T *__restrict__ X,
+                                                   int64_t ldx, int64_t slice_stride, T *__restrict__ C,
+                                                   int64_t ldc, uint32_t w, uint32_t nslices, int accumulate) {
+    static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
+    if (blockIdx.x < coop_grid)
+        panel_sweep<T, VEC, OFF32, HAS_VALS, true>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
+                                                   ldx, slice_stride, C, ldc, w, nslices, accumulate);
+    else
+        panel_sweep<T, VEC, OFF32, HAS_VALS, false>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
+                                                    colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate);
 }
 
 // Slice-major copy of X for the panel sweep: Xs[s][j][0:F] = X[j][s*F : (s+1)*F] (zero padded past

@@ -63,7 +63,9 @@ struct Tunables {
     int64_t panel_mode = 0;             // 0 = auto (cost rule), 1 = force the L2-blocked panel kernel, 2 = never
     int64_t panel_bytes = 4 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
     int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
+    int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
+    int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
 
@@ -91,6 +93,7 @@ struct Part {
     uint32_t *d_items = nullptr;            // [3][n_items]: rows | begins | lens
     size_t n_items = 0;
     std::vector<size_t> panel_off;          // npanels + 1 offsets into the item arrays
+    std::vector<uint32_t> panel_coop;       // per panel: leading items long enough for the wave-cooperative mode
     uint32_t npanels = 0, panel_cols = 0;
     std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
 };
@@ -111,8 +114,6 @@ struct Group {
     size_t xq_bytes = 0;
     void *oq = nullptr;
     size_t oq_bytes = 0;
-    void *xs = nullptr;       // slice-major copy of X for the panel sweep
-    size_t xs_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
     size_t d_ptrs_n = 0;
     int *d_flags = nullptr;
@@ -133,6 +134,12 @@ struct Context {
     int64_t nr_ranks = 0;
     std::set<Group *> groups;
     std::mutex mu;
+    // slice-major copy of the current X, shared by all groups of the process (one X per product)
+    void *xs = nullptr;
+    size_t xs_bytes = 0;
+    const void *xs_src = nullptr;
+    int64_t xs_ld = 0, xs_rows = 0, xs_w = 0;
+    size_t xs_es = 0;
 } g_ctx;
 
 bool is_device_ptr(const void *p) {
@@ -190,7 +197,6 @@ void free_group(Group *g) {
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
-    if (g->xs) (void)hipFree(g->xs);
     if (g->xq) (void)hipFree(g->xq);
     if (g->oq) (void)hipFree(g->oq);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
@@ -313,12 +319,21 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             KernelTimer kt(g, st);
             if (g_tune.panel_pack) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
-                if (int rc = ensure(&g->xs, &g->xs_bytes, std::max<size_t>(need, 256))) return rc;
-                const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
-                if (threads > 0)
-                    hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256),
-                                       0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)g->xs);
-                Xg = (const T *)g->xs;
+                const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
+                                  g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
+                if (!same) {
+                    if (int rc = ensure(&g_ctx.xs, &g_ctx.xs_bytes, std::max<size_t>(need, 256))) return rc;
+                    const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
+                    if (threads > 0)
+                        hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)),
+                                           dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)g_ctx.xs);
+                    g_ctx.xs_src = X;
+                    g_ctx.xs_ld = ldx;
+                    g_ctx.xs_rows = p.ncols;
+                    g_ctx.xs_w = (int64_t)w;
+                    g_ctx.xs_es = sizeof(T);
+                }
+                Xg = (const T *)g_ctx.xs;
                 ldg = F;
                 slice_stride = (int64_t)p.ncols * F;
             }
@@ -328,11 +343,16 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const size_t o = p.panel_off[q];
                 const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
                 if (cnt == 0) continue;
-                const uint32_t row_blocks = (cnt + rows_per_block - 1) / rows_per_block;
+                const uint32_t ncoop = p.panel_coop[q], nnorm = cnt - ncoop;
+                const uint32_t row_blocks = (nnorm + rows_per_block - 1) / rows_per_block;
+                const uint32_t coop_blocks = (ncoop + 3) / 4;  // one wave per long item, 4 waves per block
+                const uint32_t coop_grid = ncoop ? 8u * nslices * ((coop_blocks + 7) / 8) : 0u;
+                const uint32_t norm_grid = nnorm ? 8u * nslices * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(8u * nslices * ((row_blocks + 7) / 8)), dim3(256), 0, st, ir, \
-                       ib, il, p.colind, vals, Xg, ldg, slice_stride, C, ldc, cnt, w, nslices, accumulate ? 1 : 0)
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(coop_grid + norm_grid), dim3(256), 0, st,           \
+                       ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xg, ldg, \
+                       slice_stride, C, ldc, w, nslices, accumulate ? 1 : 0)
                 if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
                 else if (off32) PYGIM_LAUNCH_PANEL(true, false);
                 else if (vals) PYGIM_LAUNCH_PANEL(false, true);
@@ -626,6 +646,10 @@ int pygim_release(void) {
     }
     if (g_ctx.inited) (void)hipDeviceSynchronize();
     for (Group *g : gs) free_group(g);
+    if (g_ctx.xs) (void)hipFree(g_ctx.xs);
+    g_ctx.xs = nullptr;
+    g_ctx.xs_bytes = 0;
+    g_ctx.xs_src = nullptr;
     g_ctx.inited = false;
     return 0;
 }
@@ -661,6 +685,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_bytes") slot = &g_tune.panel_bytes;
     else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
     else if (n == "panel_pack") slot = &g_tune.panel_pack;
+    else if (n == "panel_coop") slot = &g_tune.panel_coop;
+    else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
     if (!slot) return -1;
     const int64_t old = *slot;
     *slot = value;
@@ -815,17 +841,19 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                 if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
                 const uint32_t *rp = h_rowptr.data();
                 const size_t nr = (size_t)p.nrows;
-                // rows whose share of ONE panel exceeds the threshold leave the sweep (a lane group walks
-                // an item serially; the segment kernels cut such rows over many waves instead)
+                // rows whose share of ONE panel is enormous (16x the long-row threshold) leave the sweep for
+                // the segment kernels; merely long items stay and are walked by a whole wave (panel_coop)
                 std::vector<char> heavy(nr, 0);
                 for (uint32_t q = 0; q < npan; q++) {
                     const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
                     for (size_t r = 0; r < nr; r++)
-                        if (hi[r] - lo[r] > base_thresh) heavy[r] = 1;
+                        if ((uint64_t)(hi[r] - lo[r]) > (uint64_t)base_thresh * 16) heavy[r] = 1;
                 }
                 if (!build_long(p.lp_panel, base_thresh, &heavy)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
                 std::vector<uint32_t> rows_v, beg_v, len_v, order;
                 p.panel_off.assign(1, 0);
+                p.panel_coop.clear();
+                const uint32_t coop_cap = (uint32_t)std::max<int64_t>(64, g_tune.panel_coop);
                 for (uint32_t q = 0; q < npan; q++) {
                     const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
                     order.clear();
@@ -837,6 +865,9 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                     std::stable_sort(order.begin(), order.end(), [lo, hi](uint32_t a, uint32_t b) {
                         return (hi[a] - lo[a]) > (hi[b] - lo[b]);
                     });
+                    uint32_t nco = 0;
+                    for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
+                    p.panel_coop.push_back(nco);
                     for (uint32_t r : order) {
                         rows_v.push_back(r);
                         beg_v.push_back(lo[r]);

@@ -231,6 +231,7 @@ def test_panel_kernel_keeps_stored_order(rng, dt):
     npdt = NP_DTYPES[dt]
     old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 64)]
     old_long = _lib.set_tunable("long_row_threshold", 1 << 20)  # keep every row in one ordered sweep
+    old_coop = _lib.set_tunable("panel_coop", 1 << 20)           # ... walked by ONE lane group (stored order)
     try:
         rowptr, col = random_csr(rng, 400, 600, 40, long_rows=[(11, 5000)])
         x = (rng.random((600, 64)) * 2 - 1).astype(npdt)
@@ -256,6 +257,7 @@ def test_panel_kernel_keeps_stored_order(rng, dt):
         _lib.set_tunable("panel_mode", old[0])
         _lib.set_tunable("panel_bytes", old[1])
         _lib.set_tunable("long_row_threshold", old_long)
+        _lib.set_tunable("panel_coop", old_coop)
 
 
 def test_panel_kernel_banded_rows(rng):
@@ -282,3 +284,30 @@ def test_panel_kernel_banded_rows(rng):
     finally:
         _lib.set_tunable("panel_mode", old[0])
         _lib.set_tunable("panel_bytes", old[1])
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_panel_cooperative_items(rng, dt):
+    """items longer than panel_coop are walked by a whole wave (8 lane groups, partial sums added):
+    exact for integers and for the integer-valued driver features in every float type; real-valued
+    floats stay inside the 1e-5 bound"""
+    npdt = NP_DTYPES[dt]
+    old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 300), _lib.set_tunable("panel_coop", 64)]
+    try:
+        rowptr, col = random_csr(rng, 300, 900, 30, long_rows=[(0, 9000), (7, 65), (100, 700), (299, 2049)])
+        for h in (32, 96, 256):
+            x = driver_features(rng, 900, h, npdt)
+            vals = rng.integers(1, 4, size=len(col)).astype(npdt)
+            for v in (None, vals):
+                ref = oracle.spmm_csr(rowptr, col, v, x)
+                out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [300], [900], [x], h)
+                assert np.array_equal(out, ref), (dt, h, v is None)
+        if dt in ("FLT32", "DBL64"):
+            x = (rng.random((900, 64)) * 2 - 1).astype(npdt)
+            ref = oracle.spmm_csr(rowptr, col, None, x)
+            out, _ = run_group_host("CSR", [rowptr], [col], None, [300], [900], [x], 64)
+            assert np.all(np.abs(out.astype(np.float64) - ref) <= 1e-5 * abs_scale(rowptr, col, None, x))
+    finally:
+        _lib.set_tunable("panel_mode", old[0])
+        _lib.set_tunable("panel_bytes", old[1])
+        _lib.set_tunable("panel_coop", old[2])

@@ -123,10 +123,16 @@ def test_fused_quantise_aggregate_dequantise(rng, dt):
         outq_ref = oracle.spmm_csr(rowptr, col, None, xq_ref)
         ref = oracle.symmetric_dequantize(outq_ref, 1.0, s_ref)
         assert np.float32(scale.item()) == s_ref
-        assert np.array_equal(out.cpu().numpy(), ref)
+        if dt == "FLT32":
+            # "quantised" floats are integers up to 2^19: sums of a 5000-entry row exceed 2^24, so the
+            # float result depends on the summation order (long items are summed by 8 lane groups)
+            mag = oracle.spmm_csr(rowptr, col, None, np.abs(xq_ref)) * s_ref
+            assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-5 * mag + 1e-30)
+        else:
+            assert np.array_equal(out.cpu().numpy(), ref)
         # and the unfused torch path of this package gives the same tensor
         unfused = qz.message_and_aggregate(A, x.cuda(), fused=False)
-        assert torch.equal(unfused.cpu(), out.cpu())
+        assert torch.equal(unfused.cpu(), out.cpu())  # same kernels, same order -> same bits
         assert torch.equal(qz.message_and_aggregate(A, x.cuda()).cpu(), out.cpu())
     finally:
         torch.ops.pim_ops.dpu_release()
