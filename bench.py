@@ -151,19 +151,39 @@ def main():
         outs.append(g[rank])
         my_rows += c1 - c0
         my_nnz += hi - lo
-    stream = torch.cuda.current_stream().cuda_stream
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
+    # pieces run on their own streams (measured on one GPU: 4 pieces of a 1/8 row block cost 1.40 ms on
+    # 4 streams vs 1.78 ms back to back); piece 0 also re-lays X slice-major, the others wait for it
+    side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if world > 1 else []
 
     def step():
+        if world == 1:
+            for c in range(K):
+                _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
+                _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
+            return
         pending = []
-        for c in range(K):
-            # X is re-laid slice-major by the first piece of every step; the other pieces of the same
-            # step reuse that copy (same X, same step)
-            _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
-            _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
-            if world > 1:
+        _lib.set_tunable("xs_reuse", 0)
+        _lib.spmm_run_group(handles[0], [x.data_ptr()], outs[0].data_ptr(), stream)
+        ready = torch.cuda.Event()
+        ready.record(main_stream)
+        pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
+        _lib.set_tunable("xs_reuse", 1)
+        for c in range(1, K):
+            s = side[c - 1]
+            s.wait_event(ready)
+            with torch.cuda.stream(s):
+                _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s.cuda_stream)
                 pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
-        for wk in pending:
-            wk.wait()  # stream-level wait, the host does not block
+        for c, wk in enumerate(pending):
+            if c == 0:
+                wk.wait()
+            else:
+                with torch.cuda.stream(side[c - 1]):
+                    wk.wait()
+        for s in side:
+            main_stream.wait_stream(s)
 
     def fence():
         if world > 1:
@@ -222,7 +242,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
                    "columns": "clustered" if args.clustered else "uniform",
-                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world}, {K} pieces per rank, RCCL all-gather of C overlapped with the next piece"},
+                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world}, {K} pieces per rank on {K} streams, each piece all-gathered (RCCL) as soon as it is done"},
         "roofline": roofline,
     }
 
