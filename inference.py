@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's inference.py: end-to-end GNN inference (GCN / GIN / SAGE, random
+weights, eval mode) with the aggregation on the MI355X backend, timed as ``[DATA]infer_time(ms)``.
+
+Same flags as the reference (inference.py:96-124) plus ``--device`` and multi-GPU through
+``python -m torch.distributed.run --nproc-per-node N inference.py --version spmm ...`` (row split of A,
+RCCL all-gather between layers: BASELINE config 4).  Datasets are seeded synthetic graphs with the
+named dataset's node / edge counts (no network); labels are random, so the accuracy print only keeps
+the reference's log shape (its model is untrained too, inference.py:154-163).
+"""
+import argparse
+import datetime
+import os
+
+import torch
+
+from pygim_amd import gnn, pim_ops, synth
+from pygim_amd.backend_pim.grande import prepare_pim_spmm_grande
+from pygim_amd.backend_pim.spmm import prepare_pim_spmm
+from pygim_amd.backend_pim.spmv import prepare_pim_spmv
+from pygim_amd.sparse_tensor import SparseTensor
+from spmm_test import DATASETS, TORCH_TYPES
+
+
+@torch.no_grad()
+def test(args, model, data):
+    model.eval()
+    if data["x"].is_cuda:
+        torch.cuda.synchronize()
+    st = datetime.datetime.now()
+    y_pred = model(data["x"], data["adj_t"], data["edge_attr"])
+    if y_pred.is_cuda:
+        torch.cuda.synchronize()
+    print("[DATA]infer_time(ms): ", (datetime.datetime.now() - st).total_seconds() * 1000, flush=True)
+    y_pred = y_pred.argmax(dim=-1)
+    return (y_pred.eq(data["y"]).sum() / y_pred.size(0)).item()
+
+
+def get_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", type=str, default="PubMed", choices=sorted(DATASETS))
+    ap.add_argument("--datadir", type=str, default="./data")
+    ap.add_argument("--version", type=str, default="grande", choices=["spmm", "grande", "spmv", "cpu"])
+    ap.add_argument("--lib_path", type=str, default="./backend_pim/spmm_grande/build/libbackend_pim.so")
+    ap.add_argument("--model", type=str, default="gcn", choices=["gcn", "gin", "sage"])
+    ap.add_argument("--num_layers", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--hidden_size", type=int, default=256)
+    ap.add_argument("--in_features", type=int, default=128)
+    ap.add_argument("--num_classes", type=int, default=41)
+    ap.add_argument("--data_type", type=str, default="INT32", choices=sorted(TORCH_TYPES))
+    ap.add_argument("--sp_format", type=str, default="CSR", choices=["CSR", "COO"])
+    ap.add_argument("--sp_parts", type=int, default=1)
+    ap.add_argument("--ds_parts", type=int, default=1)
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--nr_dpus", type=int, default=0)
+    ap.add_argument("--device", type=str, default="cuda" if torch.cuda.is_available() else "cpu")
+    args = ap.parse_args()
+    print(args, flush=True)
+    args.data_type = TORCH_TYPES[args.data_type]
+    return args
+
+
+def main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+        args.device = "cuda"
+    n, nnz, dmax = DATASETS[args.dataset]
+    gen = "cuda" if torch.cuda.is_available() else "cpu"
+    rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=gen)
+    torch.manual_seed(0)
+    x = torch.randn(n, args.in_features)
+    y = torch.randint(0, args.num_classes, (n,))
+    data = {"x": x.to(args.device), "y": y.to(args.device), "edge_attr": None}
+    adj_t = SparseTensor(rowptr=rowptr.cpu().long(), col=col.cpu().long(), sparse_sizes=(n, n))
+    if args.version == "cpu":
+        data["adj_t"] = adj_t
+        data["x"], data["y"] = x, y
+    elif world > 1:
+        from pygim_amd.dist import RowSplitAdj
+
+        data["adj_t"] = RowSplitAdj(rowptr.cpu(), col.cpu(), n, args.data_type, args.hidden_size)
+    else:
+        pim_ops.load(args.version)
+        if args.version == "grande":
+            units = torch.ops.pim_ops.dpu_init_ranks(args.sp_parts)
+            data["adj_t"] = prepare_pim_spmm_grande(adj_t, args, units)
+        else:
+            torch.ops.pim_ops.dpu_init_ranks(args.sp_parts * args.ds_parts)
+            data["adj_t"] = (prepare_pim_spmm if args.version == "spmm" else prepare_pim_spmv)(adj_t, args)
+    Model = {"gcn": gnn.GCN, "gin": gnn.GIN, "sage": gnn.SAGE}[args.model]
+    torch.manual_seed(1)
+    model = Model(args.in_features, args.hidden_size, args.num_classes, args.num_layers).to(data["x"].device)
+    for i in range(args.repeat):
+        if rank == 0:
+            print("-------------------- Model={} nrl={} Repeat={}--------------------".format(args.model, args.num_layers, i), flush=True)
+        acc = test(args, model, data)
+        if rank == 0:
+            print(f"Test_acc: {acc:.4f}")
+    if args.version != "cpu" and world == 1:
+        torch.ops.pim_ops.dpu_release()
+
+
+if __name__ == "__main__":
+    main(get_args())

@@ -154,3 +154,53 @@ class FeatureSplitSpMM:
         mine[:, : c_block.size(1)] = c_block
         dist.all_gather_into_tensor(stage.view(-1), mine.reshape(-1).clone(), group=self.group)
         return torch.cat([stage[i, :, : self.widths[i]] for i in range(self.world)], dim=1)
+
+
+class RowSplitAdj:
+    """What a conv layer's ``adj_t`` is on N GPUs (BASELINE config 4): an nnz-balanced ROW block of A per
+    rank, features replicated.  ``mul_quantized`` = quantise (over the full, replicated X) -> local rows
+    of A . X_q -> dequantise, then one all-gather of the row blocks; ``mul`` = the plain product."""
+
+    def __init__(self, rowptr, col, ncols, dtype, h, group=None):
+        from . import _lib, pim_ops
+
+        self._lib = _lib
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.dtype, self.hidden_size = dtype, h
+        self.nrows = rowptr.numel() - 1
+        if not _lib.is_initialized():
+            _lib.init_ranks(self.world)
+        self.split = partition.partition_by_nnz(rowptr, self.world)
+        r0, r1 = self.split[self.rank], self.split[self.rank + 1]
+        lo, hi = int(rowptr[r0]), int(rowptr[r1])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self._keep = [(rowptr[r0:r1 + 1] - lo).to(dev, torch.int32).contiguous(), col[lo:hi].to(dev, torch.int32).contiguous()]
+        self.handle = _lib.group_create(_lib.CSR, pim_ops.DTYPE_CODE[dtype], [self._keep[0].data_ptr()],
+                                        [self._keep[1].data_ptr()], None, [r1 - r0], [ncols], [hi - lo], [1], [h], h)
+        self.my_rows = r1 - r0
+        self.max_rows = max(self.split[i + 1] - self.split[i] for i in range(self.world))
+
+    def _gather(self, buf):
+        if self.world > 1:
+            dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), group=self.group)
+        if self.world == 1 or all(self.split[i + 1] - self.split[i] == self.max_rows for i in range(self.world)):
+            return buf.view(self.world * self.max_rows, -1)[: self.nrows]
+        return torch.cat([buf[i, : self.split[i + 1] - self.split[i]] for i in range(self.world)], dim=0)
+
+    def mul_quantized(self, x):
+        assert x.is_cuda and x.dtype == torch.float32 and x.size(1) == self.hidden_size
+        x = x.contiguous()
+        buf = torch.empty((self.world, self.max_rows, self.hidden_size), dtype=torch.float32, device=x.device)
+        scale = torch.empty((), dtype=torch.float32, device=x.device)
+        self._lib.quant_spmm_run(self.handle, x.data_ptr(), x.size(1), buf[self.rank].data_ptr(), scale.data_ptr(),
+                                 torch.cuda.current_stream(x.device).cuda_stream)
+        return self._gather(buf), scale
+
+    def mul(self, x):
+        assert x.is_cuda and x.dtype == self.dtype
+        x = x.contiguous()
+        buf = torch.empty((self.world, self.max_rows, self.hidden_size), dtype=self.dtype, device=x.device)
+        self._lib.spmm_run_group(self.handle, [x.data_ptr()], buf[self.rank].data_ptr(),
+                                 torch.cuda.current_stream(x.device).cuda_stream)
+        return self._gather(buf)
