@@ -1,0 +1,88 @@
+"""Partition chooser for N GPUs.
+
+The reference's utils/autotuner.py:263-343 picks ``(sp_parts, ds_parts, balance)`` by pricing, for every
+candidate split, load + compute + retrieve + host-merge time from UPMEM calibration constants
+(autotuner.py:23-89) -- and depends on an op (``prepare_tune_csr``) that is not in the repository.
+Here the same idea is restated for one node of MI355Xs with constants MEASURED this round on the
+hardware (profiles/): a candidate is a (row parts x feature parts) grid over the
+GPUs; its price is the slowest GPU's product time plus the collective that re-assembles C.
+
+    product  : gather-model bytes / rate, rate = L2-blocked sweep when a row has enough entries per
+               column panel, else the Infinity-Cache/HBM row-gather rate
+    all-gather of C over xGMI (row parts), nothing inside the product for feature parts, but a narrower
+               feature block gathers less than a cache line per entry below 128 B.
+Returns the reference's ``[sp_parts, ds_parts, balance_dpu, balance_tasklet, None]`` shape.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+# measured on MI355X this round (bytes/s)
+RATE_PANEL = 17.0e12        # k_csr_panel, Reddit-shaped, h = 256 f32
+RATE_GATHER_FAR = 4.8e12    # row-per-wave gathers from HBM (products-shaped, X = 2.5 GB)
+RATE_GATHER_MALL = 7.0e12   # row-per-wave gathers, X about the size of the Infinity Cache (Reddit, panel off)
+RATE_STREAM = 5.0e12        # streaming reads/writes (index arrays, C)
+XGMI_IN = 7 * 45e9          # inbound bytes/s per GPU, 7 links (spec 7 x ~64 GB/s per direction; 70 % assumed)
+PANEL_BYTES = 4 << 20
+LAUNCH = 6e-6               # per kernel launch incl. ramp, back to back
+
+
+@dataclass
+class Choice:
+    row_parts: int
+    feat_parts: int
+    seconds: float
+    product_s: float
+    collective_s: float
+    panel: bool
+
+
+def product_seconds(nrows, ncols, nnz, h, es):
+    """one GPU: rows x all columns, h features"""
+    if nrows == 0 or nnz == 0 or h == 0:
+        return 0.0, False
+    row_bytes = h * es
+    line_bytes = max(row_bytes, 128) if row_bytes < 128 else row_bytes  # at least one cache line per entry
+    gather = nnz * line_bytes
+    npanels = max(1, math.ceil(ncols * 128 / PANEL_BYTES))
+    panel = row_bytes >= 64 and (npanels == 1 or nnz / (nrows * npanels) >= 8)
+    if panel:
+        nsl = math.ceil(row_bytes / 128)
+        t = gather / RATE_PANEL + npanels * (2 * nrows * row_bytes) / RATE_STREAM / 8 + nsl * 4 * nnz / RATE_STREAM / 8
+        t += npanels * LAUNCH + ncols * row_bytes * 2 / RATE_STREAM
+    else:
+        x_bytes = ncols * row_bytes
+        rate = RATE_GATHER_MALL if x_bytes <= 300e6 else RATE_GATHER_FAR
+        t = gather / rate + LAUNCH
+    return t, panel
+
+
+def price(nrows, ncols, nnz, h, es, row_parts, feat_parts):
+    hp = math.ceil(h / feat_parts)
+    t, panel = product_seconds(math.ceil(nrows / row_parts), ncols, nnz / row_parts, hp, es)
+    gpus = row_parts * feat_parts
+    # every GPU ends with the full C: it receives everything it did not compute
+    coll = 0.0 if gpus == 1 else (nrows * h * es) * (1 - 1 / gpus) / XGMI_IN
+    return Choice(row_parts, feat_parts, t + coll, t, coll, panel)
+
+
+def choose(nrows, ncols, nnz, h, elem_bytes, n_gpus):
+    """best (row parts x feature parts) grid over n_gpus GPUs and the table of all candidates"""
+    table = []
+    for r in range(1, n_gpus + 1):
+        if n_gpus % r:
+            continue
+        f = n_gpus // r
+        if f > h:
+            continue
+        table.append(price(nrows, ncols, nnz, h, elem_bytes, r, f))
+    best = min(table, key=lambda c: c.seconds)
+    return best, table
+
+
+def autotune(nrows, ncols, nnz, hidden_size, elem_bytes=4, n_gpus=8):
+    """reference-shaped result: [sp_parts, ds_parts, balance over GPUs, balance inside a GPU, None]
+    (utils/autotuner.py:333-343).  sp_parts here are ROW parts, balanced by nnz."""
+    best, _ = choose(nrows, ncols, nnz, hidden_size, elem_bytes, n_gpus)
+    return [best.row_parts, best.feat_parts, "nnz", "nnz", None]

@@ -159,3 +159,19 @@ def test_quantiser_matches_oracle_restatement(rng):
     out = qz.message_and_aggregate(adj, x[:150])
     ref = oracle.symmetric_dequantize(oracle.spmm_csr(rowptr, col, None, xq.numpy()), 1.0, np.float32(scale.item()))
     assert np.allclose(out.numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_partition_chooser():
+    from pygim_amd import autotune as at
+
+    # Reddit-shaped, one GPU: the L2-blocked sweep is chosen and priced near the measured 6.9 ms
+    best, table = at.choose(232965, 232965, 114615892, 256, 4, 1)
+    assert best.panel and 4e-3 < best.seconds < 12e-3 and len(table) == 1
+    # 8 GPUs: every divisor grid is priced; low-degree graph (products-shaped) never uses panels
+    best8, table8 = at.choose(232965, 232965, 114615892, 256, 4, 8)
+    assert {(c.row_parts, c.feat_parts) for c in table8} == {(1, 8), (2, 4), (4, 2), (8, 1)}
+    assert best8.seconds < best.seconds
+    _, t = at.choose(2449029, 2449029, 123718280, 256, 4, 1)
+    assert not t[0].panel
+    cfg = at.autotune(232965, 232965, 114615892, 256)
+    assert len(cfg) == 5 and cfg[0] * cfg[1] == 8
