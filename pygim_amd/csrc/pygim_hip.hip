@@ -259,7 +259,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     // L2-blocked panel sweep or row-per-wave kernels?
     bool use_panel = false;
     if constexpr (VEC * sizeof(T) == 16) {
-        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 64 && nrows > 0;
+        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 32 && nrows > 0;
         if (use_panel && g_tune.panel_mode == 0)
             use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
     }
@@ -317,7 +317,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st);
-            if (g_tune.panel_pack) {
+            if (g_tune.panel_pack && nslices > 1) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
                 const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
                                   g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
@@ -823,22 +823,39 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         // 128-byte feature slice fits the L2 budget
         if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
             const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
-            const uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
-            const bool worth = g_tune.panel_mode == 1 || npan == 1 ||
-                               (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
+            uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
+            bool worth = g_tune.panel_mode == 1 || npan == 1 ||
+                         (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
+            if (!worth) {
+                // too few entries per (row, panel) for L2 blocking.  Rows of at most one cache line still
+                // gain from the sweep's other half -- length-sorted items, 32-id column chunks, wave-
+                // cooperative long rows -- so they get a ONE-panel plan (no blocking, no X copy); wider
+                // rows are better served by whole-row gathers (k_csr_wide).
+                int64_t wmax = 1;
+                for (auto dcw : p.dense_cols) wmax = std::max(wmax, dcw);
+                if (wmax * (int64_t)es <= 128) {
+                    npan = 1;
+                    worth = true;
+                }
+            }
             if (worth) {
                 p.npanels = npan;
                 p.panel_cols = (uint32_t)((p.ncols + npan - 1) / npan);
                 // panel pointers of every row (device binary searches), then the lists on the host
                 const size_t pp_elems = (size_t)(npan + 1) * (size_t)p.nrows;
-                uint32_t *d_pp = nullptr;
-                if (hipMalloc((void **)&d_pp, pp_elems * 4) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers"));
-                hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
-                                   (const uint32_t *)nullptr, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, d_pp);
                 std::vector<uint32_t> pp(pp_elems);
-                const hipError_t ce = hipMemcpy(pp.data(), d_pp, pp_elems * 4, hipMemcpyDeviceToHost);
-                (void)hipFree(d_pp);
-                if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
+                if (npan == 1) {
+                    std::copy(h_rowptr.begin(), h_rowptr.end() - 1, pp.begin());
+                    std::copy(h_rowptr.begin() + 1, h_rowptr.end(), pp.begin() + p.nrows);
+                } else {
+                    uint32_t *d_pp = nullptr;
+                    if (hipMalloc((void **)&d_pp, pp_elems * 4) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers"));
+                    hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
+                                       (const uint32_t *)nullptr, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, d_pp);
+                    const hipError_t ce = hipMemcpy(pp.data(), d_pp, pp_elems * 4, hipMemcpyDeviceToHost);
+                    (void)hipFree(d_pp);
+                    if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
+                }
                 const uint32_t *rp = h_rowptr.data();
                 const size_t nr = (size_t)p.nrows;
                 // rows whose share of ONE panel is enormous (16x the long-row threshold) leave the sweep for
@@ -862,9 +879,16 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
                         if (heavy[r]) continue;                          // segment kernels
                         if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
                     }
-                    std::stable_sort(order.begin(), order.end(), [lo, hi](uint32_t a, uint32_t b) {
-                        return (hi[a] - lo[a]) > (hi[b] - lo[b]);
-                    });
+                    {   // stable counting sort by item length, longest first (O(items + longest))
+                        uint32_t longest = 0;
+                        for (uint32_t r : order) longest = std::max(longest, hi[r] - lo[r]);
+                        std::vector<size_t> start((size_t)longest + 2, 0);
+                        for (uint32_t r : order) start[(size_t)(longest - (hi[r] - lo[r])) + 1]++;
+                        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+                        std::vector<uint32_t> sorted(order.size());
+                        for (uint32_t r : order) sorted[start[(size_t)(longest - (hi[r] - lo[r]))]++] = r;
+                        order.swap(sorted);
+                    }
                     uint32_t nco = 0;
                     for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
                     p.panel_coop.push_back(nco);
