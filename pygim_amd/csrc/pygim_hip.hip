@@ -82,12 +82,10 @@ struct Part {
     uint32_t *colind = nullptr;
     void *vals = nullptr;        // nullptr when all ones
     bool own_rowptr = false, own_rowind = false, own_colind = false, own_vals = false;
-    // long-row plan (rows with more than long_row_threshold entries)
-    // lp_base: used by the row-per-wave kernels; lp_panel: used with the panel sweep, where a row is
+    // long-row plans (rows cut into segments over many waves).  lp_base: used by the row-per-wave kernels; lp_panel: used with the panel sweep, where a row is
     // only "long" when its share of ONE panel would be (threshold x npanels): segment kernels gather
     // whole rows of X past the L2 blocking, so the panel sweep keeps as many rows as it can
     LongPlan lp_base, lp_panel;
-    // L2-blocked plan: degree-sorted row order + per-panel entry ranges of every row
     // L2-blocked plan: per column panel, the list of (row, first entry, length|FIRST) work items
     // sorted by length (rows without entries in a panel do not appear in its list)
     uint32_t *d_items = nullptr;            // [3][n_items]: rows | begins | lens
@@ -443,6 +441,122 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
     }
 }
 
+// One-time plans of a part (needs its row pointers on the host): the long-row segment plans and the
+// L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
+// (spmm_mul_csr.c:118-259) -- same purpose, different machine.
+int build_plans(Part &p, size_t es, hipStream_t st) {
+    std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
+    if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(PYGIM_ERR_HIP, "rowptr D2H");
+    auto build_long = [&](LongPlan &lp, uint32_t thresh, const std::vector<char> *flags) -> bool {
+        lp.thresh = thresh;
+        std::vector<uint32_t> tasks, desc;
+        const uint32_t seg = (uint32_t)std::min<int64_t>(thresh, std::max<int64_t>(64, g_tune.long_segment));
+        plan_long_rows(h_rowptr.data(), p.nrows, thresh, seg, flags, tasks, desc);
+        lp.n_tasks = (uint32_t)(tasks.size() / 3);
+        lp.n_long = (uint32_t)(desc.size() / 3);
+        if (!lp.n_tasks) return true;
+        return hipMalloc((void **)&lp.d_tasks, tasks.size() * 4) == hipSuccess &&
+               hipMalloc((void **)&lp.d_desc, desc.size() * 4) == hipSuccess &&
+               hipMemcpy(lp.d_tasks, tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemcpy(lp.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    const uint32_t base_thresh = (uint32_t)std::min<int64_t>(0x7FFFFFFF, std::max<int64_t>(64, g_tune.long_row_threshold));
+    if (!build_long(p.lp_base, base_thresh, nullptr)) return fail(PYGIM_ERR_HIP, "long-row plan upload");
+    // L2-blocked plan: columns cut into panels whose 128-byte feature slice fits the L2 budget,
+    // per panel the length-sorted list of work items
+    if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
+        const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
+        uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
+        bool worth = g_tune.panel_mode == 1 || npan == 1 ||
+                     (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
+        if (!worth) {
+            // too few entries per (row, panel) for L2 blocking.  Rows of at most one cache line still
+            // gain from the sweep's other half -- length-sorted items, 32-id column chunks, wave-
+            // cooperative long rows -- so they get a ONE-panel plan (no blocking, no X copy); wider
+            // rows are better served by whole-row gathers (k_csr_wide).
+            int64_t wmax = 1;
+            for (auto dcw : p.dense_cols) wmax = std::max(wmax, dcw);
+            if (wmax * (int64_t)es <= 128) {
+                npan = 1;
+                worth = true;
+            }
+        }
+        if (worth) {
+            p.npanels = npan;
+            p.panel_cols = (uint32_t)((p.ncols + npan - 1) / npan);
+            // panel pointers of every row (device binary searches), then the lists on the host
+            const size_t pp_elems = (size_t)(npan + 1) * (size_t)p.nrows;
+            std::vector<uint32_t> pp(pp_elems);
+            if (npan == 1) {
+                std::copy(h_rowptr.begin(), h_rowptr.end() - 1, pp.begin());
+                std::copy(h_rowptr.begin() + 1, h_rowptr.end(), pp.begin() + p.nrows);
+            } else {
+                uint32_t *d_pp = nullptr;
+                if (hipMalloc((void **)&d_pp, pp_elems * 4) != hipSuccess) return fail(PYGIM_ERR_HIP, "panel pointers");
+                hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
+                                   (const uint32_t *)nullptr, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, d_pp);
+                const hipError_t ce = hipMemcpy(pp.data(), d_pp, pp_elems * 4, hipMemcpyDeviceToHost);
+                (void)hipFree(d_pp);
+                if (ce != hipSuccess) return fail(PYGIM_ERR_HIP, "panel pointers D2H");
+            }
+            const uint32_t *rp = h_rowptr.data();
+            const size_t nr = (size_t)p.nrows;
+            // rows whose share of ONE panel is enormous (16x the long-row threshold) leave the sweep for
+            // the segment kernels; merely long items stay and are walked by a whole wave (panel_coop)
+            std::vector<char> heavy(nr, 0);
+            for (uint32_t q = 0; q < npan; q++) {
+                const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
+                for (size_t r = 0; r < nr; r++)
+                    if ((uint64_t)(hi[r] - lo[r]) > (uint64_t)base_thresh * 16) heavy[r] = 1;
+            }
+            if (!build_long(p.lp_panel, base_thresh, &heavy)) return fail(PYGIM_ERR_HIP, "long-row plan upload");
+            std::vector<uint32_t> rows_v, beg_v, len_v, order;
+            p.panel_off.assign(1, 0);
+            p.panel_coop.clear();
+            const uint32_t coop_cap = (uint32_t)std::max<int64_t>(64, g_tune.panel_coop);
+            for (uint32_t q = 0; q < npan; q++) {
+                const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
+                order.clear();
+                for (size_t r = 0; r < nr; r++) {
+                    const uint32_t deg = rp[r + 1] - rp[r];
+                    if (heavy[r]) continue;                          // segment kernels
+                    if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
+                }
+                {   // stable counting sort by item length, longest first (O(items + longest))
+                    uint32_t longest = 0;
+                    for (uint32_t r : order) longest = std::max(longest, hi[r] - lo[r]);
+                    std::vector<size_t> start((size_t)longest + 2, 0);
+                    for (uint32_t r : order) start[(size_t)(longest - (hi[r] - lo[r])) + 1]++;
+                    for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+                    std::vector<uint32_t> sorted(order.size());
+                    for (uint32_t r : order) sorted[start[(size_t)(longest - (hi[r] - lo[r]))]++] = r;
+                    order.swap(sorted);
+                }
+                uint32_t nco = 0;
+                for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
+                p.panel_coop.push_back(nco);
+                for (uint32_t r : order) {
+                    rows_v.push_back(r);
+                    beg_v.push_back(lo[r]);
+                    const uint32_t first = (lo[r] == rp[r]) ? 0x80000000u : 0u;  // no entries in earlier panels
+                    len_v.push_back((hi[r] - lo[r]) | first);
+                }
+                p.panel_off.push_back(rows_v.size());
+            }
+            p.n_items = rows_v.size();
+            if (p.n_items > 0) {
+                if (hipMalloc((void **)&p.d_items, 3 * p.n_items * 4) != hipSuccess ||
+                    hipMemcpy(p.d_items, rows_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(p.d_items + p.n_items, beg_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(p.d_items + 2 * p.n_items, len_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(PYGIM_ERR_HIP, "panel plan upload");
+            }
+        }
+    }
+    return 0;
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -752,7 +866,6 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         if (v) {
             if ((rc = to_device<void>(v, (size_t)p.nnz * es, &p.vals, &p.own_vals, st))) return bail(rc);
         }
-        std::vector<uint32_t> h_rowptr;
         if (format == PYGIM_CSR) {
             if ((rc = to_device<uint32_t>(idx0[i], (size_t)(p.nrows + 1) * 4, &p.rowptr, &p.own_rowptr, st))) return bail(rc);
             hipLaunchKernelGGL(k_check_csr, dim3((unsigned)((std::max(p.nrows + 1, p.nnz) + 255) / 256)), dim3(256), 0,
@@ -801,115 +914,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.vals = nullptr;
             p.own_vals = false;
         }
-        std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
-        if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return bail(fail(PYGIM_ERR_HIP, "rowptr D2H"));
-        auto build_long = [&](LongPlan &lp, uint32_t thresh, const std::vector<char> *flags) -> bool {
-            lp.thresh = thresh;
-            std::vector<uint32_t> tasks, desc;
-            const uint32_t seg = (uint32_t)std::min<int64_t>(thresh, std::max<int64_t>(64, g_tune.long_segment));
-            plan_long_rows(h_rowptr.data(), p.nrows, thresh, seg, flags, tasks, desc);
-            lp.n_tasks = (uint32_t)(tasks.size() / 3);
-            lp.n_long = (uint32_t)(desc.size() / 3);
-            if (!lp.n_tasks) return true;
-            return hipMalloc((void **)&lp.d_tasks, tasks.size() * 4) == hipSuccess &&
-                   hipMalloc((void **)&lp.d_desc, desc.size() * 4) == hipSuccess &&
-                   hipMemcpy(lp.d_tasks, tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                   hipMemcpy(lp.d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-        };
-        const uint32_t base_thresh = (uint32_t)std::min<int64_t>(0x7FFFFFFF, std::max<int64_t>(64, g_tune.long_row_threshold));
-        if (!build_long(p.lp_base, base_thresh, nullptr)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
-        // L2-blocked plan (CSR groups): rows sorted by degree, columns cut into panels whose
-        // 128-byte feature slice fits the L2 budget
-        if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
-            const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
-            uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
-            bool worth = g_tune.panel_mode == 1 || npan == 1 ||
-                         (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
-            if (!worth) {
-                // too few entries per (row, panel) for L2 blocking.  Rows of at most one cache line still
-                // gain from the sweep's other half -- length-sorted items, 32-id column chunks, wave-
-                // cooperative long rows -- so they get a ONE-panel plan (no blocking, no X copy); wider
-                // rows are better served by whole-row gathers (k_csr_wide).
-                int64_t wmax = 1;
-                for (auto dcw : p.dense_cols) wmax = std::max(wmax, dcw);
-                if (wmax * (int64_t)es <= 128) {
-                    npan = 1;
-                    worth = true;
-                }
-            }
-            if (worth) {
-                p.npanels = npan;
-                p.panel_cols = (uint32_t)((p.ncols + npan - 1) / npan);
-                // panel pointers of every row (device binary searches), then the lists on the host
-                const size_t pp_elems = (size_t)(npan + 1) * (size_t)p.nrows;
-                std::vector<uint32_t> pp(pp_elems);
-                if (npan == 1) {
-                    std::copy(h_rowptr.begin(), h_rowptr.end() - 1, pp.begin());
-                    std::copy(h_rowptr.begin() + 1, h_rowptr.end(), pp.begin() + p.nrows);
-                } else {
-                    uint32_t *d_pp = nullptr;
-                    if (hipMalloc((void **)&d_pp, pp_elems * 4) != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers"));
-                    hipLaunchKernelGGL(k_build_panel_ptr, dim3((unsigned)((pp_elems + 255) / 256)), dim3(256), 0, st,
-                                       (const uint32_t *)nullptr, p.rowptr, p.colind, (uint32_t)p.nrows, npan, p.panel_cols, d_pp);
-                    const hipError_t ce = hipMemcpy(pp.data(), d_pp, pp_elems * 4, hipMemcpyDeviceToHost);
-                    (void)hipFree(d_pp);
-                    if (ce != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "panel pointers D2H"));
-                }
-                const uint32_t *rp = h_rowptr.data();
-                const size_t nr = (size_t)p.nrows;
-                // rows whose share of ONE panel is enormous (16x the long-row threshold) leave the sweep for
-                // the segment kernels; merely long items stay and are walked by a whole wave (panel_coop)
-                std::vector<char> heavy(nr, 0);
-                for (uint32_t q = 0; q < npan; q++) {
-                    const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
-                    for (size_t r = 0; r < nr; r++)
-                        if ((uint64_t)(hi[r] - lo[r]) > (uint64_t)base_thresh * 16) heavy[r] = 1;
-                }
-                if (!build_long(p.lp_panel, base_thresh, &heavy)) return bail(fail(PYGIM_ERR_HIP, "long-row plan upload"));
-                std::vector<uint32_t> rows_v, beg_v, len_v, order;
-                p.panel_off.assign(1, 0);
-                p.panel_coop.clear();
-                const uint32_t coop_cap = (uint32_t)std::max<int64_t>(64, g_tune.panel_coop);
-                for (uint32_t q = 0; q < npan; q++) {
-                    const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
-                    order.clear();
-                    for (size_t r = 0; r < nr; r++) {
-                        const uint32_t deg = rp[r + 1] - rp[r];
-                        if (heavy[r]) continue;                          // segment kernels
-                        if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
-                    }
-                    {   // stable counting sort by item length, longest first (O(items + longest))
-                        uint32_t longest = 0;
-                        for (uint32_t r : order) longest = std::max(longest, hi[r] - lo[r]);
-                        std::vector<size_t> start((size_t)longest + 2, 0);
-                        for (uint32_t r : order) start[(size_t)(longest - (hi[r] - lo[r])) + 1]++;
-                        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
-                        std::vector<uint32_t> sorted(order.size());
-                        for (uint32_t r : order) sorted[start[(size_t)(longest - (hi[r] - lo[r]))]++] = r;
-                        order.swap(sorted);
-                    }
-                    uint32_t nco = 0;
-                    for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
-                    p.panel_coop.push_back(nco);
-                    for (uint32_t r : order) {
-                        rows_v.push_back(r);
-                        beg_v.push_back(lo[r]);
-                        const uint32_t first = (lo[r] == rp[r]) ? 0x80000000u : 0u;  // no entries in earlier panels
-                        len_v.push_back((hi[r] - lo[r]) | first);
-                    }
-                    p.panel_off.push_back(rows_v.size());
-                }
-                p.n_items = rows_v.size();
-                if (p.n_items > 0) {
-                    if (hipMalloc((void **)&p.d_items, 3 * p.n_items * 4) != hipSuccess ||
-                        hipMemcpy(p.d_items, rows_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                        hipMemcpy(p.d_items + p.n_items, beg_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                        hipMemcpy(p.d_items + 2 * p.n_items, len_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
-                        return bail(fail(PYGIM_ERR_HIP, "panel plan upload"));
-                }
-            }
-        }
+        if ((rc = build_plans(p, es, st))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;
