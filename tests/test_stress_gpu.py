@@ -1,0 +1,98 @@
+"""Randomised parity sweep on the GPU: shapes, degree skew, widths, element types, formats, sp/ds splits and
+kernel-plan knobs drawn from a seeded generator; every result is compared with the oracle (bit-exact:
+integer-valued features keep float sums exact in any order).  Also: hipGraph capture of a product."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ALL_DTYPES, NP_DTYPES, coalesce, driver_features
+from pygim_amd import _lib
+from test_parity_gpu import run_group_host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def backend():
+    assert torch.cuda.is_available()
+    _lib.init_ranks(1)
+    yield
+    _lib.release()
+
+
+def skewed_csr(rng, nrows, ncols, mean_deg, sigma, clustered):
+    deg = np.minimum(np.floor(np.exp(rng.normal(np.log(max(mean_deg, 0.3)), sigma, nrows))).astype(np.int64), 6000)
+    deg[rng.random(nrows) < 0.1] = 0
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    if clustered:
+        centre = np.repeat((np.arange(nrows) * ncols / max(nrows, 1)).astype(np.int64), deg)
+        col = np.clip(centre + rng.integers(-max(ncols // 20, 2), max(ncols // 20, 2), size=int(rowptr[-1])), 0, ncols - 1)
+    else:
+        col = rng.integers(0, ncols, size=int(rowptr[-1]), dtype=np.int64)
+    for r in range(nrows):
+        col[rowptr[r]:rowptr[r + 1]].sort()
+    return rowptr.astype(np.int32), col.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dt = ALL_DTYPES[seed % 6]
+    npdt = NP_DTYPES[dt]
+    fmt = "COO" if rng.random() < 0.4 else "CSR"
+    nrows = int(rng.integers(1, 900))
+    ncols = int(rng.integers(1, 2500))
+    h = int(rng.choice([1, 2, 7, 16, 31, 32, 48, 64, 100, 128, 200, 256, 320]))
+    rowptr, col = skewed_csr(rng, nrows, ncols, float(rng.choice([0.5, 3, 12, 60])), float(rng.choice([0.3, 1.0, 1.6])),
+                             bool(rng.random() < 0.4))
+    weighted = bool(rng.random() < 0.4)
+    knobs = {"panel_mode": int(rng.choice([0, 1, 2])), "panel_bytes": int(rng.choice([128 * 16, 128 * 200, 4 << 20])),
+             "panel_coop": int(rng.choice([64, 512, 1 << 20])), "long_row_threshold": int(rng.choice([128, 4096])),
+             "long_segment": int(rng.choice([64, 512])), "coo_chunk": int(rng.choice([64, 512])),
+             "panel_pack": int(rng.choice([0, 1]))}
+    old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
+    try:
+        x = driver_features(rng, ncols, h, npdt)
+        if fmt == "CSR":
+            vals = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else None
+            ref = oracle.spmm_csr(rowptr, col, vals, x)
+            out, _ = run_group_host("CSR", [rowptr], [col], None if vals is None else [vals], [nrows], [ncols], [x], h)
+        else:
+            r, c, v = coalesce(rowptr, col, npdt)
+            if weighted:
+                v = (v * rng.integers(1, 3, size=len(v))).astype(npdt)
+            ref = oracle.spmm_coo(r, c, v, x, nrows)
+            out, _ = run_group_host("COO", [r], [c], [v], [nrows], [ncols], [x], h)
+        assert np.array_equal(out, ref), (seed, dt, fmt, nrows, ncols, h, knobs)
+    finally:
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
+
+
+def test_product_is_graph_capturable(rng=np.random.default_rng(3)):
+    """the run entry points only enqueue work on the caller's stream (plus a forked side stream joined by
+    events), so a warmed-up product can be captured into a hipGraph and replayed"""
+    rowptr, col = skewed_csr(rng, 3000, 3000, 30, 1.2, False)
+    rowptr[-1] = len(col)
+    x = driver_features(rng, 3000, 128, np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    drp, dcol, dx = d(rowptr), d(col), d(x)
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [drp.data_ptr()], [dcol.data_ptr()], None, [3000], [3000], [len(col)], [1], [128], 128)
+    out = torch.zeros((3000, 128), dtype=torch.float32, device="cuda")
+    ref = oracle.spmm_csr(rowptr, col, None, x)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):  # warm-up: scratch buffers get their size outside the capture
+            _lib.spmm_run_group(hd, [dx.data_ptr()], out.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        _lib.spmm_run_group(hd, [dx.data_ptr()], out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    dx.copy_(torch.from_numpy(x))  # same buffers, replay
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    _lib.group_free(hd)
