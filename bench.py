@@ -70,7 +70,16 @@ def cpu_baseline(rowptr, col, x, args):
     oracle.spmm_csr_rowpar(rp, cl, None, xh, nthreads=threads, out=out)
     dt = time.perf_counter() - t0
     gflops = 2.0 * nnz * xh.shape[1] / dt / 1e9
-    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"),
             "sample": f"rows [0,{nrows}) of the same graph ({nnz} nnz, h={xh.shape[1]}), "
                       f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
 
