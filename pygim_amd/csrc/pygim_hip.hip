@@ -471,16 +471,12 @@ int build_plans(Part &p, size_t es, hipStream_t st) {
         bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                      (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
         if (!worth) {
-            // too few entries per (row, panel) for L2 blocking.  Rows of at most one cache line still
-            // gain from the sweep's other half -- length-sorted items, 32-id column chunks, wave-
-            // cooperative long rows -- so they get a ONE-panel plan (no blocking, no X copy); wider
-            // rows are better served by whole-row gathers (k_csr_wide).
-            int64_t wmax = 1;
-            for (auto dcw : p.dense_cols) wmax = std::max(wmax, dcw);
-            if (wmax * (int64_t)es <= 128) {
-                npan = 1;
-                worth = true;
-            }
+            // too few entries per (row, panel) for L2 blocking: ONE panel.  The sweep's other half --
+            // length-sorted items, 32-id column chunks, line-sized gathers from the slice-major copy, wave-
+            // cooperative long rows -- still beats whole-row gathers (products-shaped, X = 2.5 GB:
+            // 23.8 ms against 28.6 ms for k_csr_wide)
+            npan = 1;
+            worth = true;
         }
         if (worth) {
             p.npanels = npan;
