@@ -6,19 +6,19 @@
 //               val[e] * X[col[e], k]
 // in val_dt arithmetic (spmm_default/support/common.h:39-60): integers are
 // two's-complement modular at the element width, floats are summed in stored
-// order.  How it is computed is CDNA4-specific:
-//   * a 64-lane wavefront spreads over the FEATURE dimension with one 16-byte
-//     vector per lane (1 KiB of a row of X per wave-instruction), so every
-//     gather of an X row is one fully coalesced global_load_dwordx4;
-//   * column ids (and values) of up to 64 entries are fetched with one coalesced
-//     load per wave and handed out through v_readlane (scalar registers), so the
-//     address of each gathered row is scalar-base + lane offset;
-//   * 8 row gathers are kept in flight per wave before the first add;
-//   * sums stay in registers in stored order -> bit-identical to a sequential CPU
-//     loop for every row handled by a single wave.
-// Rows longer than a threshold are cut into fixed-size segments handled by
-// separate waves; the segment sums are added in segment order by a second small
-// kernel (deterministic, no atomics).
+// order.  How it is computed is CDNA4-specific.  Kernels, most used first:
+//   k_csr_panel / panel_sweep   the general path: features cut into 128-byte slices (one
+//       cache line per gathered row), columns into L2-sized panels, one launch per panel over
+//       length-sorted (row, panel) work items; an 8-lane group per item, a whole wave for long
+//       items; XCD-aware block->slice mapping; X read from a slice-major copy (k_slice_pack).
+//   k_csr_wide, k_csr_sub       row-per-wave / rows-per-wave gathers for operands that are not
+//       16-byte aligned (odd widths, grande's 8-byte-padded windows).
+//   k_long_segments + k_long_reduce   rows far too long for one wave: fixed segments on a forked
+//       stream, partial sums added in segment order (deterministic, no atomics).
+//   k_coo_wide + k_coo_fixup    native COO: equal-nnz chunks per wave, carries fixed up in order.
+//   k_absmax_bits / k_quantize / k_dequantize   the conv layers' quantiser around the product.
+// Sums stay in registers in stored order wherever one lane group owns a row, which makes float
+// results bit-identical to a sequential CPU loop there (the file is built with -ffp-contract=off).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
