@@ -315,7 +315,8 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st);
-            if (g_tune.panel_pack && nslices > 1) {
+            // (rows of one slice that are already contiguous lines need no copy)
+            if (g_tune.panel_pack && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128)) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
                 const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
                                   g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
