@@ -198,6 +198,36 @@ def _spmv_run_group(handle, B_parts):
     return out
 
 
+# ---- MatrixMarket debug loaders of the default variant (spmm_default/utils.hpp:139-173) -------------
+def _read_mtx_csr(filename):
+    import scipy.io
+    import scipy.sparse
+
+    m = scipy.sparse.csr_matrix(scipy.io.mmread(filename))
+    m.sort_indices()
+    return m
+
+
+def _read_matrix_rowptr(filename: str):
+    return torch.from_numpy(_read_mtx_csr(filename).indptr.astype("int32"))
+
+
+def _read_matrix_colind(filename: str):
+    return torch.from_numpy(_read_mtx_csr(filename).indices.astype("int32"))
+
+
+def _read_matrix_values(filename: str):
+    return torch.from_numpy(_read_mtx_csr(filename).data.astype("int32"))  # int32 view, like the reference
+
+
+def _read_matrix_nrows(filename: str):
+    return int(_read_mtx_csr(filename).shape[0])
+
+
+def _read_matrix_ncols(filename: str):
+    return int(_read_mtx_csr(filename).shape[1])
+
+
 _SCHEMAS = {
     "spmm": [
         ("dpu_init_ranks(int nr_ranks) -> ()", _dpu_init_ranks_void),
@@ -210,6 +240,11 @@ _SCHEMAS = {
         ("spmm_coo_to_device_group(Tensor[] row_indices, Tensor[] col_indices, Tensor[] values, int[] nrows, "
          "int[] ncols, int[] dense_cols, int h_size) -> int", _spmm_coo_to_device_group),
         ("spmm_coo_run_group(int sp_group_ptr, Tensor[] B_parts) -> Tensor", _spmm_run_group),
+        ("read_matrix_rowptr(str filename) -> Tensor", _read_matrix_rowptr),
+        ("read_matrix_colind(str filename) -> Tensor", _read_matrix_colind),
+        ("read_matrix_values(str filename) -> Tensor", _read_matrix_values),
+        ("read_matrix_nrows(str filename) -> int", _read_matrix_nrows),
+        ("read_matrix_ncols(str filename) -> int", _read_matrix_ncols),
     ],
     "grande": [
         ("dpu_init_ranks(int nr_ranks) -> int[]", _dpu_init_ranks_list),

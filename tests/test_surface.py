@@ -175,3 +175,20 @@ def test_partition_chooser():
     assert not t[0].panel
     cfg = at.autotune(232965, 232965, 114615892, 256)
     assert len(cfg) == 5 and cfg[0] * cfg[1] == 8
+
+
+def test_matrix_market_debug_ops(fake, tmp_path):
+    """read_matrix_* of the default variant (spmm_default/utils.hpp:139-173): .mtx -> int32 CSR arrays"""
+    import scipy.io
+    import scipy.sparse as sp
+
+    m = sp.random(30, 20, density=0.2, format="coo", random_state=3, data_rvs=lambda k: np.arange(1, k + 1).astype(float))
+    path = str(tmp_path / "tiny.mtx")
+    scipy.io.mmwrite(path, m)
+    pim_ops.load("spmm")
+    csr = m.tocsr()
+    csr.sort_indices()
+    assert torch.ops.pim_ops.read_matrix_nrows(path) == 30 and torch.ops.pim_ops.read_matrix_ncols(path) == 20
+    assert torch.ops.pim_ops.read_matrix_rowptr(path).tolist() == csr.indptr.tolist()
+    assert torch.ops.pim_ops.read_matrix_colind(path).tolist() == csr.indices.tolist()
+    assert torch.ops.pim_ops.read_matrix_values(path).dtype == torch.int32
