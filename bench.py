@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU, 4 otherwise)")
+    ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
 
@@ -131,73 +131,107 @@ def main():
     _lib.set_tunable("kernel_events", 1)
     rowptr_cpu = rowptr.cpu()
     split = nnz_balanced_row_split(rowptr_cpu, world)
-    # each rank's row block is cut again into `chunks` nnz-balanced pieces so that the all-gather of
-    # piece k (RCCL's stream) overlaps the product of piece k+1 (this stream)
-    K = max(1, args.chunks if args.chunks > 0 else (4 if world > 1 else 1))
-
-    def chunk_bounds(r):
-        a, bnd = split[r], split[r + 1]
-        sub = nnz_balanced_row_split(rowptr_cpu[a:bnd + 1] - rowptr_cpu[a], K)
-        return [a + v for v in sub]
-
-    bounds = [chunk_bounds(r) for r in range(world)]
-    mine_b = bounds[rank]
-    handles, outs, gathers = [], [], []
-    my_rows = my_nnz = 0
-    keep = []
-    for c in range(K):
-        c0, c1 = mine_b[c], mine_b[c + 1]
-        lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
-        rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
-        col_c = col[lo:hi].contiguous()
-        keep += [rp_c, col_c]
-        handles.append(_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None,
-                                         [c1 - c0], [n], [hi - lo], [1], [h], h))
-        pad_rows = max(bounds[r][c + 1] - bounds[r][c] for r in range(world))
-        # gather buffer of piece c: world blocks of pad_rows rows; this rank's block is written in place
-        g = torch.empty((world, max(pad_rows, 1), h), dtype=torch.float32, device=dev)
-        gathers.append(g)
-        outs.append(g[rank])
-        my_rows += c1 - c0
-        my_nnz += hi - lo
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
-    # pieces run on their own streams (measured on one GPU: 4 pieces of a 1/8 row block cost 1.40 ms on
-    # 4 streams vs 1.78 ms back to back); piece 0 also re-lays X slice-major, the others wait for it
-    side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if world > 1 else []
 
-    def step():
-        if world == 1:
+    class Pieces:
+        """This rank's row block cut into K nnz-balanced pieces.  On N > 1 GPUs every piece runs on its
+        own stream and is all-gathered (RCCL) as soon as it is done, so the exchange of piece k overlaps
+        the products of the other pieces; piece 0 also re-lays X slice-major, the others wait for it."""
+
+        def __init__(self, K):
+            self.K = K
+            self.bounds = []
+            for r in range(world):
+                a0, b0 = split[r], split[r + 1]
+                sub = nnz_balanced_row_split(rowptr_cpu[a0:b0 + 1] - rowptr_cpu[a0], K)
+                self.bounds.append([a0 + v for v in sub])
+            self.mine_b = self.bounds[rank]
+            self.handles, self.outs, self.gathers, self.keep = [], [], [], []
+            self.my_rows = self.my_nnz = 0
             for c in range(K):
-                _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
-                _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
-            return
-        pending = []
-        _lib.set_tunable("xs_reuse", 0)
-        _lib.spmm_run_group(handles[0], [x.data_ptr()], outs[0].data_ptr(), stream)
-        ready = torch.cuda.Event()
-        ready.record(main_stream)
-        pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
-        _lib.set_tunable("xs_reuse", 1)
-        for c in range(1, K):
-            s = side[c - 1]
-            s.wait_event(ready)
-            with torch.cuda.stream(s):
-                _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s.cuda_stream)
-                pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
-        for c, wk in enumerate(pending):
-            if c == 0:
-                wk.wait()
-            else:
-                with torch.cuda.stream(side[c - 1]):
-                    wk.wait()
-        for s in side:
-            main_stream.wait_stream(s)
+                c0, c1 = self.mine_b[c], self.mine_b[c + 1]
+                lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
+                rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
+                col_c = col[lo:hi].contiguous()
+                self.keep += [rp_c, col_c]
+                self.handles.append(_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None,
+                                                      [c1 - c0], [n], [hi - lo], [1], [h], h))
+                pad_rows = max(self.bounds[r][c + 1] - self.bounds[r][c] for r in range(world))
+                # gather buffer of piece c: world blocks of pad_rows rows; this rank's block is written in place
+                g = torch.empty((world, max(pad_rows, 1), h), dtype=torch.float32, device=dev)
+                self.gathers.append(g)
+                self.outs.append(g[rank])
+                self.my_rows += c1 - c0
+                self.my_nnz += hi - lo
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if world > 1 else []
+
+        def step(self):
+            K, handles, outs, gathers, side = self.K, self.handles, self.outs, self.gathers, self.side
+            if world == 1:
+                for c in range(K):
+                    _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
+                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
+                return
+            pending = []
+            _lib.set_tunable("xs_reuse", 0)
+            _lib.spmm_run_group(handles[0], [x.data_ptr()], outs[0].data_ptr(), stream)
+            ready = torch.cuda.Event()
+            ready.record(main_stream)
+            pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
+            _lib.set_tunable("xs_reuse", 1)
+            for c in range(1, K):
+                s_c = side[c - 1]
+                s_c.wait_event(ready)
+                with torch.cuda.stream(s_c):
+                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s_c.cuda_stream)
+                    pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
+            for c, wk in enumerate(pending):
+                if c == 0:
+                    wk.wait()  # stream-level wait, the host does not block
+                else:
+                    with torch.cuda.stream(side[c - 1]):
+                        wk.wait()
+            for s_c in side:
+                main_stream.wait_stream(s_c)
+
+        def free(self):
+            for hd in self.handles:
+                _lib.group_free(hd)
+            self.handles = []
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # number of pieces: fixed by --chunks, else 1 on one GPU and, on N > 1, whichever of 1 / 2 / 4 is
+    # fastest on THIS node (measured before the warm-up; all ranks agree through a max-reduce)
+    if args.chunks > 0 or world == 1:
+        plan = Pieces(max(1, args.chunks))
+    else:
+        best = None
+        for cand in (1, 2, 4):
+            pl = Pieces(cand)
+            for _ in range(2):
+                pl.step()
+            fence()
+            t_c = time.perf_counter()
+            for _ in range(3):
+                pl.step()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if best is None or float(tt.item()) < best[0]:
+                if best is not None:
+                    best[1].free()
+                best = (float(tt.item()), pl)
+            else:
+                pl.free()
+        plan = best[1]
+    K, step = plan.K, plan.step
+    handles, outs, gathers, bounds, mine_b = plan.handles, plan.outs, plan.gathers, plan.bounds, plan.mine_b
+    my_rows, my_nnz = plan.my_rows, plan.my_nnz
 
     for _ in range(args.warmup):
         step()

@@ -571,8 +571,9 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     // 8 * nslices strands are taken slice-major, nslices per XCD, and an XCD walks its strands one after
     // the other.  So an XCD's L2 holds one slice panel at a time, whatever nslices is (8 slices: XCD x =
     // slice x; 4 slices: two XCDs share a slice; 16 slices: an XCD does two slices in turn).
-    constexpr uint32_t ITEMS_PER_BLOCK = COOP ? 4u : 4u * G;  // 4 waves per block
-    const uint32_t item_blocks = (nitems + ITEMS_PER_BLOCK - 1) / ITEMS_PER_BLOCK;
+    const uint32_t nwaves = blockDim.x >> 6;  // waves per block (launch parameter)
+    const uint32_t items_per_block = COOP ? nwaves : nwaves * G;
+    const uint32_t item_blocks = (nitems + items_per_block - 1) / items_per_block;
     const uint32_t strand_len = (item_blocks + 7) >> 3;
     const uint32_t xcd = blk & 7u, kseq = blk >> 3;
     const uint32_t strand = xcd * nslices + kseq / strand_len;
@@ -580,7 +581,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     const uint32_t rb = (strand & 7u) + 8u * (kseq % strand_len);
     if (rb >= item_blocks) return;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint64_t i64 = COOP ? ((uint64_t)rb * 4 + wv) : (((uint64_t)rb * 4 + wv) * G + grp);
+    const uint64_t i64 = COOP ? ((uint64_t)rb * nwaves + wv) : (((uint64_t)rb * nwaves + wv) * G + grp);
     const bool row_ok = i64 < nitems;
     const uint32_t i = row_ok ? (uint32_t)i64 : 0u;
     // work item = (row, first entry, length | FIRST flag): the part of one row that falls into

@@ -63,6 +63,7 @@ struct Tunables {
     int64_t panel_mode = 0;             // 0 = auto (cost rule), 1 = force the L2-blocked panel kernel, 2 = never
     int64_t panel_bytes = 4 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
     int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
+    int64_t panel_block = 256;          // threads per block of the sweep kernel (64, 128 or 256)
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
@@ -310,7 +311,9 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             constexpr int LOG_LPR = 3;
             constexpr uint32_t F = VEC << LOG_LPR;            // elements per 128-byte slice
             const uint32_t nslices = (w + F - 1) / F;
-            const uint32_t rows_per_block = 4 * (64 >> LOG_LPR);
+            const uint32_t bthreads = (g_tune.panel_block == 64 || g_tune.panel_block == 128) ? (uint32_t)g_tune.panel_block : 256u;
+            const uint32_t bwaves = bthreads >> 6;
+            const uint32_t rows_per_block = bwaves * (64 >> LOG_LPR);
             // gather source: slice-major copy (default) or the caller's row-major X
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
@@ -344,12 +347,12 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 if (cnt == 0) continue;
                 const uint32_t ncoop = p.panel_coop[q], nnorm = cnt - ncoop;
                 const uint32_t row_blocks = (nnorm + rows_per_block - 1) / rows_per_block;
-                const uint32_t coop_blocks = (ncoop + 3) / 4;  // one wave per long item, 4 waves per block
+                const uint32_t coop_blocks = (ncoop + bwaves - 1) / bwaves;  // one wave per long item
                 const uint32_t coop_grid = ncoop ? 8u * nslices * ((coop_blocks + 7) / 8) : 0u;
                 const uint32_t norm_grid = nnorm ? 8u * nslices * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(coop_grid + norm_grid), dim3(256), 0, st,           \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,      \
                        ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xg, ldg, \
                        slice_stride, C, ldc, w, nslices, accumulate ? 1 : 0)
                 if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
@@ -797,6 +800,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
     else if (n == "panel_pack") slot = &g_tune.panel_pack;
     else if (n == "panel_coop") slot = &g_tune.panel_coop;
+    else if (n == "panel_block") slot = &g_tune.panel_block;
     else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
     if (!slot) return -1;
     const int64_t old = *slot;
