@@ -960,6 +960,18 @@ __global__ void k_check_csr(const uint32_t *__restrict__ rowptr, const uint32_t 
     if (i == 0 && (rowptr[0] != 0 || rowptr[nrows] != nnz)) flag[0] = 1;
     if (i < nnz && colind[i] >= ncols) flag[1] = 1;
 }
+// flag[0] |= 1 when some row's column ids are not non-decreasing (column panels need sorted rows)
+__global__ void k_check_sorted_cols(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
+                                    uint32_t nrows, int *flag) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t s = rowptr[r], e = rowptr[r + 1];
+    for (uint32_t k = s + 1; k < e; k++)
+        if (colind[k - 1] > colind[k]) {
+            flag[0] = 1;
+            return;
+        }
+}
 template <typename T> __global__ void k_check_ones(const T *__restrict__ v, uint32_t n, int *flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !(v[i] == T(1))) flag[0] = 1;

@@ -448,7 +448,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // One-time plans of a part (needs its row pointers on the host): the long-row segment plans and the
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
-int build_plans(Part &p, size_t es, hipStream_t st) {
+int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
     if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PYGIM_ERR_HIP, "rowptr D2H");
@@ -474,6 +474,17 @@ int build_plans(Part &p, size_t es, hipStream_t st) {
         uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
         bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                      (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
+        if (npan > 1 && worth) {
+            // column panels are cut by binary search inside each row: the rows must hold sorted column ids
+            // (torch_sparse / coalesce() deliver them sorted); otherwise fall back to one panel
+            int unsorted = 0;
+            if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
+            hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr,
+                               p.colind, (uint32_t)p.nrows, d_flag_sorted);
+            if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(PYGIM_ERR_HIP, "sortedness check");
+            if (unsorted) worth = false;
+        }
         if (!worth) {
             // too few entries per (row, panel) for L2 blocking: ONE panel.  The sweep's other half --
             // length-sorted items, 32-id column chunks, line-sized gathers from the slice-major copy, wave-
@@ -915,7 +926,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.vals = nullptr;
             p.own_vals = false;
         }
-        if ((rc = build_plans(p, es, st))) return bail(rc);
+        if ((rc = build_plans(p, es, g->d_flags + 4, st))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;

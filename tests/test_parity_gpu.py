@@ -311,3 +311,22 @@ def test_panel_cooperative_items(rng, dt):
         _lib.set_tunable("panel_mode", old[0])
         _lib.set_tunable("panel_bytes", old[1])
         _lib.set_tunable("panel_coop", old[2])
+
+
+def test_unsorted_columns_inside_rows(rng):
+    """CSR whose rows hold their column ids in arbitrary order: column panels (binary search per row) must not
+    be used; the result is still exact"""
+    rowptr, col = random_csr(rng, 400, 3000, 40)
+    col = col.copy()
+    for r in range(400):
+        rng.shuffle(col[rowptr[r]:rowptr[r + 1]])
+    x = driver_features(rng, 3000, 64, np.int32)
+    ref = oracle.spmm_csr(rowptr, col, None, x)
+    old = [_lib.set_tunable("panel_mode", 1), _lib.set_tunable("panel_bytes", 128 * 100)]
+    try:
+        out, info = run_group_host("CSR", [rowptr], [col], None, [400], [3000], [x], 64)
+        assert info["n_panels"] == 1
+        assert np.array_equal(out, ref)
+    finally:
+        _lib.set_tunable("panel_mode", old[0])
+        _lib.set_tunable("panel_bytes", old[1])
