@@ -10,8 +10,6 @@ Dataset statistics are the public PyG / OGB figures, pinned here as constants.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 
 # name -> (N, nnz, d_max)
@@ -119,4 +117,4 @@ def flops(nnz, h):
 
 
 __all__ = ["SHAPES", "degrees", "make_csr", "make_shape", "csr_to_coo_coalesced", "features",
-           "algorithmic_bytes", "gather_bytes", "flops", "math"]
+           "algorithmic_bytes", "gather_bytes", "flops"]
