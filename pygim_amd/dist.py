@@ -23,7 +23,7 @@ world_size 2 over gloo.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.distributed as dist
