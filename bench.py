@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature"])
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
@@ -200,19 +201,102 @@ def main():
                 _lib.group_free(hd)
             self.handles = []
 
+        def full_c(self):
+            """the assembled [n, h] result as this rank holds it after a step"""
+            return torch.cat([self.gathers[c][r, : self.bounds[r][c + 1] - self.bounds[r][c]]
+                              for r in range(world) for c in range(self.K)])
+
+        def describe(self):
+            if world == 1:
+                return "single GPU" if self.K == 1 else f"single GPU, {self.K} row pieces"
+            return (f"sp_parts={world} as an nnz-balanced row split, {self.K} piece(s) per rank on their own streams, each "
+                    f"all-gathered (RCCL) as soon as it is done")
+
+    class FeaturePieces:
+        """ds_parts = world: rank r owns the feature block X[:, r*h/world : (r+1)*h/world] and computes that
+        block of C for ALL rows (A replicated), in K nnz-balanced row pieces on their own streams; each piece
+        is all-gathered along the feature dimension and laid row-major as soon as it is done."""
+
+        def __init__(self, K):
+            self.K = K
+            self.hw = h // world
+            self.f0 = rank * self.hw
+            self.b = nnz_balanced_row_split(rowptr_cpu, K)
+            self.C = torch.empty((n, h), dtype=torch.float32, device=dev)
+            self.handles, self.gathers, self.keep = [], [], []
+            self.my_rows, self.my_nnz = n, nnz
+            for c in range(K):
+                c0, c1 = self.b[c], self.b[c + 1]
+                lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
+                rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
+                col_c = col[lo:hi].contiguous()
+                self.keep += [rp_c, col_c]
+                self.handles.append(_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None,
+                                                      [c1 - c0], [n], [hi - lo], [1], [self.hw], self.hw))
+                self.gathers.append(torch.empty((world, max(c1 - c0, 1), self.hw), dtype=torch.float32, device=dev))
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
+
+        def _piece(self, c, s):
+            c0, c1 = self.b[c], self.b[c + 1]
+            g = self.gathers[c]
+            mine = g[rank]
+            # product on the strided feature window of X (row stride h): C_block[rows_c, hw]
+            _lib.block_run(self.handles[c], 0, x.data_ptr() + 4 * self.f0, h, mine.data_ptr(), self.hw, self.hw, False,
+                           s.cuda_stream)
+            if world > 1:
+                wk = dist.all_gather_into_tensor(g.view(-1), mine.reshape(-1), async_op=True)
+                wk.wait()
+            if c1 > c0:
+                self.C[c0:c1].view(c1 - c0, world, self.hw).copy_(g[:, : c1 - c0].permute(1, 0, 2))
+
+        def step(self):
+            _lib.set_tunable("xs_reuse", 0)
+            self._piece(0, main_stream)
+            if self.K > 1:
+                ready = torch.cuda.Event()
+                ready.record(main_stream)
+                _lib.set_tunable("xs_reuse", 1)  # same feature window of the same X within this step
+                for c in range(1, self.K):
+                    s_c = self.side[c - 1]
+                    s_c.wait_event(ready)
+                    with torch.cuda.stream(s_c):
+                        self._piece(c, s_c)
+                for s_c in self.side:
+                    main_stream.wait_stream(s_c)
+
+        def free(self):
+            for hd in self.handles:
+                _lib.group_free(hd)
+            self.handles = []
+
+        def full_c(self):
+            return self.C
+
+        def describe(self):
+            return (f"ds_parts={world} as a feature split (A replicated, {self.hw} features per rank), {self.K} row piece(s) "
+                    f"per rank on their own streams, each all-gathered (RCCL) along the features and laid row-major")
+
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # number of pieces: fixed by --chunks, else 1 on one GPU and, on N > 1, whichever of 1 / 2 / 4 is
-    # fastest on THIS node (measured before the warm-up; all ranks agree through a max-reduce)
-    if args.chunks > 0 or world == 1:
-        plan = Pieces(max(1, args.chunks))
+    # partition and number of pieces: fixed by --partition / --chunks, else a single piece on one GPU and,
+    # on N > 1, whichever candidate is fastest on THIS node (measured before the warm-up; all ranks agree
+    # through a max-reduce): row split (sp_parts) in 1 / 2 / 4 pieces, feature split (ds_parts) in 1 / 2
+    feat_ok = h % world == 0 and (h // world) * 4 >= 32
+    cands = []
+    if args.partition in ("auto", "row"):
+        cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if world == 1 else (1, 2, 4)))]
+    if args.partition in ("auto", "feature") and feat_ok and (world > 1 or args.partition == "feature"):
+        cands += [(FeaturePieces, k) for k in ((args.chunks,) if args.chunks > 0 else (1, 2))]
+    assert cands, "no admissible partition"
+    if len(cands) == 1:
+        plan = cands[0][0](cands[0][1])
     else:
         best = None
-        for cand in (1, 2, 4):
-            pl = Pieces(cand)
+        for cls, kk in cands:
+            pl = cls(kk)
             for _ in range(2):
                 pl.step()
             fence()
@@ -221,17 +305,20 @@ def main():
                 pl.step()
             fence()
             tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             if best is None or float(tt.item()) < best[0]:
                 if best is not None:
                     best[1].free()
                 best = (float(tt.item()), pl)
             else:
                 pl.free()
+            del pl
         plan = best[1]
     K, step = plan.K, plan.step
-    handles, outs, gathers, bounds, mine_b = plan.handles, plan.outs, plan.gathers, plan.bounds, plan.mine_b
+    handles = plan.handles
     my_rows, my_nnz = plan.my_rows, plan.my_nnz
+    my_h = getattr(plan, "hw", h)
 
     for _ in range(args.warmup):
         step()
@@ -258,7 +345,7 @@ def main():
 
     # roofline of the dominant kernel on THIS rank's block: HIP events (on the launch stream) bracket
     # the panel launches of each product; kernel_ms = their sum per product
-    alg_bytes = synth.algorithmic_bytes(my_rows, n, my_nnz, h, 4, "CSR", with_values=True)
+    alg_bytes = synth.algorithmic_bytes(my_rows, n, my_nnz, my_h, 4, "CSR", with_values=True)
     k_ms = k_ms_sum / max(k_count, 1)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic = None
@@ -276,8 +363,8 @@ def main():
                 "kernel": kname, "kernel_ms": round(k_ms, 4), "products_timed": k_count,
                 "launches_per_product": max(n_panels, 1),
                 "algorithmic_bytes": alg_bytes,
-                "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
-                "fp32_frac": round(synth.flops(my_nnz, h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None}
+                "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
+                "fp32_frac": round(synth.flops(my_nnz, my_h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None}
 
     result = {
         "metric": "SpMM GFLOP/s, Reddit-shaped CSR h=256 fp32", "value": round(gflops, 2), "unit": "GFLOP/s",
@@ -285,7 +372,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
                    "columns": "clustered" if args.clustered else "uniform",
-                   "partition": "single GPU" if world == 1 else f"nnz-balanced row split x{world}, {K} pieces per rank on {K} streams, each piece all-gathered (RCCL) as soon as it is done"},
+                   "partition": plan.describe()},
         "roofline": roofline,
     }
 
@@ -293,11 +380,11 @@ def main():
         base, cpu_out = cpu_baseline(rowptr, col, x, args)
         result["cpu_baseline"] = base
         if not args.no_check:
-            got = torch.cat([outs[c][: mine_b[c + 1] - mine_b[c]] for c in range(K)])[: cpu_out.shape[0]].cpu().numpy()
+            got = plan.full_c()[: cpu_out.shape[0]].cpu().numpy()
             result["check"] = "bit-exact vs oracle on the sampled rows" if np.array_equal(got, cpu_out) else "MISMATCH"
     if world > 1:
         # every rank now holds every block: column-count checksum of the assembled C (exact: small integers)
-        full = torch.cat([gathers[c][r, : bounds[r][c + 1] - bounds[r][c]] for r in range(world) for c in range(K)])
+        full = plan.full_c()
         colcount = torch.bincount(col.long(), minlength=n).double()
         ok = full.shape[0] == n and torch.equal(full.double().sum(0), colcount @ x.double())
         flag = torch.tensor([0 if ok else 1], device=dev)
