@@ -407,7 +407,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
 
 int launch_block_any(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w,
                      bool accumulate, hipStream_t st) {
-    if (w <= 0) return 0;
+    if (w <= 0 || p.nrows == 0) return 0;  // nothing to write
     switch (g->dtype) {
         case PYGIM_INT8: return launch_block<int8_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
         case PYGIM_INT16: return launch_block<int16_t>(g, p, X, ldx, C, ldc, w, accumulate, st);

@@ -205,6 +205,9 @@ def test_error_behaviour(rng):
     out, _ = run_group_host("COO", [np.zeros(0, np.int32)], [np.zeros(0, np.int32)], [np.zeros(0, np.int32)], [50],
                             [50], [x], 8)
     assert not out.any()
+    # no rows at all
+    out, _ = run_group_host("CSR", [np.zeros(1, np.int32)], [np.zeros(0, np.int32)], None, [0], [50], [x], 8)
+    assert out.shape == (0, 8)
 
 
 @pytest.mark.parametrize("dt", ALL_DTYPES)
