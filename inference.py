@@ -107,4 +107,5 @@ def main(args):
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("PYGIM_DATA_LOG", "1")  # the reference's per-run [DATA] timer lines
     main(get_args())

@@ -34,6 +34,18 @@ _variant = None
 _groups = {}  # handle -> dict(keepalive tensors, dtype, shapes)
 
 
+def _log_timers(handle, on_host: bool) -> None:
+    """the reference prints its Timer buckets after every run (spmm_mul_csr.c:563-580, parsed by
+    utils/experiment.py:468-491); same keys, in milliseconds, when PYGIM_DATA_LOG=1 (the driver scripts set it)"""
+    import os
+
+    if not on_host or os.environ.get("PYGIM_DATA_LOG", "0") != "1":
+        return
+    t = _lib.group_timers(handle)
+    print(f"[DATA]load_sparse_time: {t[4]:.3f}\n[DATA]load_dense_time: {t[0]:.3f}\n[DATA]kernel_time: {t[1]:.3f}\n"
+          f"[DATA]retrieve_result_time: {t[2]:.3f}\n[DATA]alignment_time: {t[3]:.3f}", flush=True)
+
+
 def _stream_of(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
@@ -145,6 +157,7 @@ def _spmm_run_group(handle, B_parts):
         parts.append(b.contiguous())
     out = torch.empty((g["rows"], g["h"]), dtype=g["dtype"], device=dev)
     _lib.spmm_run_group(handle, [b.data_ptr() for b in parts], out.data_ptr(), _stream_of(out))
+    _log_timers(handle, not out.is_cuda)
     return out
 
 
@@ -171,6 +184,7 @@ def _grande_run_group(handle, B_parts):
     out = torch.empty((g["rows"], g["h"]), dtype=g["dtype"], device=dev)
     _lib.grande_run_group(handle, [b.data_ptr() for b in parts], [b.size(1) for b in parts], out.data_ptr(),
                           _stream_of(out))
+    _log_timers(handle, not out.is_cuda)
     return out
 
 
@@ -195,6 +209,7 @@ def _spmv_run_group(handle, B_parts):
         vecs.append(b.contiguous())
     out = torch.empty((g["rows"], nd), dtype=g["dtype"], device=dev)
     _lib.spmv_run_group(handle, [b.data_ptr() for b in vecs], out.data_ptr(), _stream_of(out))
+    _log_timers(handle, not out.is_cuda)
     return out
 
 

@@ -10,6 +10,7 @@ are compared (the reference has the comparison commented out, spmm_test.py:36-37
 """
 import argparse
 import datetime
+import os
 import sys
 
 import torch
@@ -113,4 +114,5 @@ def main(args):
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("PYGIM_DATA_LOG", "1")  # the reference's per-run [DATA] timer lines
     main(get_args())
