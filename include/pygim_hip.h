@@ -18,7 +18,12 @@
  *
  * Threading: like the reference (one process-global `dpus` singleton,
  * spmm_default/pytorch_api.cpp:152) the library holds one device context per
- * process; calls are not re-entrant for the same group handle.
+ * process; calls are not re-entrant for the same group handle.  The tunables and
+ * the slice-major copy of X are process-global: products that run concurrently on
+ * DIFFERENT streams must either share the same X (tunable "xs_reuse" = 1 after the
+ * first of them was enqueued and an event orders them, as bench.py does) or be
+ * serialised by the caller.  Scratch buffers are sized on first use (hipMalloc), so
+ * capture a product into a hipGraph only after one warm-up call.
  */
 #ifndef PYGIM_HIP_H
 #define PYGIM_HIP_H
