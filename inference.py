@@ -32,6 +32,7 @@ def test(args, model, data):
     if y_pred.is_cuda:
         torch.cuda.synchronize()
     print("[DATA]infer_time(ms): ", (datetime.datetime.now() - st).total_seconds() * 1000, flush=True)
+    print("[DATA]logits_checksum: ", float(y_pred.double().abs().sum()), flush=True)
     y_pred = y_pred.argmax(dim=-1)
     return (y_pred.eq(data["y"]).sum() / y_pred.size(0)).item()
 
@@ -67,8 +68,10 @@ def main(args):
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        backend = os.environ.get("PYGIM_BENCH_BACKEND", "nccl")  # gloo = logic check with several ranks on one GPU
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr if backend == "nccl" else lr % torch.cuda.device_count())
+        dist.init_process_group(backend)
         args.device = "cuda"
     n, nnz, dmax = DATASETS[args.dataset]
     gen = "cuda" if torch.cuda.is_available() else "cpu"
