@@ -33,6 +33,8 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     elif not os.path.exists(_REF_PATH):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(_HERE, "_ref", "libref_utils.so")) and os.path.isdir("/root/reference"):
+        subprocess.call(["make", "-C", _HERE, "ref_utils"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 _lib = None
@@ -206,6 +208,33 @@ def ref_partition_tsklt_by_nnz_coo(nnz, nparts):
     split = np.zeros(nparts + 2, dtype=np.uint32)
     ref.partition_tsklt_by_nnz_coo(ctypes.c_uint32(nnz), _p(split), ctypes.c_int(nparts))
     return split[: nparts + 1]
+
+
+_REF_UTILS_PATH = os.path.join(_HERE, "_ref", "libref_utils.so")
+
+
+def have_ref_utils():
+    return os.path.exists(_REF_UTILS_PATH)
+
+
+def ref_read_matrix_csr(path):
+    """The reference's own reader (spmm_default/utils.hpp:15-70 readCOOMatrix, :87-127 coo2csr,
+    compiled in place by `make ref_utils` with INT32 values): returns (nrows, ncols, rowptr, colind,
+    values) exactly as its read_matrix_* debug ops would see them."""
+    import torch  # noqa: F401  (libref_utils.so links libtorch: load torch's copies first)
+    ref = ctypes.CDLL(_REF_UTILS_PATH)
+    rd = getattr(ref, "_Z13readCOOMatrixPKc")
+    rd.restype = ctypes.POINTER(_RefCOO)
+    cv = getattr(ref, "_Z7coo2csrP9COOMatrix")
+    cv.restype = ctypes.POINTER(_RefCSR)
+    cv.argtypes = [ctypes.POINTER(_RefCOO)]
+    coo = rd(os.fsencode(path))
+    csr = cv(coo).contents
+    n, nnz = int(csr.nrows), int(csr.nnz)
+    take = lambda ptr, cnt, dt: np.ctypeslib.as_array(
+        ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)), shape=(cnt,)).view(dt).copy()
+    return (n, int(csr.ncols), take(csr.rowptr, n + 1, np.uint32), take(csr.colind, max(nnz, 1), np.uint32)[:nnz],
+            take(csr.values, max(nnz, 1), np.int32)[:nnz])
 
 
 # --------------------------------------------------------------------------- #

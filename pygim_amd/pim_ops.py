@@ -19,6 +19,8 @@ per call) or on the HIP device (no copies; the result stays on the device).
 """
 from __future__ import annotations
 
+import types
+
 import torch
 
 from . import _lib
@@ -215,12 +217,33 @@ def _spmv_run_group(handle, B_parts):
 
 # ---- MatrixMarket debug loaders of the default variant (spmm_default/utils.hpp:139-173) -------------
 def _read_mtx_csr(filename):
-    import scipy.io
-    import scipy.sparse
+    """The reference's reader, restated (spmm_default/utils.hpp:16-70 readCOOMatrix, :86-127 coo2csr):
+    skip '%' lines; first data line = rows cols nnz; row and column counts padded up to even; 1-based
+    indices; the value column is IGNORED (every stored value is 1); entries keep file order inside a row."""
+    import numpy as np
 
-    m = scipy.sparse.csr_matrix(scipy.io.mmread(filename))
-    m.sort_indices()
-    return m
+    rows, cols = [], []
+    shape = None
+    with open(filename) as fh:
+        for line in fh:
+            tok = line.split()
+            if not tok or tok[0].startswith("%"):
+                continue
+            if shape is None:
+                shape = (int(tok[0]), int(tok[1]), int(tok[2]))
+                continue
+            rows.append(int(tok[0]) - 1)
+            cols.append(int(tok[1]) - 1)
+    nrows, ncols, nnz = shape
+    nrows += nrows % 2
+    ncols += ncols % 2
+    r = np.asarray(rows[:nnz], dtype=np.int64)
+    c = np.asarray(cols[:nnz], dtype=np.int64)
+    order = np.argsort(r, kind="stable")
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=nrows), out=rowptr[1:])
+    return types.SimpleNamespace(indptr=rowptr, indices=c[order], data=np.ones(len(order), dtype=np.int32),
+                                 shape=(nrows, ncols))
 
 
 def _read_matrix_rowptr(filename: str):

@@ -177,18 +177,47 @@ def test_partition_chooser():
     assert len(cfg) == 5 and cfg[0] * cfg[1] == 8
 
 
-def test_matrix_market_debug_ops(fake, tmp_path):
-    """read_matrix_* of the default variant (spmm_default/utils.hpp:139-173): .mtx -> int32 CSR arrays"""
-    import scipy.io
-    import scipy.sparse as sp
+def _write_mtx(path, nrows, ncols, rows, cols, vals=None, comments=2):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        for k in range(comments):
+            f.write("% comment line {}\n".format(k))
+        f.write("{} {} {}\n".format(nrows, ncols, len(rows)))
+        for k, (r, c) in enumerate(zip(rows, cols)):
+            v = 1.0 if vals is None else vals[k]
+            f.write("{} {} {}\n".format(r + 1, c + 1, v))
 
-    m = sp.random(30, 20, density=0.2, format="coo", random_state=3, data_rvs=lambda k: np.arange(1, k + 1).astype(float))
+
+def _restated_reader(path, nrows, ncols, rows, cols):
+    """what utils.hpp:15-127 produces: shape padded to even, ones, file order kept inside each row"""
+    nr, nc = nrows + nrows % 2, ncols + ncols % 2
+    order = np.argsort(np.asarray(rows), kind="stable")
+    rowptr = np.zeros(nr + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=nr), out=rowptr[1:])
+    return nr, nc, rowptr, np.asarray(cols)[order]
+
+
+@pytest.mark.parametrize("shape", [(30, 20), (31, 17), (7, 7)])
+def test_matrix_market_debug_ops(fake, tmp_path, shape):
+    """read_matrix_* of the default variant (spmm_default/utils.hpp:139-173): .mtx -> int32 CSR arrays with the
+    reference reader's semantics (even-padded shape, value column ignored = ones, unsorted columns kept in file
+    order) and, where oracle/_ref/libref_utils.so exists, equal to the reference reader itself."""
+    import oracle
+
+    rng = np.random.default_rng(shape[0])
+    nnz = 5 * shape[0]
+    rows, cols = rng.integers(0, shape[0], nnz), rng.integers(0, shape[1], nnz)
     path = str(tmp_path / "tiny.mtx")
-    scipy.io.mmwrite(path, m)
+    _write_mtx(path, shape[0], shape[1], rows, cols, vals=rng.integers(2, 9, nnz))
     pim_ops.load("spmm")
-    csr = m.tocsr()
-    csr.sort_indices()
-    assert torch.ops.pim_ops.read_matrix_nrows(path) == 30 and torch.ops.pim_ops.read_matrix_ncols(path) == 20
-    assert torch.ops.pim_ops.read_matrix_rowptr(path).tolist() == csr.indptr.tolist()
-    assert torch.ops.pim_ops.read_matrix_colind(path).tolist() == csr.indices.tolist()
-    assert torch.ops.pim_ops.read_matrix_values(path).dtype == torch.int32
+    nr, nc, rowptr, colind = _restated_reader(path, shape[0], shape[1], rows, cols)
+    ops = torch.ops.pim_ops
+    assert ops.read_matrix_nrows(path) == nr and ops.read_matrix_ncols(path) == nc
+    got_ptr, got_col, got_val = ops.read_matrix_rowptr(path), ops.read_matrix_colind(path), ops.read_matrix_values(path)
+    assert got_ptr.dtype == got_col.dtype == got_val.dtype == torch.int32
+    assert got_ptr.tolist() == rowptr.tolist() and got_col.tolist() == colind.tolist()
+    assert got_val.tolist() == [1] * nnz
+    if oracle.have_ref_utils():
+        rn, rc, rptr, rcol, rval = oracle.ref_read_matrix_csr(path)
+        assert (rn, rc) == (nr, nc)
+        assert rptr.tolist() == got_ptr.tolist() and rcol.tolist() == got_col.tolist() and rval.tolist() == got_val.tolist()
