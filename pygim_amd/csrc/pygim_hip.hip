@@ -66,6 +66,7 @@ struct Tunables {
     int64_t panel_block = 256;          // threads per block of the sweep kernel (64, 128 or 256)
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
+    int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
     int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
@@ -341,6 +342,20 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             }
             // 32-bit gather offsets when every gathered byte of a slice sits below 4 GiB of its base
             const bool off32 = ((uint64_t)p.ncols * (uint64_t)ldg + F) * sizeof(T) < (1ull << 32);
+            // X far beyond the Infinity Cache (256 MiB): sweep a few slices per launch, every XCD on the same
+            // slice(s), so that the gather footprint of a launch is ncols * 128 B * group instead of all of X
+            uint32_t sgroup = nslices;
+            if (g_tune.slice_group_bytes > 0) {
+                const uint64_t per_slice = (uint64_t)p.ncols * F * sizeof(T);
+                if (per_slice * nslices > (uint64_t)g_tune.slice_group_bytes)
+                    sgroup = (uint32_t)std::max<uint64_t>(1, (uint64_t)g_tune.slice_group_bytes / std::max<uint64_t>(per_slice, 1));
+                sgroup = std::min(sgroup, nslices);
+            }
+            for (uint32_t s0 = 0; s0 < nslices; s0 += sgroup) {
+            const uint32_t ns = std::min(sgroup, nslices - s0);
+            const T *Xs0 = Xg + (int64_t)s0 * slice_stride;
+            T *Cs0 = C + (size_t)s0 * F;
+            const uint32_t ws = std::min<uint32_t>(w - s0 * F, ns * F);
             for (uint32_t q = 0; q < p.npanels; q++) {
                 const size_t o = p.panel_off[q];
                 const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
@@ -348,18 +363,19 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t ncoop = p.panel_coop[q], nnorm = cnt - ncoop;
                 const uint32_t row_blocks = (nnorm + rows_per_block - 1) / rows_per_block;
                 const uint32_t coop_blocks = (ncoop + bwaves - 1) / bwaves;  // one wave per long item
-                const uint32_t coop_grid = ncoop ? 8u * nslices * ((coop_blocks + 7) / 8) : 0u;
-                const uint32_t norm_grid = nnorm ? 8u * nslices * ((row_blocks + 7) / 8) : 0u;
+                const uint32_t coop_grid = ncoop ? 8u * ns * ((coop_blocks + 7) / 8) : 0u;
+                const uint32_t norm_grid = nnorm ? 8u * ns * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
     hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,      \
-                       ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xg, ldg, \
-                       slice_stride, C, ldc, w, nslices, accumulate ? 1 : 0)
+                       ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xs0, ldg, \
+                       slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0)
                 if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
                 else if (off32) PYGIM_LAUNCH_PANEL(true, false);
                 else if (vals) PYGIM_LAUNCH_PANEL(false, true);
                 else PYGIM_LAUNCH_PANEL(false, false);
 #undef PYGIM_LAUNCH_PANEL
+            }
             }
             kt.stop();
             return join();
@@ -813,7 +829,11 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_coop") slot = &g_tune.panel_coop;
     else if (n == "panel_block") slot = &g_tune.panel_block;
     else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
-    if (!slot) return -1;
+    else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
+    if (!slot) {
+        fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
+        return -1;
+    }
     const int64_t old = *slot;
     *slot = value;
     return old;

@@ -227,6 +227,33 @@ def test_panel_kernel_all_types(rng, dt):
         _lib.set_tunable("panel_bytes", old[1])
 
 
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+@pytest.mark.parametrize("group_slices", [1, 3])
+def test_panel_sweep_in_slice_groups(rng, dt, group_slices):
+    """X beyond the Infinity Cache is swept a few feature slices per launch (tunable slice_group_bytes):
+    forced here on a small graph, 1 or 3 slices at a time, ragged last group, weighted and unweighted,
+    slice-major copy and row-major gathers"""
+    npdt = NP_DTYPES[dt]
+    ncols = 500
+    old = {k: _lib.set_tunable(k, v) for k, v in
+           {"panel_mode": 1, "panel_bytes": 128 * 200, "slice_group_bytes": ncols * 128 * group_slices}.items()}
+    try:
+        rowptr, col = random_csr(rng, 300, ncols, 9, empty_frac=0.1, long_rows=[(5, 1500)])
+        vals = rng.integers(-3, 4, size=len(col)).astype(npdt)
+        for pack in (1, 0):
+            old_pack = _lib.set_tunable("panel_pack", pack)
+            for h in (32, 100, 256, 264):
+                x = driver_features(rng, ncols, h, npdt)
+                for v in (None, vals):
+                    ref = oracle.spmm_csr(rowptr, col, v, x)
+                    out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [300], [ncols], [x], h)
+                    assert np.array_equal(out, ref), (dt, h, pack, v is not None)
+            _lib.set_tunable("panel_pack", old_pack)
+    finally:
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
+
+
 @pytest.mark.parametrize("dt", ["FLT32", "DBL64"])
 def test_panel_kernel_keeps_stored_order(rng, dt):
     """real-valued features and weights: the panel sweep continues each row's running sum from C,
