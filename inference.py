@@ -19,7 +19,7 @@ from pygim_amd.backend_pim.grande import prepare_pim_spmm_grande
 from pygim_amd.backend_pim.spmm import prepare_pim_spmm
 from pygim_amd.backend_pim.spmv import prepare_pim_spmv
 from pygim_amd.sparse_tensor import SparseTensor
-from spmm_test import DATASETS, TORCH_TYPES
+from spmm_test import DATASETS, TORCH_TYPES, load_ops
 
 
 @torch.no_grad()
@@ -89,7 +89,7 @@ def main(args):
 
         data["adj_t"] = RowSplitAdj(rowptr.cpu(), col.cpu(), n, args.data_type, args.hidden_size)
     else:
-        pim_ops.load(args.version)
+        load_ops(args)
         if args.version == "grande":
             units = torch.ops.pim_ops.dpu_init_ranks(args.sp_parts)
             data["adj_t"] = prepare_pim_spmm_grande(adj_t, args, units)

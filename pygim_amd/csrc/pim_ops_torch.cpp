@@ -9,6 +9,11 @@
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -109,6 +114,18 @@ void spmm_free_group(int64_t handle) {
     chk(pygim_group_free(handle));
 }
 
+// the reference prints its Timer buckets after every run (spmm_default/spmm_mul_csr.c:563-580; parsed by
+// utils/experiment.py:466-491): same keys, milliseconds, for host-tensor calls when PYGIM_DATA_LOG=1
+void log_timers(int64_t handle, bool on_host) {
+    const char *e = std::getenv("PYGIM_DATA_LOG");
+    if (!on_host || !e || e[0] != '1') return;
+    double t[5] = {0, 0, 0, 0, 0};
+    if (pygim_group_timers(handle, t) != 0) return;
+    std::printf("[DATA]load_sparse_time: %.3f\n[DATA]load_dense_time: %.3f\n[DATA]kernel_time: %.3f\n"
+                "[DATA]retrieve_result_time: %.3f\n[DATA]alignment_time: %.3f\n", t[4], t[0], t[1], t[2], t[3]);
+    std::fflush(stdout);
+}
+
 at::Tensor run_common(int64_t handle, std::vector<at::Tensor> &parts, int kind) {
     const Meta &m = meta(handle);
     TORCH_CHECK(!parts.empty(), "no dense parts");
@@ -126,6 +143,7 @@ at::Tensor run_common(int64_t handle, std::vector<at::Tensor> &parts, int kind) 
     if (kind == 0) chk(pygim_spmm_run_group(handle, ptrs.data(), out.data_ptr(), st));
     else if (kind == 1) chk(pygim_grande_run_group(handle, ptrs.data(), lds.data(), out.data_ptr(), st));
     else chk(pygim_spmv_run_group(handle, ptrs.data(), out.data_ptr(), st));
+    log_timers(handle, !out.is_cuda());
     return out;
 }
 
@@ -192,6 +210,68 @@ at::Tensor spmv_coo_run_group(int64_t handle, std::vector<at::Tensor> B_parts) {
 #endif
 #endif
 
+#if PYGIM_VARIANT == 0
+// ---- MatrixMarket debug ops (spmm_default/utils.hpp:139-173) ------------------------------------
+// Same result as the reference reader + coo2csr (utils.hpp:15-127): '%' lines skipped, the size line
+// gives rows / columns / entries, both dimensions padded to even, indices 1-based in the file, the
+// value column ignored (every stored value is 1), entries of a row kept in file order.
+struct MtxCsr {
+    int64_t nrows = 0, ncols = 0;
+    std::vector<int32_t> rowptr, colind, values;
+};
+MtxCsr read_mtx(const std::string &path) {
+    std::ifstream in(path);
+    TORCH_CHECK(in.good(), "cannot open ", path);
+    MtxCsr m;
+    std::vector<int32_t> r, c;
+    std::string line;
+    bool sized = false;
+    int64_t nnz = 0;
+    while (std::getline(in, line)) {
+        const size_t b = line.find_first_not_of(" \t\r");
+        if (b == std::string::npos || line[b] == '%') continue;
+        const char *p = line.c_str() + b;
+        char *q = nullptr;
+        const long a0 = std::strtol(p, &q, 10);
+        const long a1 = std::strtol(q, &q, 10);
+        if (!sized) {
+            nnz = std::strtol(q, &q, 10);
+            m.nrows = a0 + (a0 & 1);
+            m.ncols = a1 + (a1 & 1);
+            r.reserve((size_t)nnz);
+            c.reserve((size_t)nnz);
+            sized = true;
+        } else if ((int64_t)r.size() < nnz) {
+            r.push_back((int32_t)(a0 - 1));
+            c.push_back((int32_t)(a1 - 1));
+        }
+    }
+    TORCH_CHECK(sized, "no size line in ", path);
+    TORCH_CHECK((int64_t)r.size() == nnz, path, ": size line promises ", nnz, " entries, file holds ", r.size());
+    m.rowptr.assign((size_t)m.nrows + 1, 0);
+    for (size_t k = 0; k < r.size(); k++) {
+        TORCH_CHECK(r[k] >= 0 && r[k] < m.nrows && c[k] >= 0 && c[k] < m.ncols, path, ": entry ", k, " out of range");
+        m.rowptr[(size_t)r[k] + 1]++;
+    }
+    for (int64_t i = 0; i < m.nrows; i++) m.rowptr[(size_t)i + 1] += m.rowptr[(size_t)i];
+    std::vector<int32_t> next(m.rowptr.begin(), m.rowptr.end() - 1);
+    m.colind.resize(r.size());
+    for (size_t k = 0; k < r.size(); k++) m.colind[(size_t)next[(size_t)r[k]]++] = c[k];
+    m.values.assign(r.size(), 1);
+    return m;
+}
+at::Tensor as_i32(const std::vector<int32_t> &v) {
+    at::Tensor t = at::empty({(int64_t)v.size()}, at::kInt);
+    if (!v.empty()) std::memcpy(t.data_ptr<int32_t>(), v.data(), v.size() * sizeof(int32_t));
+    return t;
+}
+at::Tensor read_matrix_rowptr(std::string f) { return as_i32(read_mtx(f).rowptr); }
+at::Tensor read_matrix_colind(std::string f) { return as_i32(read_mtx(f).colind); }
+at::Tensor read_matrix_values(std::string f) { return as_i32(read_mtx(f).values); }
+int64_t read_matrix_nrows(std::string f) { return read_mtx(f).nrows; }
+int64_t read_matrix_ncols(std::string f) { return read_mtx(f).ncols; }
+#endif
+
 }  // namespace
 
 TORCH_LIBRARY(pim_ops, m) {
@@ -209,6 +289,11 @@ TORCH_LIBRARY(pim_ops, m) {
 #if PYGIM_VARIANT == 0
     m.def("spmm_coo_to_device_group", &spmm_coo_to_device_group);
     m.def("spmm_coo_run_group", &spmm_coo_run_group);
+    m.def("read_matrix_rowptr", &read_matrix_rowptr);
+    m.def("read_matrix_colind", &read_matrix_colind);
+    m.def("read_matrix_values", &read_matrix_values);
+    m.def("read_matrix_nrows", &read_matrix_nrows);
+    m.def("read_matrix_ncols", &read_matrix_ncols);
 #endif
 #endif
 }

@@ -323,6 +323,8 @@ def load(variant: str = "spmm"):
     if _variant == variant:
         return
     if _library is not None:
+        if _library == "native":
+            raise RuntimeError("a libbackend_pim.so is already loaded in this process (one variant per process, like the reference)")
         _library._destroy()
         _library = None
     lib = torch.library.Library("pim_ops", "DEF")
@@ -332,16 +334,36 @@ def load(variant: str = "spmm"):
     _library, _variant = lib, variant
 
 
-def load_library(path: str):
-    """``torch.ops.load_library(args.lib_path)`` counterpart (spmm_test.py:111).
-
-    A reference-style path (``./backend_pim/spmm_grande/build/libbackend_pim.so``) selects
-    the variant by its directory name; anything else loads the default SpMM variant.
-    """
+def variant_of(path: str) -> str:
+    """variant a reference-style library path names (``.../spmm_grande/build/libbackend_pim.so``)"""
     p = path.lower()
     if "grande" in p:
-        load("grande")
-    elif "spmv" in p or "sparsep" in p:
-        load("spmv")
-    else:
-        load("spmm")
+        return "grande"
+    if "spmv" in p or "sparsep" in p:
+        return "spmv"
+    return "spmm"
+
+
+def load_library(path: str):
+    """``torch.ops.load_library(args.lib_path)`` counterpart (spmm_test.py:111, inference.py:134).
+
+    An existing shared object is loaded exactly that way (the TORCH_LIBRARY shim over the C ABI that
+    ``make -C pygim_amd/csrc shims`` puts at the reference's paths); a path that does not exist selects
+    the variant by its directory name and registers the same ops from Python over the same C ABI.
+    """
+    global _library, _variant
+    import os
+
+    path = path.strip('"')
+    variant = variant_of(path)
+    if not os.path.isfile(path):
+        return load(variant)
+    _lib.lib()  # libpygim_hip.so (and torch's HIP runtime) first; fails loudly when not built
+    if _variant == variant:
+        return
+    if _library is not None:
+        if _library == "native":
+            raise RuntimeError("a libbackend_pim.so is already loaded in this process (one variant per process, like the reference)")
+        _library._destroy()
+    torch.ops.load_library(path)
+    _library, _variant = "native", variant

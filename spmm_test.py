@@ -86,12 +86,22 @@ def get_args():
     return args
 
 
+def load_ops(args):
+    """``torch.ops.load_library(args.lib_path)`` (reference spmm_test.py:111) when --lib_path names a built
+    library of the variant --version asks for; otherwise the same ops are registered from Python over the
+    same C ABI (the flag defaults name the spmm_default library whatever --version says)."""
+    path = args.lib_path.strip('"')
+    if os.path.isfile(path) and pim_ops.variant_of(path) == args.version:
+        pim_ops.load_library(path)
+    else:
+        pim_ops.load(args.version)
+
+
 def main(args):
     adj_t, x = load_graph(args)
     pim_adj_t = None
     if args.version != "cpu":
-        # --lib_path selects the variant, as the reference's one-.so-per-variant builds do
-        pim_ops.load({"spmm": "spmm", "grande": "grande", "spmv": "spmv"}[args.version])
+        load_ops(args)
         dpus_per_rank = None
         if args.nr_dpus == 0:
             if args.version == "grande":

@@ -22,6 +22,35 @@ names = {"spmm": ["spmm_csr_to_device_group", "spmm_csr_run_group", "spmm_coo_to
          "spmv": ["spmv_coo_to_device_group", "spmv_coo_run_group"]}[variant]
 for nme in names + ["dpu_init_ranks", "dpu_init_dpus", "dpu_release", "spmm_free_group"]:
     assert hasattr(ops, nme), nme
+if variant == "spmm":
+    # MatrixMarket debug ops of the default variant (utils.hpp:139-173): against the reference reader built in
+    # place (oracle/_ref/libref_utils.so) when present, else against the stated semantics
+    import tempfile
+
+    import oracle as _oracle
+
+    rng_m = np.random.default_rng(11)
+    for nr_, nc_ in ((30, 20), (31, 17)):
+        nnz_ = 6 * nr_
+        rr, cc = rng_m.integers(0, nr_, nnz_), rng_m.integers(0, nc_, nnz_)
+        with tempfile.NamedTemporaryFile("w", suffix=".mtx", delete=False) as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n% a comment\n")
+            f.write(f"{nr_} {nc_} {nnz_}\n")
+            for a_, b_ in zip(rr, cc):
+                f.write(f"{a_ + 1} {b_ + 1} 2.5\n")
+        order = np.argsort(rr, kind="stable")
+        want_ptr = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=nr_ + nr_ % 2))])
+        got = (ops.read_matrix_nrows(f.name), ops.read_matrix_ncols(f.name), ops.read_matrix_rowptr(f.name),
+               ops.read_matrix_colind(f.name), ops.read_matrix_values(f.name))
+        assert got[0] == nr_ + nr_ % 2 and got[1] == nc_ + nc_ % 2
+        assert got[2].dtype == got[3].dtype == got[4].dtype == torch.int32
+        assert got[2].tolist() == want_ptr.tolist() and got[3].tolist() == cc[order].tolist() and got[4].tolist() == [1] * nnz_
+        if _oracle.have_ref_utils():
+            rn, rc, rptr, rcol, rval = _oracle.ref_read_matrix_csr(f.name)
+            assert (rn, rc) == got[:2] and rptr.tolist() == got[2].tolist() and rcol.tolist() == got[3].tolist()
+            assert rval.tolist() == got[4].tolist()
+        os.unlink(f.name)
+    print("OK mtx")
 if not on_gpu:
     try:
         ops.dpu_init_ranks(1)

@@ -31,3 +31,53 @@ def test_bench_emits_one_json_line_with_the_contract_fields():
     # value = whole-job GFLOP/s of the stated workload
     flops = 2 * d["config"]["nnz"] * d["config"]["h"]
     assert abs(d["value"] - flops / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+
+
+def _parse_like_the_harness(stdout):
+    """the reference harness' result grammar (utils/experiment.py:466-491): `[DATA]key: value` lines, grouped by the
+    'Repeat' / 'Model' banner lines, mean over repeats of the per-repeat sums"""
+    import collections
+    import re
+
+    import numpy as np
+
+    engine = re.compile(r"^\[DATA](.*?): (.*)")
+    results, repeat = collections.defaultdict(list), 0
+    for line in stdout.splitlines():
+        if line.startswith("-------------------- Repeat") or line.startswith("-------------------- Model"):
+            repeat += 1
+        m = engine.findall(line.strip())
+        if m:
+            results[m[0][0]].append(float(m[0][1]))
+    out = {k: np.asarray(v).reshape(repeat, -1).mean(axis=0).sum(axis=-1) for k, v in results.items()}
+    out["repeat"] = repeat
+    return out
+
+
+@pytest.mark.parametrize("version,lib,fmt", [("spmm", "spmm_default", "COO"), ("spmm", "spmm_default", "CSR"),
+                                             ("grande", "spmm_grande", "CSR"), ("spmv", "spmv_sparseP", "COO")])
+def test_spmm_test_driver_under_the_harness_command_line(version, lib, fmt):
+    """the command line utils/experiment.py:408-424 builds (singular --sp_part/--ds_part, quoted --lib_path, --nr_dpus)
+    drives spmm_test.py, and its stdout parses with the harness grammar"""
+    lib_path = os.path.join(ROOT, "backend_pim", lib, "build", "libbackend_pim.so")
+    cmd = [sys.executable, os.path.join(ROOT, "spmm_test.py"), "--dataset=PubMed", "--datadir=./data", f"--sp_format={fmt}",
+           "--data_type=INT32", "--hidden_size=64", "--sp_part=2", "--ds_part=2", "--repeat=2", f"--lib_path={lib_path}",
+           f"--version={version}",
+           # grande wants one rank (= 8 compute units here, 64 DPUs on UPMEM) per sparse part (grande.py:57)
+           "--nr_dpus=16" if version == "grande" else "--nr_dpus=64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    res = _parse_like_the_harness(r.stdout)
+    assert res["repeat"] == 2
+    assert res["pim_time_spmm(ms)"] > 0 and res["torch_time(ms)"] > 0 and res["outputs_equal"] == 1.0
+
+
+def test_inference_driver_under_the_harness_command_line():
+    lib_path = os.path.join(ROOT, "backend_pim", "spmm_grande", "build", "libbackend_pim.so")
+    cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "--dataset=PubMed", "--datadir=./data", "--sp_format=CSR",
+           "--data_type=INT32", "--hidden_size=64", "--sp_part=1", "--ds_part=2", "--repeat=2", f"--lib_path={lib_path}",
+           "--version=grande", "--model=gcn", "--num_layers=3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    res = _parse_like_the_harness(r.stdout)
+    assert res["repeat"] == 2 and res["infer_time(ms)"] > 0

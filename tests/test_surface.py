@@ -27,6 +27,7 @@ def fake(monkeypatch):
     monkeypatch.setattr(pim_ops, "_variant", None)
     yield f
     if pim_ops._library is not None:
+        assert pim_ops._library != "native", "a test loaded the C++ shim in the pytest process"
         pim_ops._library._destroy()
         pim_ops._library = None
     pim_ops._variant = None
@@ -137,9 +138,9 @@ def test_spmv_wrapper(rng, fake):
 def test_variant_schemas(fake):
     pim_ops.load("spmm")
     assert torch.ops.pim_ops.dpu_init_ranks(2) is None
-    pim_ops.load_library("./backend_pim/spmm_grande/build/libbackend_pim.so")
+    pim_ops.load_library("/not/built/backend_pim/spmm_grande/build/libbackend_pim.so")  # absent file -> Python registration
     assert pim_ops.current_variant() == "grande" and list(torch.ops.pim_ops.dpu_init_ranks(2)) == [8, 8]
-    pim_ops.load_library("./backend_pim/spmv_sparseP/build/libbackend_pim.so")
+    pim_ops.load_library("/not/built/backend_pim/spmv_sparseP/build/libbackend_pim.so")
     assert pim_ops.current_variant() == "spmv" and hasattr(torch.ops.pim_ops, "spmv_coo_run_group")
 
 
