@@ -67,6 +67,7 @@ struct Tunables {
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
+    int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
@@ -114,6 +115,8 @@ struct Group {
     size_t xq_bytes = 0;
     void *oq = nullptr;
     size_t oq_bytes = 0;
+    void *xcat = nullptr;     // dense windows of one sparse part laid side by side (fused block product)
+    size_t xcat_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
     size_t d_ptrs_n = 0;
     int *d_flags = nullptr;
@@ -137,6 +140,7 @@ struct Context {
     // slice-major copy of the current X, shared by all groups of the process (one X per product)
     void *xs = nullptr;
     size_t xs_bytes = 0;
+
     const void *xs_src = nullptr;
     int64_t xs_ld = 0, xs_rows = 0, xs_w = 0;
     size_t xs_es = 0;
@@ -197,6 +201,7 @@ void free_group(Group *g) {
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
+    if (g->xcat) (void)hipFree(g->xcat);
     if (g->xq) (void)hipFree(g->xq);
     if (g->oq) (void)hipFree(g->oq);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
@@ -677,7 +682,46 @@ static int run_group_common(Group *g, const void *const *windows, const int64_t 
     for (size_t i = 0; i < g->parts.size(); i++) {
         Part &p = g->parts[i];
         int64_t acol = 0;
-        for (size_t j = 0; j < p.dense_cols.size(); j++) {
+        const size_t nd = p.dense_cols.size();
+        // Several dense windows (ds_parts chunks, grande's per-unit feature windows) are one product of the
+        // full width here: a window is an artefact of the reference's DPU layout, and narrow windows
+        // (32 int8 = 32 bytes) would waste the 128-byte gather.  Windows that already sit side by side in
+        // one row-major matrix are used in place; others are laid side by side first (one 2-D copy each).
+        if (nd > 1 && g_tune.fuse_windows) {
+            const size_t k0 = per_part ? kbase : 0;
+            int64_t wsum = 0;
+            bool adjacent = true;
+            for (size_t j = 0; j < nd; j++) {
+                if (j > 0 && (lds[k0 + j] != lds[k0] ||
+                              (const char *)dwin[k0 + j] != (const char *)dwin[k0 + j - 1] + (size_t)widths[k0 + j - 1] * es))
+                    adjacent = false;
+                wsum += widths[k0 + j];
+            }
+            const char *x = nullptr;
+            int64_t ldx = 0;
+            if (adjacent) {
+                x = (const char *)dwin[k0] + (per_part ? 0 : (size_t)brow * lds[k0] * es);
+                ldx = lds[k0];
+            } else {
+                // row stride rounded up to 16 bytes so that the sweep's 16-byte pieces stay available
+                const int64_t ldc_el = (int64_t)((((size_t)wsum * es + 15) & ~(size_t)15) / es);
+                const size_t need = (size_t)p.ncols * ldc_el * es;
+                if (int rc = ensure(&g->xcat, &g->xcat_bytes, std::max<size_t>(need, 256))) return rc;
+                int64_t a = 0;
+                for (size_t j = 0; j < nd; j++) {
+                    const size_t k = k0 + j;
+                    const char *src = (const char *)dwin[k] + (per_part ? 0 : (size_t)brow * lds[k] * es);
+                    if (widths[k] > 0 && p.ncols > 0)
+                        HIP_TRY(hipMemcpy2DAsync((char *)g->xcat + (size_t)a * es, (size_t)ldc_el * es, src, (size_t)lds[k] * es,
+                                                 (size_t)widths[k] * es, (size_t)p.ncols, hipMemcpyDeviceToDevice, st));
+                    a += widths[k];
+                }
+                x = (const char *)g->xcat;
+                ldx = ldc_el;
+            }
+            if (int rc = launch_block_any(g, p, x, ldx, dout, g->h, wsum, /*accumulate=*/i > 0, st)) return rc;
+        } else
+        for (size_t j = 0; j < nd; j++) {
             const size_t k = per_part ? kbase + j : j;
             const int64_t w = widths[k];
             const char *x = (const char *)dwin[k] + (per_part ? 0 : (size_t)brow * lds[k] * es);
@@ -790,6 +834,7 @@ int pygim_release(void) {
     if (g_ctx.xs) (void)hipFree(g_ctx.xs);
     g_ctx.xs = nullptr;
     g_ctx.xs_bytes = 0;
+
     g_ctx.xs_src = nullptr;
     g_ctx.inited = false;
     return 0;
@@ -830,6 +875,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_block") slot = &g_tune.panel_block;
     else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
     else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
+    else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

@@ -228,6 +228,75 @@ def test_panel_kernel_all_types(rng, dt):
 
 
 @pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_dense_windows_fused_into_one_product(rng, dt):
+    """several dense windows per sparse part (ds_parts chunks; grande's per-unit windows with padded strides) run as ONE
+    product of the full width (tunable fuse_windows, default on): same result as window by window and as the oracle,
+    for host and device operands, separate and side-by-side windows"""
+    npdt = NP_DTYPES[dt]
+    n, ncols_parts = 400, [150, 170]
+    rowptr, col = random_csr(rng, n, sum(ncols_parts), 12, empty_frac=0.1, long_rows=[(7, 900)])
+    # column split with local ids (spmm.py:127-136)
+    rp, cl = [], []
+    lo = 0
+    for w in ncols_parts:
+        keep = (col >= lo) & (col < lo + w)
+        rows_of = np.repeat(np.arange(n), np.diff(rowptr))
+        rp.append(np.concatenate([[0], np.cumsum(np.bincount(rows_of[keep], minlength=n))]).astype(np.int32))
+        cl.append((col[keep] - lo).astype(np.int32))
+        lo += w
+    for widths in ([32, 32, 32, 32], [3, 2, 2], [40, 24], [5] * 9):
+        h = sum(widths)
+        x = driver_features(rng, sum(ncols_parts), h, npdt)
+        ref = oracle.spmm_csr(rowptr, col, None, x)
+        chunks = [np.ascontiguousarray(x[:, a:a + w]) for a, w in zip(np.cumsum([0] + widths[:-1]), widths)]
+        outs = {}
+        for fuse in (1, 0):
+            old = _lib.set_tunable("fuse_windows", fuse)
+            try:
+                outs[fuse], _ = run_group_host("CSR", rp, cl, None, [n, n], ncols_parts, chunks, h)
+            finally:
+                _lib.set_tunable("fuse_windows", old)
+            assert np.array_equal(outs[fuse], ref), (dt, widths, fuse)
+        # grande: per-part windows with strides padded to 8 bytes (grande.py:12-23), on the device
+        pad = lambda w: -(-w * npdt().itemsize // 8) * 8 // npdt().itemsize
+        wins, lds = [], []
+        lo = 0
+        for wcols in ncols_parts:
+            a = 0
+            for w in widths:
+                buf = np.full((wcols, pad(w)), 99, dtype=npdt)
+                buf[:, :w] = x[lo:lo + wcols, a:a + w]
+                wins.append(buf)
+                lds.append(pad(w))
+                a += w
+            lo += wcols
+        out_g, _ = run_group_host("CSR", rp, cl, None, [n, n], ncols_parts, wins, h, kind="grande",
+                                  n_dense=[len(widths)] * 2, dense_cols=widths * 2, lds=lds)
+        assert np.array_equal(out_g, ref), (dt, widths, "grande")
+        # device operands, windows side by side inside one row-major matrix: used in place
+        xd = torch.from_numpy(x).cuda()
+        od = torch.empty((n, h), dtype=xd.dtype, device="cuda")
+        es = xd.element_size()
+        hd = _lib.group_create(_lib.CSR, CODE_OF_NP[np.dtype(npdt)], [_ptr(a) for a in rp], [_ptr(a) for a in cl], None, [n, n],
+                               ncols_parts, [len(c) for c in cl], [len(widths)] * 2, widths * 2, h)
+        try:
+            ptrs, ldl = [], []
+            lo = 0
+            for wcols in ncols_parts:
+                a = 0
+                for w in widths:
+                    ptrs.append(xd.data_ptr() + (lo * h + a) * es)
+                    ldl.append(h)
+                    a += w
+                lo += wcols
+            _lib.grande_run_group(hd, ptrs, ldl, od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            _lib.group_free(hd)
+        assert np.array_equal(od.cpu().numpy(), ref), (dt, widths, "in place")
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
 @pytest.mark.parametrize("group_slices", [1, 3])
 def test_panel_sweep_in_slice_groups(rng, dt, group_slices):
     """X beyond the Infinity Cache is swept a few feature slices per launch (tunable slice_group_bytes):
