@@ -142,6 +142,19 @@ int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *
  * scale_out (device float, may be NULL) receives the scale.                     */
 int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, void *stream);
 
+/* The same quantiser in its three steps, for callers that exchange the QUANTISED features between them
+ * (row-sharded multi-GPU inference: every rank quantises its row block with the global scale, the blocks
+ * are all-gathered in the narrow type, each rank aggregates its rows and dequantises them).
+ *   absmax_bits: device uint32 holding the bit pattern of max|X| (a non-negative float orders like an
+ *   unsigned integer, so ranks combine it with an integer MAX all-reduce); pygim_quant_absmax
+ *   max-accumulates into it, the caller zeroes it first.
+ *   pygim_quantize: Xq[rows, width] contiguous in `dtype` (INT8/INT16/INT32/FLT32) = round_half_even(X / scale).
+ *   pygim_dequantize: out[i] = float(Q[i]) * scale.                                     */
+int pygim_quant_absmax(const float *X, int64_t ldx, int64_t rows, int64_t width, uint32_t *absmax_bits, void *stream);
+int pygim_quantize(int dtype, const float *X, int64_t ldx, int64_t rows, int64_t width, const uint32_t *absmax_bits,
+                   void *Xq, float *scale_out, void *stream);
+int pygim_dequantize(int dtype, const void *Q, int64_t n, const uint32_t *absmax_bits, float *out, void *stream);
+
 /* ---- introspection -----------------------------------------------------------
  * Milliseconds of the last host-pointer run, in the reference's Timer buckets
  * (support/timer.h; printed as [DATA] lines, spmm_mul_csr.c:563-580):

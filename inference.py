@@ -24,17 +24,32 @@ from spmm_test import DATASETS, TORCH_TYPES, load_ops
 
 @torch.no_grad()
 def test(args, model, data):
+    """one timed forward pass; under torch.distributed every rank holds its row block of the nodes (features,
+    labels, logits): the time is the slowest rank's, checksum and accuracy are summed over the ranks"""
+    import torch.distributed as dist
+
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     model.eval()
     if data["x"].is_cuda:
         torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
     st = datetime.datetime.now()
     y_pred = model(data["x"], data["adj_t"], data["edge_attr"])
     if y_pred.is_cuda:
         torch.cuda.synchronize()
-    print("[DATA]infer_time(ms): ", (datetime.datetime.now() - st).total_seconds() * 1000, flush=True)
-    print("[DATA]logits_checksum: ", float(y_pred.double().abs().sum()), flush=True)
-    y_pred = y_pred.argmax(dim=-1)
-    return (y_pred.eq(data["y"]).sum() / y_pred.size(0)).item()
+    ms = (datetime.datetime.now() - st).total_seconds() * 1000
+    stats = torch.stack([y_pred.double().abs().sum(), y_pred.argmax(dim=-1).eq(data["y"]).sum().double(),
+                         torch.tensor(float(y_pred.size(0)), dtype=torch.float64, device=y_pred.device)])
+    if multi:
+        t = torch.tensor([ms], dtype=torch.float64, device=y_pred.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        ms = float(t.item())
+    if not multi or dist.get_rank() == 0:
+        print("[DATA]infer_time(ms): ", ms, flush=True)
+        print("[DATA]logits_checksum: ", float(stats[0]), flush=True)
+    return float(stats[1] / stats[2])
 
 
 def get_args():
@@ -85,9 +100,12 @@ def main(args):
         data["adj_t"] = adj_t
         data["x"], data["y"] = x, y
     elif world > 1:
-        from pygim_amd.dist import RowSplitAdj
+        # sp_parts = world as a row split with row-SHARDED activations (pygim_amd/dist.py RowShardAdj)
+        from pygim_amd.dist import RowShardAdj
 
-        data["adj_t"] = RowSplitAdj(rowptr.cpu(), col.cpu(), n, args.data_type, args.hidden_size)
+        shard = RowShardAdj(rowptr.cpu(), col.cpu(), n, args.data_type, args.hidden_size)
+        data["adj_t"] = shard
+        data["x"], data["y"] = shard.local_rows(data["x"]).contiguous(), shard.local_rows(data["y"]).contiguous()
     else:
         load_ops(args)
         if args.version == "grande":

@@ -16,6 +16,7 @@ EXPORTS = [
     "pygim_device_info", "pygim_group_create", "pygim_group_free", "pygim_spmm_run_group",
     "pygim_grande_run_group", "pygim_spmv_run_group", "pygim_block_run", "pygim_group_timers",
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
+    "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -63,6 +64,9 @@ def lib():
         L.pygim_group_info.argtypes = [c_i64, p_i64]
         L.pygim_group_kernel_ms.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double), p_i64, c_int]
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
+        L.pygim_quant_absmax.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
+        L.pygim_quantize.argtypes = [c_int, vp, c_i64, c_i64, c_i64, vp, vp, vp, vp]
+        L.pygim_dequantize.argtypes = [c_int, vp, c_i64, vp, vp, vp]
         L.pygim_set_tunable.argtypes = [ctypes.c_char_p, c_i64]
         L.pygim_set_tunable.restype = c_i64
         _lib = L
@@ -170,6 +174,22 @@ def group_kernel_ms(handle, reset=True):
     n = ctypes.c_int64(0)
     check(lib().pygim_group_kernel_ms(int(handle), ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
     return ms.value, n.value
+
+
+def quant_absmax(x_ptr, ldx, rows, width, bits_ptr, stream=0):
+    check(lib().pygim_quant_absmax(ctypes.c_void_p(x_ptr or None), int(ldx), int(rows), int(width), ctypes.c_void_p(bits_ptr),
+                                   ctypes.c_void_p(stream or None)))
+
+
+def quantize(dtype, x_ptr, ldx, rows, width, bits_ptr, xq_ptr, scale_ptr=0, stream=0):
+    check(lib().pygim_quantize(int(dtype), ctypes.c_void_p(x_ptr or None), int(ldx), int(rows), int(width),
+                               ctypes.c_void_p(bits_ptr), ctypes.c_void_p(xq_ptr or None), ctypes.c_void_p(scale_ptr or None),
+                               ctypes.c_void_p(stream or None)))
+
+
+def dequantize(dtype, q_ptr, n, bits_ptr, out_ptr, stream=0):
+    check(lib().pygim_dequantize(int(dtype), ctypes.c_void_p(q_ptr or None), int(n), ctypes.c_void_p(bits_ptr),
+                                 ctypes.c_void_p(out_ptr or None), ctypes.c_void_p(stream or None)))
 
 
 def quant_spmm_run(handle, x_ptr, ldx, out_ptr, scale_ptr=0, stream=0):

@@ -1005,12 +1005,22 @@ __global__ void k_pack_vectors(const T *const *__restrict__ vecs, uint32_t g, ui
 //   type otherwise);  x_q = round_half_even(x / scale) cast to the type;  out = float(out_q) * scale.
 // ---------------------------------------------------------------------------
 // max |x| as the bit pattern of a non-negative float (orders like an unsigned integer)
+// FLAT = the matrix is one contiguous, 16-byte aligned array whose length is a multiple of 4: float4 accesses
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool FLAT>
 __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w, uint32_t *out) {
     const uint64_t total = rows * w;
     uint32_t m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float v = x[(i / w) * ld + (i % w)];
-        m = max(m, __float_as_uint(fabsf(v)));
+    const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (uint64_t)gridDim.x * blockDim.x;
+    if constexpr (FLAT) {
+        const f32x4_t *x4 = reinterpret_cast<const f32x4_t *>(x);
+        for (uint64_t i = t0; i < total / 4; i += step) {
+            const f32x4_t v = __builtin_nontemporal_load(x4 + i);
+            m = max(max(m, __float_as_uint(fabsf(v.x))), __float_as_uint(fabsf(v.y)));
+            m = max(max(m, __float_as_uint(fabsf(v.z))), __float_as_uint(fabsf(v.w)));
+        }
+    } else {
+        for (uint64_t i = t0; i < total; i += step) m = max(m, __float_as_uint(fabsf(x[(i / w) * ld + (i % w)])));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
@@ -1019,23 +1029,45 @@ __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t 
 __device__ __forceinline__ float quant_scale(uint32_t absmax_bits, int log2_range) {
     return __uint_as_float(absmax_bits) * 2.0f / (float)(1u << log2_range);
 }
-template <typename T>
+template <typename T> struct Pack4 { T v[4]; } __attribute__((aligned(sizeof(T) * 4)));
+template <typename T, bool FLAT>
 __global__ void k_quantize(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w,
                            const uint32_t *__restrict__ absmax_bits, int log2_range, T *__restrict__ xq,
                            float *__restrict__ scale_out) {
     const float scale = quant_scale(*absmax_bits, log2_range);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && scale_out) *scale_out = scale;
-    if (i >= rows * w) return;
-    const float q = rintf(x[(i / w) * ld + (i % w)] / scale);  // torch.round: half to even
-    xq[i] = (T)q;
+    if constexpr (FLAT) {
+        if (i >= rows * w / 4) return;
+        const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(x) + i);
+        Pack4<T> q;  // torch.round: half to even; true division, as torch's v / scale
+        q.v[0] = (T)rintf(v.x / scale);
+        q.v[1] = (T)rintf(v.y / scale);
+        q.v[2] = (T)rintf(v.z / scale);
+        q.v[3] = (T)rintf(v.w / scale);
+        reinterpret_cast<Pack4<T> *>(xq)[i] = q;
+    } else {
+        if (i >= rows * w) return;
+        xq[i] = (T)rintf(x[(i / w) * ld + (i % w)] / scale);
+    }
 }
-template <typename T>
+template <typename T, bool FLAT>
 __global__ void k_dequantize(const T *__restrict__ q, uint64_t n, const uint32_t *__restrict__ absmax_bits,
                              int log2_range, float *__restrict__ out) {
     const float scale = 1.0f * quant_scale(*absmax_bits, log2_range);  // scale_edge (1.) * scale_x
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)q[i] * scale;
+    if constexpr (FLAT) {
+        if (i >= n / 4) return;
+        const Pack4<T> v = reinterpret_cast<const Pack4<T> *>(q)[i];
+        f32x4_t o;
+        o.x = (float)v.v[0] * scale;
+        o.y = (float)v.v[1] * scale;
+        o.z = (float)v.v[2] * scale;
+        o.w = (float)v.v[3] * scale;
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(out) + i);
+    } else {
+        if (i < n) out[i] = (float)q[i] * scale;
+    }
 }
 
 }  // namespace pygim

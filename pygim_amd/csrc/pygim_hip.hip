@@ -750,6 +750,55 @@ static int run_group_common(Group *g, const void *const *windows, const int64_t 
 
 
 
+// ---- the conv layers' quantiser (models/quantize.py:20-42) in three launches -------------------------
+static bool flat4(const void *a, int64_t ld, uint64_t rows, uint32_t w, const void *b = nullptr) {
+    return ld == (int64_t)w && (rows * w) % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
+}
+static int launch_absmax(const float *X, int64_t ldx, uint64_t rows, uint32_t w, uint32_t *amax, hipStream_t st) {
+    const uint64_t total = rows * w;
+    if (!total) return 0;
+    const bool flat = flat4(X, ldx, rows, w);
+    const uint64_t work = flat ? total / 4 : total;
+    const unsigned grid = (unsigned)std::min<uint64_t>((work + 255) / 256, 8192);
+    if (flat) hipLaunchKernelGGL(k_absmax_bits<true>, dim3(grid), dim3(256), 0, st, X, ldx, rows, w, amax);
+    else hipLaunchKernelGGL(k_absmax_bits<false>, dim3(grid), dim3(256), 0, st, X, ldx, rows, w, amax);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <typename T>
+static int launch_quantize(const float *X, int64_t ldx, uint64_t rows, uint32_t w, const uint32_t *amax, int log2_range, T *xq,
+                           float *scale_out, hipStream_t st) {
+    const uint64_t total = rows * w;
+    if (!total) return 0;
+    if (flat4(X, ldx, rows, w, xq))
+        hipLaunchKernelGGL((k_quantize<T, true>), dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, X, ldx, rows, w, amax,
+                           log2_range, xq, scale_out);
+    else
+        hipLaunchKernelGGL((k_quantize<T, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, ldx, rows, w, amax,
+                           log2_range, xq, scale_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <typename T>
+static int launch_dequantize(const T *q, uint64_t n, const uint32_t *amax, int log2_range, float *out, hipStream_t st) {
+    if (!n) return 0;
+    if (n % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 16) == 0)
+        hipLaunchKernelGGL((k_dequantize<T, true>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, q, n, amax, log2_range, out);
+    else
+        hipLaunchKernelGGL((k_dequantize<T, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, n, amax, log2_range, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int quant_log2_range(int dtype) {  // ranges of models/quantize.py:22-30
+    switch (dtype) {
+        case PYGIM_INT8: return 5;
+        case PYGIM_INT16: return 10;
+        case PYGIM_INT32: return 20;
+        case PYGIM_FLT32: return 20;
+        default: return -1;
+    }
+}
+
 template <typename T>
 static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float *scale_out, int log2_range, hipStream_t st) {
     const uint64_t rows = (uint64_t)g->total_cols, orows = (uint64_t)g->total_rows;
@@ -758,13 +807,9 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
     uint32_t *amax = (uint32_t *)(g->d_flags + 3);
     HIP_TRY(hipMemsetAsync(amax, 0, sizeof(uint32_t), st));
-    const uint64_t total = rows * h;
-    if (total) {
-        hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 4096)), dim3(256), 0, st, X,
-                           ldx, rows, h, amax);
-        hipLaunchKernelGGL((k_quantize<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, X, ldx, rows, h, amax,
-                           log2_range, (T *)g->xq, scale_out);
-    }
+    if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
+    if (int rc = launch_quantize<T>(X, ldx, rows, h, amax, log2_range, (T *)g->xq, scale_out, st)) return rc;
+    if (rows * h == 0 && scale_out) HIP_TRY(hipMemsetAsync(scale_out, 0, sizeof(float), st));
     // the group's own dense split, as windows into the row-major quantised matrix
     const size_t nd = g->parts[0].dense_cols.size();
     std::vector<const void *> win(nd);
@@ -775,12 +820,7 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
         off += g->parts[0].dense_cols[j];
     }
     if (int rc = run_group_common(g, win.data(), lds.data(), false, g->oq, st)) return rc;
-    const uint64_t on = orows * h;
-    if (on)
-        hipLaunchKernelGGL((k_dequantize<T>), dim3((unsigned)((on + 255) / 256)), dim3(256), 0, st, (const T *)g->oq, on, amax,
-                           log2_range, out);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_dequantize<T>((const T *)g->oq, orows * h, amax, log2_range, out, st);
 }
 
 // ===========================================================================
@@ -1032,6 +1072,49 @@ int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out
         case PYGIM_INT32: return quant_run_t<int32_t>(g, X, ldx, out, scale_out, 20, st);
         case PYGIM_FLT32: return quant_run_t<float>(g, X, ldx, out, scale_out, 20, st);
         default: return fail(PYGIM_ERR_INVALID, "quantised run: group type must be INT8/INT16/INT32/FLT32");
+    }
+}
+
+int pygim_quant_absmax(const float *X, int64_t ldx, int64_t rows, int64_t width, uint32_t *absmax_bits, void *stream) {
+    if (int rc = need_init()) return rc;
+    if (rows < 0 || width < 0 || ldx < width || !absmax_bits) return fail(PYGIM_ERR_INVALID, "bad absmax arguments");
+    if ((rows * width > 0 && (!X || !is_device_ptr(X))) || !is_device_ptr(absmax_bits))
+        return fail(PYGIM_ERR_INVALID, "pygim_quant_absmax needs device pointers");
+    return launch_absmax(X, ldx, (uint64_t)rows, (uint32_t)width, absmax_bits, (hipStream_t)stream);
+}
+
+int pygim_quantize(int dtype, const float *X, int64_t ldx, int64_t rows, int64_t width, const uint32_t *absmax_bits,
+                   void *Xq, float *scale_out, void *stream) {
+    if (int rc = need_init()) return rc;
+    const int k = quant_log2_range(dtype);
+    if (k < 0) return fail(PYGIM_ERR_INVALID, "quantise: type must be INT8/INT16/INT32/FLT32");
+    if (rows < 0 || width < 0 || ldx < width || !absmax_bits) return fail(PYGIM_ERR_INVALID, "bad quantise arguments");
+    if (rows * width > 0 && (!X || !Xq || !is_device_ptr(X) || !is_device_ptr(Xq)))
+        return fail(PYGIM_ERR_INVALID, "pygim_quantize needs device pointers");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t r = (uint64_t)rows;
+    const uint32_t w = (uint32_t)width;
+    switch (dtype) {
+        case PYGIM_INT8: return launch_quantize<int8_t>(X, ldx, r, w, absmax_bits, k, (int8_t *)Xq, scale_out, st);
+        case PYGIM_INT16: return launch_quantize<int16_t>(X, ldx, r, w, absmax_bits, k, (int16_t *)Xq, scale_out, st);
+        case PYGIM_INT32: return launch_quantize<int32_t>(X, ldx, r, w, absmax_bits, k, (int32_t *)Xq, scale_out, st);
+        default: return launch_quantize<float>(X, ldx, r, w, absmax_bits, k, (float *)Xq, scale_out, st);
+    }
+}
+
+int pygim_dequantize(int dtype, const void *Q, int64_t n, const uint32_t *absmax_bits, float *out, void *stream) {
+    if (int rc = need_init()) return rc;
+    const int k = quant_log2_range(dtype);
+    if (k < 0) return fail(PYGIM_ERR_INVALID, "dequantise: type must be INT8/INT16/INT32/FLT32");
+    if (n < 0 || !absmax_bits) return fail(PYGIM_ERR_INVALID, "bad dequantise arguments");
+    if (n > 0 && (!Q || !out || !is_device_ptr(Q) || !is_device_ptr(out)))
+        return fail(PYGIM_ERR_INVALID, "pygim_dequantize needs device pointers");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case PYGIM_INT8: return launch_dequantize<int8_t>((const int8_t *)Q, (uint64_t)n, absmax_bits, k, out, st);
+        case PYGIM_INT16: return launch_dequantize<int16_t>((const int16_t *)Q, (uint64_t)n, absmax_bits, k, out, st);
+        case PYGIM_INT32: return launch_dequantize<int32_t>((const int32_t *)Q, (uint64_t)n, absmax_bits, k, out, st);
+        default: return launch_dequantize<float>((const float *)Q, (uint64_t)n, absmax_bits, k, out, st);
     }
 }
 

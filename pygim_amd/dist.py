@@ -17,6 +17,9 @@ over xGMI (backend "nccl"); on CPU the same code runs over "gloo" (tests).
                     block X[:, f_r] (widths as spmm.py:62-72) and produces C[:, f_r]; no collective
                     inside the product; all-gather along features re-assembles C.
 
+  RowShardAdj       config 4 end to end: activations row-sharded through the dense layers, the aggregation
+                    all-gathers the QUANTISED row blocks (see the class).
+
 The local product goes through an *engine*: HipEngine (the C ABI, device tensors) by default.
 Tests inject an engine built on the CPU oracle to exercise the partition/collective logic with
 world_size 2 over gloo.
@@ -204,3 +207,126 @@ class RowSplitAdj:
         self._lib.spmm_run_group(self.handle, [x.data_ptr()], buf[self.rank].data_ptr(),
                                  torch.cuda.current_stream(x.device).cuda_stream)
         return self._gather(buf)
+
+
+class HipShardEngine:
+    """Device steps of RowShardAdj through the C ABI: |max| bits, quantise, product, dequantise."""
+
+    def __init__(self):
+        from . import _lib, pim_ops
+
+        self._lib = _lib
+        self._code = pim_ops.DTYPE_CODE
+        if not _lib.is_initialized():
+            _lib.init_ranks(dist.get_world_size() if dist.is_initialized() else 1)
+
+    def create(self, rowptr, col, nrows, ncols, dtype, h):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev, self.dtype, self.nrows, self.h = dev, dtype, nrows, h
+        self.code = self._code[dtype]
+        self.keep = [rowptr.to(dev, torch.int32).contiguous(), col.to(dev, torch.int32).contiguous()]
+        self.handle = self._lib.group_create(self._lib.CSR, self.code, [self.keep[0].data_ptr()], [self.keep[1].data_ptr()],
+                                             None, [nrows], [ncols], [self.keep[1].numel()], [1], [h], h)
+        return self
+
+    def _st(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.dev)
+
+    def absmax_bits(self, x):
+        bits = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._lib.quant_absmax(x.data_ptr(), x.stride(0) if x.dim() == 2 and x.size(0) > 1 else x.size(-1), x.size(0), x.size(1),
+                               bits.data_ptr(), self._st())
+        return bits
+
+    def quantize(self, x, bits, out):
+        self._lib.quantize(self.code, x.data_ptr(), x.stride(0) if x.size(0) > 1 else x.size(1), x.size(0), x.size(1),
+                           bits.data_ptr(), out.data_ptr(), 0, self._st())
+
+    def product(self, xq_full, out):
+        self._lib.spmm_run_group(self.handle, [xq_full.data_ptr()], out.data_ptr(), self._st())
+
+    def dequantize(self, q, bits, out):
+        self._lib.dequantize(self.code, q.data_ptr(), q.numel(), bits.data_ptr(), out.data_ptr(), self._st())
+
+    def free(self):
+        self._lib.group_free(self.handle)
+
+
+class RowShardAdj:
+    """``adj_t`` of a conv layer when the node features are ROW-SHARDED over the GPUs (BASELINE config 4).
+
+    Rank r keeps the nnz-balanced row block rows_r of every activation through the dense layers (Linear, BN,
+    ReLU are row-wise: no communication, 1/world of the work) and of A.  The aggregation
+    ``dequantize(A . quantize(x))`` (pyg_gcn_conv.py:130-137, quantize.py:20-42) exchanges the QUANTISED block:
+
+        bits   = max|x[rows_r]|  --MAX all-reduce, 4 bytes-->  the global scale (same value as on one GPU)
+        x_q[rows_r] = round(x[rows_r] / scale) in the adjacency type (INT8: a quarter of the fp32 bytes)
+        all-gather of the x_q row blocks --> X_q on every rank
+        out[rows_r] = float(A[rows_r, :] . X_q) * scale
+
+    The gathered blocks stay in their padded slots ([world, max_rows, h]); A's column ids are re-based once
+    to that layout (owner * max_rows + offset inside the owner's block: monotonic, rows stay sorted), so no
+    compaction pass is needed.  Every output row is summed by one GPU in stored order: integers bit-exact and
+    floats bit-identical to the one-GPU result, whatever the world size."""
+
+    def __init__(self, rowptr, col, ncols, dtype, h, group=None, engine_factory=HipShardEngine):
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.dtype, self.hidden_size = dtype, h
+        self.nrows = rowptr.numel() - 1
+        assert ncols == self.nrows, "row-sharded activations need a square adjacency"
+        self.split = partition.partition_by_nnz(rowptr, self.world)
+        self.r0, self.r1 = self.split[self.rank], self.split[self.rank + 1]
+        self.my_rows = self.r1 - self.r0
+        self.max_rows = max(max(self.split[i + 1] - self.split[i] for i in range(self.world)), 1)
+        lo, hi = int(rowptr[self.r0]), int(rowptr[self.r1])
+        c = col[lo:hi].to(torch.int64)
+        starts = torch.tensor(self.split[:-1], dtype=torch.int64, device=c.device)
+        owner = torch.bucketize(c, torch.tensor(self.split[1:-1], dtype=torch.int64, device=c.device), right=True)
+        c_padded = c + owner * self.max_rows - starts[owner]
+        self.engine = engine_factory().create(rowptr[self.r0:self.r1 + 1] - lo, c_padded, self.my_rows,
+                                              self.world * self.max_rows, dtype, h)
+        self._xq = None
+
+    def local_rows(self, t):
+        """this rank's block of a node-indexed tensor"""
+        return t[self.r0:self.r1]
+
+    def _exchange(self, buf):
+        if self.world > 1:
+            dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), group=self.group)
+        return buf.view(self.world * self.max_rows, self.hidden_size)
+
+    def _buffer(self, dtype):
+        if self._xq is None or self._xq.dtype != dtype:
+            self._xq = self.engine.empty((self.world, self.max_rows, self.hidden_size), dtype)
+        return self._xq
+
+    def mul_quantized(self, x_local):
+        assert x_local.dtype == torch.float32 and tuple(x_local.shape) == (self.my_rows, self.hidden_size), \
+            (tuple(x_local.shape), self.my_rows, self.hidden_size)
+        e = self.engine
+        x_local = x_local.contiguous()
+        bits = e.absmax_bits(x_local)
+        if self.world > 1:
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+        buf = self._buffer(self.dtype)
+        e.quantize(x_local, bits, buf[self.rank][: self.my_rows])
+        xq = self._exchange(buf)
+        out_q = e.empty((self.my_rows, self.hidden_size), self.dtype)
+        e.product(xq, out_q)
+        out = e.empty((self.my_rows, self.hidden_size), torch.float32)
+        e.dequantize(out_q, bits, out)
+        return out, bits
+
+    def mul(self, x_local):
+        """plain product on row-sharded features of the adjacency type: [rows_r, h] -> [rows_r, h]"""
+        assert x_local.dtype == self.dtype and tuple(x_local.shape) == (self.my_rows, self.hidden_size)
+        buf = self._buffer(self.dtype)
+        buf[self.rank][: self.my_rows].copy_(x_local)
+        out = self.engine.empty((self.my_rows, self.hidden_size), self.dtype)
+        self.engine.product(self._exchange(buf), out)
+        return out

@@ -9,7 +9,8 @@ pyg_sage_conv.py:122-155), written on plain torch.nn (torch_geometric is not ins
     SAGEConv: lin_l(aggregate(x)) + lin_r(x)                  (sum aggregation through adj_t.mul)
     GINConv : nn((1 + eps) * x + aggregate(x)),  nn = Linear -> BN -> ReLU -> Linear  (PyG MLP([h, h, h]))
 with aggregate = quantise -> adj_t.mul -> dequantise (pygim_amd/quantize.py).  ``adj_t`` is a
-SparseTensor (cpu path), a backend_pim SparseTensorCOO, or a pygim_amd.dist.RowSplitAdj (multi-GPU).
+SparseTensor (cpu path), a backend_pim SparseTensorCOO, or a pygim_amd.dist.RowShardAdj (multi-GPU:
+x and the result are then this rank's row block).
 """
 import torch
 import torch.nn.functional as F

@@ -52,6 +52,41 @@ class OracleEngine:
         return out
 
 
+NP_OF = {torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32, torch.float32: np.float32}
+BITS_OF = {torch.int8: 5, torch.int16: 10, torch.int32: 20, torch.float32: 20}
+
+
+class OracleShardEngine:
+    """test double for pygim_amd.dist.HipShardEngine: the quantiser steps restated with numpy float32 arithmetic
+    (models/quantize.py:20-42, as oracle.symmetric_quantize), the product by the CPU oracle"""
+
+    def create(self, rowptr, col, nrows, ncols, dtype, h):
+        self.rp, self.col = rowptr.numpy().astype(np.int32), col.numpy().astype(np.int32)
+        self.dtype, self.nrows, self.ncols, self.h = dtype, nrows, ncols, h
+        return self
+
+    def empty(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def absmax_bits(self, x):
+        m = np.float32(np.max(np.abs(x.numpy()))) if x.numel() else np.float32(0)
+        return torch.from_numpy(np.array([m], dtype=np.float32).view(np.int32).copy())
+
+    def _scale(self, bits):
+        m = bits.numpy().view(np.float32)[0]
+        return np.float32(np.float32(m * np.float32(2)) / np.float32(2 ** BITS_OF[self.dtype]))
+
+    def quantize(self, x, bits, out):
+        out.copy_(torch.from_numpy(np.rint(x.numpy() / self._scale(bits)).astype(NP_OF[self.dtype])))
+
+    def product(self, xq_full, out):
+        assert xq_full.shape[0] == self.ncols
+        out.copy_(torch.from_numpy(oracle.spmm_csr(self.rp, self.col, None, xq_full.numpy())))
+
+    def dequantize(self, q, bits, out):
+        out.copy_(torch.from_numpy(q.numpy().astype(np.float32) * np.float32(np.float32(1.0) * self._scale(bits))))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -96,6 +131,19 @@ def _worker(rank, world, port, q):
                              torch.from_numpy(loc.data.astype(np.int32)), n, c1 - c0, torch.int32, h,
                              engine_factory=OracleEngine)
         assert np.array_equal(cs.mul(x_t[c0:c1].contiguous()).numpy(), ref)
+        # row-sharded activations: quantised blocks exchanged, global scale through a MAX all-reduce
+        xf = rng.standard_normal((n, h)).astype(np.float32)
+        for tdt in (torch.int8, torch.int32, torch.float32):
+            s_ref, xq_ref = oracle.symmetric_quantize(xf, NP_OF[tdt])
+            want = oracle.symmetric_dequantize(oracle.spmm_csr(rowptr, col, None, xq_ref), 1.0, s_ref)
+            sh = pd.RowShardAdj(rp_t, col_t, n, tdt, h, engine_factory=OracleShardEngine)
+            assert sh.split == partition.partition_by_nnz(rp_t, world)
+            got, bits = sh.mul_quantized(sh.local_rows(torch.from_numpy(xf)).contiguous())
+            assert bits.numpy().view(np.float32)[0] == np.float32(np.max(np.abs(xf)))
+            assert np.array_equal(got.numpy(), want[sh.r0:sh.r1]), tdt
+            if tdt != torch.float32:
+                plain = sh.mul(sh.local_rows(torch.from_numpy(xq_ref)).contiguous())
+                assert np.array_equal(plain.numpy(), oracle.spmm_csr(rowptr, col, None, xq_ref)[sh.r0:sh.r1])
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -105,11 +153,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_multi_gpu_layer_over_gloo_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_gpu_layer_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=150) for _ in procs]
