@@ -167,7 +167,7 @@ def main():
                 self.my_nnz += hi - lo
             self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if world > 1 else []
 
-        def step(self):
+        def step(self, exchange=True):
             K, handles, outs, gathers, side = self.K, self.handles, self.outs, self.gathers, self.side
             if world == 1:
                 for c in range(K):
@@ -179,14 +179,16 @@ def main():
             _lib.spmm_run_group(handles[0], [x.data_ptr()], outs[0].data_ptr(), stream)
             ready = torch.cuda.Event()
             ready.record(main_stream)
-            pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
+            if exchange:
+                pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
             _lib.set_tunable("xs_reuse", 1)
             for c in range(1, K):
                 s_c = side[c - 1]
                 s_c.wait_event(ready)
                 with torch.cuda.stream(s_c):
                     _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s_c.cuda_stream)
-                    pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
+                    if exchange:
+                        pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
             for c, wk in enumerate(pending):
                 if c == 0:
                     wk.wait()  # stream-level wait, the host does not block
@@ -236,22 +238,24 @@ def main():
                 self.gathers.append(torch.empty((world, max(c1 - c0, 1), self.hw), dtype=torch.float32, device=dev))
             self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
 
-        def _piece(self, c, s):
+        def _piece(self, c, s, exchange=True):
             c0, c1 = self.b[c], self.b[c + 1]
             g = self.gathers[c]
             mine = g[rank]
             # product on the strided feature window of X (row stride h): C_block[rows_c, hw]
             _lib.block_run(self.handles[c], 0, x.data_ptr() + 4 * self.f0, h, mine.data_ptr(), self.hw, self.hw, False,
                            s.cuda_stream)
+            if not exchange:
+                return
             if world > 1:
                 wk = dist.all_gather_into_tensor(g.view(-1), mine.reshape(-1), async_op=True)
                 wk.wait()
             if c1 > c0:
                 self.C[c0:c1].view(c1 - c0, world, self.hw).copy_(g[:, : c1 - c0].permute(1, 0, 2))
 
-        def step(self):
+        def step(self, exchange=True):
             _lib.set_tunable("xs_reuse", 0)
-            self._piece(0, main_stream)
+            self._piece(0, main_stream, exchange)
             if self.K > 1:
                 ready = torch.cuda.Event()
                 ready.record(main_stream)
@@ -260,7 +264,7 @@ def main():
                     s_c = self.side[c - 1]
                     s_c.wait_event(ready)
                     with torch.cuda.stream(s_c):
-                        self._piece(c, s_c)
+                        self._piece(c, s_c, exchange)
                 for s_c in self.side:
                     main_stream.wait_stream(s_c)
 
@@ -340,6 +344,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # for reading the scaling: the same step without the exchange (each rank's products only), outside the timed region
+    products_only_ms = None
+    if world > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(exchange=False)
+        fence()
+        tp = torch.tensor([(time.perf_counter() - t1) / 3 * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        products_only_ms = round(float(tp.item()), 4)
+        step()  # leave the gathered C of a full step behind for the check below
+        fence()
+        for hd in handles:
+            _lib.group_kernel_ms(hd, reset=True)
     total_flops = synth.flops(nnz, h)
     gflops = total_flops / (ms_per_step * 1e-3) / 1e9
 
@@ -372,7 +391,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
                    "columns": "clustered" if args.clustered else "uniform",
-                   "partition": plan.describe()},
+                   "partition": plan.describe(),
+                   **({"ms_per_step_products_only": products_only_ms} if products_only_ms is not None else {})},
         "roofline": roofline,
     }
 
