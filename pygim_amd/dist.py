@@ -17,6 +17,7 @@ over xGMI (backend "nccl"); on CPU the same code runs over "gloo" (tests).
                     block X[:, f_r] (widths as spmm.py:62-72) and produces C[:, f_r]; no collective
                     inside the product; all-gather along features re-assembles C.
 
+  GridSpMM          row_parts x feat_parts grid (rank (i, j) = row block i x feature block j).
   RowShardAdj       config 4 end to end: activations row-sharded through the dense layers, the aggregation
                     all-gathers the QUANTISED row blocks (see the class).
 
@@ -157,6 +158,58 @@ class FeatureSplitSpMM:
         mine[:, : c_block.size(1)] = c_block
         dist.all_gather_into_tensor(stage.view(-1), mine.reshape(-1).clone(), group=self.group)
         return torch.cat([stage[i, :, : self.widths[i]] for i in range(self.world)], dim=1)
+
+
+class GridSpMM:
+    """2-D ``row_parts x feat_parts`` grid over the world (the reference's rank (i, j) = sparse part i x dense
+    part j, spmm_mul_csr.c:344-345, with sp_parts as a ROW split): rank ``i * feat_parts + j`` owns the
+    nnz-balanced row block i of A and the feature block j of X (all rows of it), and produces
+    C[rows_i, f_j] with no collective inside the product.  What the grid buys over a pure feature split: the
+    gathered row of X stays >= 128 bytes (a narrower row still moves a whole 128-byte line per entry,
+    scripts/exp_rowbytes.py), e.g. papers100M h = 128 on 8 GPUs as 2 x 4 instead of 1 x 8."""
+
+    def __init__(self, rowptr, col, values, ncols, dtype, h_total, row_parts, feat_parts, group=None,
+                 engine_factory=HipEngine):
+        self.group = group
+        self.world, self.rank = _world(group)
+        assert row_parts * feat_parts == self.world, "grid must cover the world"
+        self.row_parts, self.feat_parts = row_parts, feat_parts
+        self.i, self.j = divmod(self.rank, feat_parts)
+        self.nrows, self.h_total, self.dtype = rowptr.numel() - 1, h_total, dtype
+        self.split = partition.partition_by_nnz(rowptr, row_parts)
+        self.widths: List[int] = partition.split_widths(h_total, feat_parts)
+        self.r0, self.r1 = self.split[self.i], self.split[self.i + 1]
+        self.f0 = sum(self.widths[: self.j])
+        self.w = self.widths[self.j]
+        lo, hi = int(rowptr[self.r0]), int(rowptr[self.r1])
+        self.engine = engine_factory().create(rowptr[self.r0:self.r1 + 1] - lo, col[lo:hi],
+                                              None if values is None else values[lo:hi], self.r1 - self.r0, ncols, dtype,
+                                              self.w)
+
+    def local_features(self, x_full: torch.Tensor) -> torch.Tensor:
+        return x_full[:, self.f0:self.f0 + self.w].contiguous()
+
+    def mul_local(self, x_block: torch.Tensor) -> torch.Tensor:
+        """C[rows_i, f_j] of this rank"""
+        return self.engine.run(x_block)
+
+    def gather(self, c_block: torch.Tensor) -> torch.Tensor:
+        """full C on every rank: one all-gather of padded [max_rows, max_width] tiles, then laid out"""
+        if self.world == 1:
+            return c_block
+        mr = max(max(self.split[a + 1] - self.split[a] for a in range(self.row_parts)), 1)
+        mw = max(self.widths)
+        stage = torch.zeros((self.world, mr, mw), dtype=c_block.dtype, device=c_block.device)
+        stage[self.rank, : c_block.size(0), : c_block.size(1)] = c_block
+        dist.all_gather_into_tensor(stage.view(-1), stage[self.rank].reshape(-1).clone(), group=self.group)
+        out = torch.empty((self.nrows, self.h_total), dtype=c_block.dtype, device=c_block.device)
+        for a in range(self.row_parts):
+            f = 0
+            for b in range(self.feat_parts):
+                out[self.split[a]:self.split[a + 1], f:f + self.widths[b]] = \
+                    stage[a * self.feat_parts + b, : self.split[a + 1] - self.split[a], : self.widths[b]]
+                f += self.widths[b]
+        return out
 
 
 class RowSplitAdj:

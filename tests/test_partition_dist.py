@@ -131,6 +131,14 @@ def _worker(rank, world, port, q):
                              torch.from_numpy(loc.data.astype(np.int32)), n, c1 - c0, torch.int32, h,
                              engine_factory=OracleEngine)
         assert np.array_equal(cs.mul(x_t[c0:c1].contiguous()).numpy(), ref)
+        # 2-D grids: every factorisation of the world
+        for rparts in range(1, world + 1):
+            if world % rparts:
+                continue
+            gr = pd.GridSpMM(rp_t, col_t, None, n, torch.int32, h, rparts, world // rparts, engine_factory=OracleEngine)
+            blk = gr.mul_local(gr.local_features(x_t))
+            assert np.array_equal(blk.numpy(), ref[gr.r0:gr.r1, gr.f0:gr.f0 + gr.w]), (rparts, "local")
+            assert np.array_equal(gr.gather(blk).numpy(), ref), (rparts, "gather")
         # row-sharded activations: quantised blocks exchanged, global scale through a MAX all-reduce
         xf = rng.standard_normal((n, h)).astype(np.float32)
         for tdt in (torch.int8, torch.int32, torch.float32):
@@ -153,7 +161,7 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_multi_gpu_layer_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
