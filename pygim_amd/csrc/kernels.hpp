@@ -209,7 +209,6 @@ __device__ __forceinline__ void wave_segment(typename AccOf<T>::type (&acc)[VEC]
                                              const uint32_t *__restrict__ colind, const T *__restrict__ vals,
                                              const T *__restrict__ xlane /* X + f0 of this lane */,
                                              int64_t ldx, bool lane_on, int lane) {
-    using A = typename AccOf<T>::type;
     constexpr int DEPTH = 8;
     uint32_t mycol_next = (s + lane < e) ? __builtin_nontemporal_load(colind + s + lane) : 0u;
     T myval_next = T(1);
