@@ -71,6 +71,70 @@ def test_random_configurations(seed):
             _lib.set_tunable(k, v)
 
 
+def _col_split(rowptr, col, nrows, ncols, parts):
+    """reference col_split (spmm.py:127-136): parts of width ceil(ncols / parts), local column ids"""
+    step = -(-ncols // parts)
+    rows_of = np.repeat(np.arange(nrows), np.diff(rowptr))
+    out = []
+    for p in range(parts):
+        lo, hi = p * step, min(ncols, (p + 1) * step)
+        keep = (col >= lo) & (col < hi)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows_of[keep], minlength=nrows))]).astype(np.int32)
+        out.append((rp, (col[keep] - lo).astype(np.int32), rows_of[keep].astype(np.int32), max(hi - lo, 0), keep))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_groups(seed):
+    """whole groups: sp_parts column blocks (summed) x ds_parts feature blocks (concatenated), default and grande call
+    shapes, host operands, against the oracle's group driver (ops.hpp:42-62,97-118 restated)"""
+    rng = np.random.default_rng(5000 + seed)
+    dt = ALL_DTYPES[seed % 6]
+    npdt = NP_DTYPES[dt]
+    fmt = "COO" if seed % 3 == 1 else "CSR"
+    nrows, ncols = int(rng.integers(1, 600)), int(rng.integers(4, 1500))
+    sp_parts, ds_parts = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    h = int(rng.choice([4, 9, 32, 64, 100, 256]))
+    ds_parts = min(ds_parts, h)
+    rowptr, col = skewed_csr(rng, nrows, ncols, float(rng.choice([2, 10, 40])), float(rng.choice([0.5, 1.2])), False)
+    weighted = bool(rng.random() < 0.5)
+    vals_full = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else np.ones(len(col), dtype=npdt)
+    knobs = {"fuse_windows": int(rng.choice([0, 1])), "panel_mode": int(rng.choice([0, 1, 2])),
+             "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20]))}
+    old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
+    try:
+        x = driver_features(rng, ncols, h, npdt)
+        ref = oracle.spmm_csr(rowptr, col, vals_full if weighted else None, x)
+        parts = _col_split(rowptr, col, nrows, ncols, sp_parts)
+        widths = [len(c) for c in np.array_split(np.arange(h), ds_parts)]  # torch.chunk-like: ceil first
+        widths = [w for w in widths if w > 0]
+        offs = np.cumsum([0] + widths[:-1])
+        chunks = [np.ascontiguousarray(x[:, a:a + w]) for a, w in zip(offs, widths)]
+        idx0 = [p[0] if fmt == "CSR" else p[2] for p in parts]
+        cols = [p[1] for p in parts]
+        vals = [vals_full[p[4]] for p in parts] if (weighted or fmt == "COO") else None
+        nr, nc = [nrows] * sp_parts, [p[3] for p in parts]
+        out, _ = run_group_host(fmt, idx0, cols, vals, nr, nc, chunks, h)
+        assert np.array_equal(out, ref), (seed, dt, fmt, sp_parts, ds_parts, h, knobs, "default")
+        if fmt == "CSR":
+            # grande call shape: per-part windows [part cols, padded width]
+            pad = lambda w: -(-w * npdt().itemsize // 8) * 8 // npdt().itemsize
+            wins, lds, lo = [], [], 0
+            for p in parts:
+                for a, w in zip(offs, widths):
+                    buf = np.full((p[3], pad(w)), 55, dtype=npdt)
+                    buf[:, :w] = x[lo:lo + p[3], a:a + w]
+                    wins.append(buf)
+                    lds.append(pad(w))
+                lo += p[3]
+            out_g, _ = run_group_host("CSR", idx0, cols, vals, nr, nc, wins, h, kind="grande",
+                                      n_dense=[len(widths)] * sp_parts, dense_cols=widths * sp_parts, lds=lds)
+            assert np.array_equal(out_g, ref), (seed, dt, sp_parts, ds_parts, h, knobs, "grande")
+    finally:
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
+
+
 def test_product_is_graph_capturable(rng=np.random.default_rng(3)):
     """the run entry points only enqueue work on the caller's stream (plus a forked side stream joined by
     events), so a warmed-up product can be captured into a hipGraph and replayed"""
