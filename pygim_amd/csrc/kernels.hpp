@@ -403,7 +403,8 @@ template <int J> __device__ __forceinline__ uint32_t bcast8(uint32_t v) {
     constexpr int q = J & 3;
     constexpr int quad = q | (q << 2) | (q << 4) | (q << 6);  // quad_perm:[q,q,q,q]
     // t: lanes 0-3 of a group hold v[q], lanes 4-7 hold v[4+q]
-    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, quad, 0xF, 0xF, false);
+    // (every lane is written: no "old" value to preserve, so no register initialisation before the move)
+    const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, quad, 0xF, 0xF, false);
     // row_half_mirror (0x141): lane i <- lane 7-i inside each group of 8
     if constexpr (J < 4) {
         // want v[q] everywhere: lanes 4-7 (banks 1,3) take the mirror of lanes 0-3
@@ -536,11 +537,18 @@ template <typename T, int VEC> struct RowAcc<T, VEC, true> {
     }
 };
 
-template <bool OFF32>
-__device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xlane, uint32_t c, int64_t row_bytes64,
-                                              uint32_t row_bytes) {
-    if constexpr (OFF32) return *reinterpret_cast<const u32x4_t *>(xlane + c * row_bytes);  // 32-bit offset, uniform base
-    else return *reinterpret_cast<const u32x4_t *>(xlane + (int64_t)c * row_bytes64);
+// One gathered 16-byte piece of row c.  The base is wave-uniform (X + slice offset: an SGPR pair), the
+// per-lane part is a byte offset, so the load is `global_load_dwordx4 v, v_off, s[base]` and the address
+// costs one VALU instruction:
+//   AMODE 2: rows of exactly 128 bytes below 4 GiB (the slice-major copy): off = (c << 7) + lane_off
+//   AMODE 1: any row stride below 4 GiB: off = c * row_bytes + lane_off (32-bit multiply)
+//   AMODE 0: 64-bit offsets
+template <int AMODE>
+__device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xbase, uint32_t lane_off, uint32_t c,
+                                              int64_t row_bytes64, uint32_t row_bytes) {
+    if constexpr (AMODE == 2) return *reinterpret_cast<const u32x4_t *>(xbase + ((c << 7) + lane_off));
+    else if constexpr (AMODE == 1) return *reinterpret_cast<const u32x4_t *>(xbase + (c * row_bytes + lane_off));
+    else return *reinterpret_cast<const u32x4_t *>(xbase + ((int64_t)c * row_bytes64 + lane_off));
 }
 
 // One sweep body, two modes.
@@ -549,7 +557,7 @@ __device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xlane, ui
 //                 and the partial sums are added across the groups at the end (integers: exact; floats:
 //                 a different summation order, inside the 1e-5 bound).  Keeps long rows inside the L2-blocked
 //                 sweep instead of leaving one lane group with a serial chain of thousands of gathers.
-template <typename T, int VEC, bool OFF32, bool HAS_VALS, bool COOP>
+template <typename T, int VEC, int AMODE, bool HAS_VALS, bool COOP>
 __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__restrict__ item_row,
                                             const uint32_t *__restrict__ item_begin,
                                             const uint32_t *__restrict__ item_len, uint32_t nitems,
@@ -599,7 +607,8 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     // X is either the caller's row-major matrix (slice_stride = slice width) or the slice-major
     // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width);
     // lanes past the width re-read the first piece of their own slice (same cache line as lane 0)
-    const T *xlane = X + (int64_t)slice * slice_stride + (f0 < w ? li * VEC : 0);
+    const char *xbase = reinterpret_cast<const char *>(X + (int64_t)slice * slice_stride);  // wave-uniform
+    const uint32_t lane_off = f0 < w ? (uint32_t)li * 16u : 0u;
     const int64_t row_bytes64 = ldx * (int64_t)sizeof(T);
     const uint32_t row_bytes = (uint32_t)row_bytes64;
     T *crow = C + (int64_t)row * ldc;
@@ -678,7 +687,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
             cj[6] = bcast8<2 * B + 1>(c4[2]); cj[7] = bcast8<2 * B + 1>(c4[3]);                            \
             u32x4_t x[LPR];                                                                                \
             _Pragma("unroll") for (int j = 0; j < LPR; j++)                                                \
-                x[j] = gather_raw<OFF32>(reinterpret_cast<const char *>(xlane), cj[j], row_bytes64, row_bytes); \
+                x[j] = gather_raw<AMODE>(xbase, lane_off, cj[j], row_bytes64, row_bytes);                  \
             if constexpr (HAS_VALS) {                                                                      \
                 T vj[LPR];                                                                                 \
                 vj[0] = bcast8_t<T, 2 * B>(v4[0]); vj[1] = bcast8_t<T, 2 * B>(v4[1]);                      \
@@ -721,7 +730,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
 
 // One launch per column panel: the first coop_grid blocks take the panel's LONG items (one wave each,
 // dispatched first), the rest the ordinary items (one lane group each).
-template <typename T, int VEC, int LOG_LPR, bool OFF32, bool HAS_VALS>
+template <typename T, int VEC, int LOG_LPR, int AMODE, bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
                                                    const uint32_t *__restrict__ item_begin,
                                                    const uint32_t *__restrict__ item_len, uint32_t nitems,
@@ -734,10 +743,10 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                                                    int64_t ldc, uint32_t w, uint32_t nslices, int accumulate) {
     static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     if (blockIdx.x < coop_grid)
-        panel_sweep<T, VEC, OFF32, HAS_VALS, true>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
+        panel_sweep<T, VEC, AMODE, HAS_VALS, true>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
                                                    ldx, slice_stride, C, ldc, w, nslices, accumulate);
     else
-        panel_sweep<T, VEC, OFF32, HAS_VALS, false>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
+        panel_sweep<T, VEC, AMODE, HAS_VALS, false>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
                                                     colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate);
 }
 

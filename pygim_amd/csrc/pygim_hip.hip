@@ -371,14 +371,19 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t coop_grid = ncoop ? 8u * ns * ((coop_blocks + 7) / 8) : 0u;
                 const uint32_t norm_grid = nnorm ? 8u * ns * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
-#define PYGIM_LAUNCH_PANEL(O32, HV)                                                                         \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, O32, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,      \
+#define PYGIM_LAUNCH_PANEL(AM, HV)                                                                          \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,       \
                        ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xs0, ldg, \
                        slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0)
-                if (off32 && vals) PYGIM_LAUNCH_PANEL(true, true);
-                else if (off32) PYGIM_LAUNCH_PANEL(true, false);
-                else if (vals) PYGIM_LAUNCH_PANEL(false, true);
-                else PYGIM_LAUNCH_PANEL(false, false);
+                // addressing mode of the gathers (kernels.hpp gather_raw): 128-byte rows of the slice-major copy,
+                // any stride below 4 GiB, or 64-bit offsets
+                const int amode = !off32 ? 0 : ((size_t)ldg * sizeof(T) == 128 ? 2 : 1);
+                if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, true);
+                else if (amode == 2) PYGIM_LAUNCH_PANEL(2, false);
+                else if (amode == 1 && vals) PYGIM_LAUNCH_PANEL(1, true);
+                else if (amode == 1) PYGIM_LAUNCH_PANEL(1, false);
+                else if (vals) PYGIM_LAUNCH_PANEL(0, true);
+                else PYGIM_LAUNCH_PANEL(0, false);
 #undef PYGIM_LAUNCH_PANEL
             }
             }
