@@ -450,6 +450,7 @@ __device__ __forceinline__ void gather_vec(const T *__restrict__ xlane, uint32_t
 // add -- instead of 16 unpack+add pairs per gathered 16-byte piece (int8 h=256: 4.3 -> 2.x ms).
 // ---------------------------------------------------------------------------
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x4_u __attribute__((ext_vector_type(4), aligned(2)));  // 4 panel-local column ids, any 2-byte alignment
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));  // one gathered 16-byte piece, untyped
 __device__ __forceinline__ uint32_t add_packed_u16(uint32_t a, uint32_t b) {
     union { uint32_t u; u16x2_t v; } x, y;
@@ -541,12 +542,13 @@ template <typename T, int VEC> struct RowAcc<T, VEC, true> {
 // per-lane part is a byte offset, so the load is `global_load_dwordx4 v, v_off, s[base]` and the address
 // costs one VALU instruction:
 //   AMODE 2: rows of exactly 128 bytes below 4 GiB (the slice-major copy): off = (c << 7) + lane_off
+//   AMODE 3: as 2, and the column ids come from the 16-bit panel-local array (see load_chunk)
 //   AMODE 1: any row stride below 4 GiB: off = c * row_bytes + lane_off (32-bit multiply)
 //   AMODE 0: 64-bit offsets
 template <int AMODE>
 __device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xbase, uint32_t lane_off, uint32_t c,
                                               int64_t row_bytes64, uint32_t row_bytes) {
-    if constexpr (AMODE == 2) return *reinterpret_cast<const u32x4_t *>(xbase + ((c << 7) + lane_off));
+    if constexpr (AMODE >= 2) return *reinterpret_cast<const u32x4_t *>(xbase + ((c << 7) + lane_off));
     else if constexpr (AMODE == 1) return *reinterpret_cast<const u32x4_t *>(xbase + (c * row_bytes + lane_off));
     else return *reinterpret_cast<const u32x4_t *>(xbase + ((int64_t)c * row_bytes64 + lane_off));
 }
@@ -564,7 +566,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
                                             const uint32_t *__restrict__ colind, const T *__restrict__ vals,
                                             const T *__restrict__ X, int64_t ldx, int64_t slice_stride,
                                             T *__restrict__ C, int64_t ldc, uint32_t w, uint32_t nslices,
-                                            int accumulate) {
+                                            int accumulate, uint32_t col_base) {
     static_assert(VEC * sizeof(T) == 16, "the sweep gathers 16-byte pieces");
     constexpr bool PACKED = !HAS_VALS && sizeof(T) < 4;
     constexpr int LPR = 8;   // lanes per 128-byte slice of a row
@@ -646,7 +648,19 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     T v4[4], v4n[4];
     auto load_chunk = [&](uint32_t cbase, uint32_t (&cc)[4], T (&vv)[4]) {
         const uint32_t base = cbase + 4u * (uint32_t)li;
-        if (base + 4u <= len) {
+        if constexpr (AMODE == 3) {
+            // 16-bit ids relative to the first column of this launch's panel (same entry order as colind):
+            // half the index bytes through L2 per slice; entries past the end read column col_base (valid)
+            const unsigned short *c16 = reinterpret_cast<const unsigned short *>(colind);
+            if (base + 4u <= len) {
+                const u16x4_u q = __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(c16 + s + base));
+                cc[0] = col_base + q[0]; cc[1] = col_base + q[1]; cc[2] = col_base + q[2]; cc[3] = col_base + q[3];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    cc[k] = col_base + ((base + k < len) ? (uint32_t)__builtin_nontemporal_load(c16 + s + base + k) : 0u);
+            }
+        } else if (base + 4u <= len) {
             const u32x4_u q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(colind + s + base));
             cc[0] = q[0]; cc[1] = q[1]; cc[2] = q[2]; cc[3] = q[3];
         } else {
@@ -740,14 +754,15 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                                                    uint32_t coop_grid, const uint32_t *__restrict__ colind,
                                                    const T *__restrict__ vals, const T *__restrict__ X,
                                                    int64_t ldx, int64_t slice_stride, T *__restrict__ C,
-                                                   int64_t ldc, uint32_t w, uint32_t nslices, int accumulate) {
+                                                   int64_t ldc, uint32_t w, uint32_t nslices, int accumulate,
+                                                   uint32_t col_base) {
     static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     if (blockIdx.x < coop_grid)
         panel_sweep<T, VEC, AMODE, HAS_VALS, true>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
-                                                   ldx, slice_stride, C, ldc, w, nslices, accumulate);
+                                                   ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base);
     else
         panel_sweep<T, VEC, AMODE, HAS_VALS, false>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
-                                                    colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate);
+                                                    colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base);
 }
 
 // Slice-major copy of X for the panel sweep: Xs[s][j][0:F] = X[j][s*F : (s+1)*F] (zero padded past
@@ -1076,6 +1091,13 @@ __global__ void k_dequantize(const T *__restrict__ q, uint64_t n, const uint32_t
     } else {
         if (i < n) out[i] = (float)q[i] * scale;
     }
+}
+
+// 16-bit panel-local column ids for the panel sweep: col16[e] = colind[e] - (first column of e's panel)
+__global__ void k_make_col16(const uint32_t *__restrict__ colind, uint64_t nnz, uint32_t panel_cols,
+                             unsigned short *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) out[i] = (unsigned short)(colind[i] % panel_cols);
 }
 
 }  // namespace pygim

@@ -67,6 +67,7 @@ struct Tunables {
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
+    int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
@@ -96,6 +97,7 @@ struct Part {
     std::vector<size_t> panel_off;          // npanels + 1 offsets into the item arrays
     std::vector<uint32_t> panel_coop;       // per panel: leading items long enough for the wave-cooperative mode
     uint32_t npanels = 0, panel_cols = 0;
+    unsigned short *col16 = nullptr;        // panel-local 16-bit column ids (panels of <= 65536 columns), same order as colind
     std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
 };
 
@@ -197,6 +199,7 @@ void free_group(Group *g) {
             if (lp->d_desc) (void)hipFree(lp->d_desc);
         }
         if (p.d_items) (void)hipFree(p.d_items);
+        if (p.col16) (void)hipFree(p.col16);
     }
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
@@ -373,12 +376,16 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL(AM, HV)                                                                          \
     hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,       \
-                       ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid, p.colind, vals, Xs0, ldg, \
-                       slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0)
-                // addressing mode of the gathers (kernels.hpp gather_raw): 128-byte rows of the slice-major copy,
-                // any stride below 4 GiB, or 64-bit offsets
-                const int amode = !off32 ? 0 : ((size_t)ldg * sizeof(T) == 128 ? 2 : 1);
-                if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, true);
+                       ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid,                           \
+                       (AM == 3 ? (const uint32_t *)p.col16 : p.colind), vals, Xs0, ldg,                                  \
+                       slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0, q * p.panel_cols)
+                // addressing mode of the gathers (kernels.hpp gather_raw): 128-byte rows of the slice-major copy
+                // (with 16-bit panel-local column ids when the plan has them), any stride below 4 GiB, or 64-bit
+                int amode = !off32 ? 0 : ((size_t)ldg * sizeof(T) == 128 ? 2 : 1);
+                if (amode == 2 && p.col16 && g_tune.panel_col16) amode = 3;
+                if (amode == 3 && vals) PYGIM_LAUNCH_PANEL(3, true);
+                else if (amode == 3) PYGIM_LAUNCH_PANEL(3, false);
+                else if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, true);
                 else if (amode == 2) PYGIM_LAUNCH_PANEL(2, false);
                 else if (amode == 1 && vals) PYGIM_LAUNCH_PANEL(1, true);
                 else if (amode == 1) PYGIM_LAUNCH_PANEL(1, false);
@@ -588,6 +595,13 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
                     hipMemcpy(p.d_items + p.n_items, beg_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(p.d_items + 2 * p.n_items, len_v.data(), p.n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
                     return fail(PYGIM_ERR_HIP, "panel plan upload");
+                // 16-bit panel-local column ids (2 bytes per entry more, half the index bytes per sweep)
+                if (g_tune.panel_col16 && p.panel_cols <= 65536 && p.nnz > 0) {
+                    if (hipMalloc((void **)&p.col16, (size_t)p.nnz * 2) != hipSuccess) return fail(PYGIM_ERR_HIP, "col16 alloc");
+                    hipLaunchKernelGGL(k_make_col16, dim3((unsigned)((p.nnz + 255) / 256)), dim3(256), 0, st, p.colind,
+                                       (uint64_t)p.nnz, p.panel_cols, p.col16);
+                    if (hipStreamSynchronize(st) != hipSuccess) return fail(PYGIM_ERR_HIP, "col16 build");
+                }
             }
         }
     }
@@ -921,6 +935,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
     else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
+    else if (n == "panel_col16") slot = &g_tune.panel_col16;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

@@ -228,6 +228,30 @@ def test_panel_kernel_all_types(rng, dt):
 
 
 @pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_panel_sweep_with_16bit_panel_local_column_ids(rng, dt):
+    """the plan's 16-bit panel-local column ids (tunable panel_col16, default on; panels of <= 65536 columns) against
+    the 32-bit ids and the oracle: many small panels, one panel, ragged row ends at odd 2-byte alignments, weighted,
+    wave-cooperative long items, > 65536 columns in one panel (falls back to 32-bit ids)"""
+    npdt = NP_DTYPES[dt]
+    cases = [(500, 700, 128 * 50, 11), (300, 60000, 1 << 40, 5), (200, 70000, 1 << 40, 4), (64, 3000, 128 * 1000, 300)]
+    for nrows, ncols, pbytes, deg in cases:
+        rowptr, col = random_csr(rng, nrows, ncols, deg, empty_frac=0.1, long_rows=[(2, 1200)])
+        vals = rng.integers(-3, 4, size=len(col)).astype(npdt)
+        x = driver_features(rng, ncols, 64, npdt)
+        for v in (None, vals):
+            ref = oracle.spmm_csr(rowptr, col, v, x)
+            for c16 in (1, 0):
+                old = {k: _lib.set_tunable(k, val) for k, val in
+                       {"panel_mode": 1, "panel_bytes": pbytes, "panel_col16": c16, "panel_coop": 64}.items()}
+                try:
+                    out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [nrows], [ncols], [x], 64)
+                finally:
+                    for k, val in old.items():
+                        _lib.set_tunable(k, val)
+                assert np.array_equal(out, ref), (dt, nrows, ncols, c16, v is not None)
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
 def test_dense_windows_fused_into_one_product(rng, dt):
     """several dense windows per sparse part (ds_parts chunks; grande's per-unit windows with padded strides) run as ONE
     product of the full width (tunable fuse_windows, default on): same result as window by window and as the oracle,

@@ -51,7 +51,8 @@ def test_random_configurations(seed):
     knobs = {"panel_mode": int(rng.choice([0, 1, 2])), "panel_bytes": int(rng.choice([128 * 16, 128 * 200, 4 << 20])),
              "panel_coop": int(rng.choice([64, 512, 1 << 20])), "long_row_threshold": int(rng.choice([128, 4096])),
              "long_segment": int(rng.choice([64, 512])), "coo_chunk": int(rng.choice([64, 512])),
-             "panel_pack": int(rng.choice([0, 1])), "slice_group_bytes": int(rng.choice([0, 1, ncols * 128 * 3, 640 << 20]))}
+             "panel_pack": int(rng.choice([0, 1])), "slice_group_bytes": int(rng.choice([0, 1, ncols * 128 * 3, 640 << 20])),
+             "panel_col16": int(rng.choice([0, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
@@ -100,7 +101,8 @@ def test_random_groups(seed):
     weighted = bool(rng.random() < 0.5)
     vals_full = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else np.ones(len(col), dtype=npdt)
     knobs = {"fuse_windows": int(rng.choice([0, 1])), "panel_mode": int(rng.choice([0, 1, 2])),
-             "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20]))}
+             "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20])),
+             "panel_col16": int(rng.choice([0, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
