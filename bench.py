@@ -375,7 +375,11 @@ def main():
             traffic = None
     info = _lib.group_info(handles[0])
     n_panels = int(info["n_panels"])
-    kname = (f"k_slice_pack + k_csr_panel<float,4,3,true,false> x {n_panels} panel launches per product" if n_panels
+    # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
+    col16 = _lib.set_tunable("panel_col16", 1)
+    _lib.set_tunable("panel_col16", col16)
+    amode = 3 if (col16 and n / max(n_panels, 1) <= 65536) else 2
+    kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false> x {n_panels} panel launches per product" if n_panels
              else "k_csr_wide<float,4>")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

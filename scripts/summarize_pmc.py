@@ -37,7 +37,9 @@ if dom and (dom, "WRITE_SIZE") in agg:
     f_tot, f_n = agg[(dom, "FETCH_SIZE")]
     w_tot, w_n = agg[(dom, "WRITE_SIZE")]
     per_launch = (2.0 * f_tot / f_n + w_tot / w_n) * 1024.0
-    launches_per_product = int(os.environ.get("LAUNCHES_PER_PRODUCT", "1"))
+    # launches per product: the sweep's dispatches over those of k_slice_pack (one per product), else the env override
+    packs = [n for (k, c), (tot, n) in agg.items() if c == "FETCH_SIZE" and k.startswith("k_slice_pack")]
+    launches_per_product = int(os.environ.get("LAUNCHES_PER_PRODUCT", "0")) or (max(1, round(f_n / packs[0])) if packs else 1)
     hit = agg.get((dom, "TCC_HIT_sum"), [0, 1])
     miss = agg.get((dom, "TCC_MISS_sum"), [0, 1])
     rec = {"kernel": dom, "hbm_bytes_per_launch": per_launch, "launches_per_product": launches_per_product,
