@@ -18,12 +18,13 @@
  *
  * Threading: like the reference (one process-global `dpus` singleton,
  * spmm_default/pytorch_api.cpp:152) the library holds one device context per
- * process; calls are not re-entrant for the same group handle.  The tunables and
- * the slice-major copy of X are process-global: products that run concurrently on
- * DIFFERENT streams must either share the same X (tunable "xs_reuse" = 1 after the
- * first of them was enqueued and an event orders them, as bench.py does) or be
- * serialised by the caller.  Scratch buffers are sized on first use (hipMalloc), so
- * capture a product into a hipGraph only after one warm-up call.
+ * process; calls are not re-entrant for the same group handle.  The tunables are
+ * process-global.  The slice-major copy of X that the panel sweep gathers from lives in
+ * one buffer per launch stream, so products on different streams do not disturb each
+ * other; with tunable "xs_reuse" = 1 the caller vouches that X is unchanged since the
+ * most recent product (on whichever stream) and orders the streams itself (an event
+ * after the first product, as bench.py does): the copy is then shared, not repeated.
+ * Scratch buffers are sized on first use (hipMalloc), so capture a product into a hipGraph only after one warm-up call.
  */
 #ifndef PYGIM_HIP_H
 #define PYGIM_HIP_H

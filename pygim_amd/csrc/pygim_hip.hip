@@ -21,6 +21,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <map>
 #include <vector>
 
 using namespace pygim;
@@ -139,9 +140,11 @@ struct Context {
     int64_t nr_ranks = 0;
     std::set<Group *> groups;
     std::mutex mu;
-    // slice-major copy of the current X, shared by all groups of the process (one X per product)
-    void *xs = nullptr;
-    size_t xs_bytes = 0;
+    // slice-major copies of X for the panel sweep: one buffer per launch stream (products on different streams
+    // never share a buffer), plus a record of the most recent copy for callers that vouch "same X" (xs_reuse)
+    struct XsBuf { void *ptr = nullptr; size_t bytes = 0; };
+    std::map<hipStream_t, XsBuf> xs_by_stream;
+    void *xs = nullptr;  // the most recent copy (whichever stream made it)
 
     const void *xs_src = nullptr;
     int64_t xs_ld = 0, xs_rows = 0, xs_w = 0;
@@ -330,21 +333,32 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             // (rows of one slice that are already contiguous lines need no copy)
             if (g_tune.panel_pack && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128)) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
-                const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
-                                  g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
-                if (!same) {
-                    if (int rc = ensure(&g_ctx.xs, &g_ctx.xs_bytes, std::max<size_t>(need, 256))) return rc;
-                    const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
-                    if (threads > 0)
-                        hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)),
-                                           dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)g_ctx.xs);
-                    g_ctx.xs_src = X;
-                    g_ctx.xs_ld = ldx;
-                    g_ctx.xs_rows = p.ncols;
-                    g_ctx.xs_w = (int64_t)w;
-                    g_ctx.xs_es = sizeof(T);
+                void *xs_use = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(g_ctx.mu);
+                    const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
+                                      g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
+                    if (same) {
+                        xs_use = g_ctx.xs;
+                    } else {
+                        Context::XsBuf &b = g_ctx.xs_by_stream[st];
+                        if (int rc = ensure(&b.ptr, &b.bytes, std::max<size_t>(need, 256))) return rc;
+                        xs_use = b.ptr;
+                        g_ctx.xs = b.ptr;
+                        g_ctx.xs_src = X;
+                        g_ctx.xs_ld = ldx;
+                        g_ctx.xs_rows = p.ncols;
+                        g_ctx.xs_w = (int64_t)w;
+                        g_ctx.xs_es = sizeof(T);
+                    }
+                    if (!same) {
+                        const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
+                        if (threads > 0)
+                            hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)),
+                                               dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)xs_use);
+                    }
                 }
-                Xg = (const T *)g_ctx.xs;
+                Xg = (const T *)xs_use;
                 ldg = F;
                 slice_stride = (int64_t)p.ncols * F;
             }
@@ -890,9 +904,10 @@ int pygim_release(void) {
     }
     if (g_ctx.inited) (void)hipDeviceSynchronize();
     for (Group *g : gs) free_group(g);
-    if (g_ctx.xs) (void)hipFree(g_ctx.xs);
+    for (auto &kv : g_ctx.xs_by_stream)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_ctx.xs_by_stream.clear();
     g_ctx.xs = nullptr;
-    g_ctx.xs_bytes = 0;
 
     g_ctx.xs_src = nullptr;
     g_ctx.inited = false;

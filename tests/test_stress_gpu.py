@@ -162,3 +162,31 @@ def test_product_is_graph_capturable(rng=np.random.default_rng(3)):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
     _lib.group_free(hd)
+
+
+def test_concurrent_products_on_two_streams_with_different_features():
+    """two groups, two streams, two different X in flight at once: each product gathers from its own slice-major
+    copy (one buffer per launch stream), so neither disturbs the other"""
+    rng = np.random.default_rng(17)
+    n, h = 20000, 256
+    rowptr, col = skewed_csr(rng, n, n, 40, 1.0, False)
+    d = lambda a: torch.from_numpy(a).cuda()
+    rp, cl = d(rowptr), d(col)
+    xs = [driver_features(rng, n, h, np.int32) for _ in range(2)]
+    refs = [oracle.spmm_csr(rowptr, col, None, x) for x in xs]
+    xd = [d(x) for x in xs]
+    outs = [torch.empty((n, h), dtype=torch.int32, device="cuda") for _ in range(2)]
+    hds = [_lib.group_create(_lib.CSR, _lib.INT32, [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [len(col)], [1], [h], h)
+           for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    try:
+        torch.cuda.synchronize()
+        for rep in range(6):
+            for k in range(2):
+                _lib.spmm_run_group(hds[k], [xd[k].data_ptr()], outs[k].data_ptr(), streams[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.array_equal(outs[k].cpu().numpy(), refs[k]), k
+    finally:
+        for hd in hds:
+            _lib.group_free(hd)
