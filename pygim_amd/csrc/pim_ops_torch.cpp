@@ -138,7 +138,11 @@ at::Tensor run_common(int64_t handle, std::vector<at::Tensor> &parts, int kind) 
         lds.push_back(p.dim() == 2 ? p.size(1) : 1);
     }
     const int64_t out_cols = kind == 2 ? (int64_t)parts.size() : m.h;
-    at::Tensor out = at::empty({m.rows, out_cols}, parts[0].options());
+    // host operands: the result lives in page-locked host memory (torch's caching host allocator), so the device-to-host
+    // copy runs at PCIe speed instead of faulting fresh pages in; PYGIM_PINNED_OUT=0 gives pageable memory
+    const char *po = std::getenv("PYGIM_PINNED_OUT");
+    const bool pinned = !parts[0].is_cuda() && !(po && po[0] == '0');
+    at::Tensor out = at::empty({m.rows, out_cols}, parts[0].options().pinned_memory(pinned));
     void *st = stream_of(out);
     if (kind == 0) chk(pygim_spmm_run_group(handle, ptrs.data(), out.data_ptr(), st));
     else if (kind == 1) chk(pygim_grande_run_group(handle, ptrs.data(), lds.data(), out.data_ptr(), st));
