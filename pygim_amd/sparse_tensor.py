@@ -171,6 +171,21 @@ def _shim_matmul(src, other, reduce: str = "sum"):
     Sum-reduce only (the reference's call sites use the default, spmm_test.py:25).
     """
     assert reduce in ("sum", "add")
+    if other.is_floating_point() and not other.is_cuda:
+        # floats: torch's CSR x dense kernel (MKL, all cores) -- about 20x faster than the COO path on the
+        # Reddit-shaped graph; integer element types are not implemented there
+        try:
+            rowptr, col, value = src.csr()
+            if value is None:
+                value = torch.ones(col.numel(), dtype=other.dtype)
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # "Sparse CSR tensor support is in beta state"
+                a = torch.sparse_csr_tensor(rowptr, col, value.to(other.dtype), size=tuple(src.sizes()))
+            return a @ other
+        except RuntimeError:
+            pass
     row, col, value = src.coo()
     if value is None:
         value = torch.ones(src.nnz(), dtype=other.dtype, device=other.device)
