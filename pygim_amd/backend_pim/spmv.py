@@ -56,8 +56,21 @@ class SparseTensorCOO(SparseGroupBase):
         return res[:self.raw.size(0), ...]
 
     def mul(self, B: torch.Tensor):
+        if B.is_cuda and B.dtype == self.dtype and len(self.coo) == 1:
+            return self._mul_device(B)
         panels = dense_split(B, B.size(1) // self.groups)
         return torch.cat([self.mul_single(panel) for panel in panels], dim=1)
+
+    def _mul_device(self, B: torch.Tensor):
+        """device-resident features: the h SpMVs of the loop above are ONE product over the whole [N, h] matrix (same
+        sums, same order per output element) -- no per-group calls, no vector packing, 128-byte gathers"""
+        from .. import _lib
+
+        Bp = self._pad_rows(B).contiguous()
+        out = torch.empty((self.coo[0].size(0), Bp.size(1)), dtype=self.dtype, device=B.device)
+        _lib.block_run(self.sp_info_ptr, 0, Bp.data_ptr(), Bp.size(1), out.data_ptr(), Bp.size(1), Bp.size(1), False,
+                       torch.cuda.current_stream(B.device).cuda_stream)
+        return out[:self.raw.size(0), ...]
 
     def col_split(self, nparts=4):
         assert False
