@@ -137,6 +137,45 @@ def main():
         save("partition_ref", n_cases=k, **kw)
     else:
         print("oracle/_ref missing: partition vectors NOT regenerated")
+    # (6) quantise -> aggregate -> dequantise of the conv layers (pyg_gcn_conv.py:130-137, quantize.py:20-42) with a fixed
+    # x: the numpy restatement, accepted only when the torch statement of the same lines gives the same bits
+    from pygim_amd import quantize as qz
+
+    rng6 = np.random.default_rng(66)
+    rowptr, col = random_csr(rng6, 256, 256, 14, empty_frac=0.1, long_rows=[(5, 1200)])
+    x = (rng6.standard_normal((256, 40)) * 2.5).astype(np.float32)
+    for name in ("INT8", "INT16", "INT32", "FLT32"):
+        npdt = NP_DTYPES[name]
+        scale, xq = oracle.symmetric_quantize(x, npdt)
+        out_q = oracle.spmm_csr(rowptr, col, None, xq)
+        out = oracle.symmetric_dequantize(out_q, 1.0, scale)
+        s_t, xq_t = qz.symmetric_quantize(torch.from_numpy(x), TORCH_OF[name])
+        assert np.float32(s_t.item()) == scale and np.array_equal(xq_t.numpy(), xq), "numpy vs torch quantiser"
+        out_t = qz.symmetric_dequantize(torch.from_numpy(out_q), 1.0, s_t)
+        assert np.array_equal(out_t.numpy(), out)
+        save(f"quant_gcn_{name}", rowptr=rowptr, col=col, x=x, scale=np.float32(scale), xq=xq, out_q=out_q, out=out)
+    # (7) MatrixMarket reader: outputs of the REFERENCE's own readCOOMatrix + coo2csr (utils.hpp:15-127, compiled in place
+    # into oracle/_ref/libref_utils.so) on small files; the file text travels in the fixture
+    if oracle.have_ref_utils():
+        import tempfile
+
+        rng7 = np.random.default_rng(77)
+        kw = {}
+        for k, (nr_, nc_) in enumerate(((12, 9), (33, 40), (7, 7), (50, 3))):
+            nnz_ = 4 * nr_
+            rr, cc = rng7.integers(0, nr_, nnz_), rng7.integers(0, nc_, nnz_)
+            text = "%%MatrixMarket matrix coordinate real general\n% generated by tests/golden/make_golden.py\n"
+            text += f"{nr_} {nc_} {nnz_}\n" + "".join(f"{a + 1} {b + 1} {rng7.integers(1, 9)}.5\n" for a, b in zip(rr, cc))
+            with tempfile.NamedTemporaryFile("w", suffix=".mtx", delete=False) as f:
+                f.write(text)
+            n_, m_, rp_, ci_, va_ = oracle.ref_read_matrix_csr(f.name)
+            os.unlink(f.name)
+            kw[f"text_{k}"] = np.frombuffer(text.encode(), dtype=np.uint8)
+            kw[f"shape_{k}"] = np.array([n_, m_], dtype=np.int64)
+            kw[f"rowptr_{k}"], kw[f"colind_{k}"], kw[f"values_{k}"] = rp_.astype(np.int32), ci_.astype(np.int32), va_
+        save("mtx_ref", n_cases=4, **kw)
+    else:
+        print("oracle/_ref/libref_utils.so missing: mtx vectors NOT regenerated")
 
 
 if __name__ == "__main__":

@@ -50,6 +50,16 @@ if variant == "spmm":
             assert (rn, rc) == got[:2] and rptr.tolist() == got[2].tolist() and rcol.tolist() == got[3].tolist()
             assert rval.tolist() == got[4].tolist()
         os.unlink(f.name)
+    # ... and the committed outputs of the reference reader (tests/golden/mtx_ref.npz)
+    zg = np.load(os.path.join(ROOT, "tests", "golden", "mtx_ref.npz"))
+    for k in range(int(zg["n_cases"])):
+        with tempfile.NamedTemporaryFile("wb", suffix=".mtx", delete=False) as f:
+            f.write(zg[f"text_{k}"].tobytes())
+        assert [ops.read_matrix_nrows(f.name), ops.read_matrix_ncols(f.name)] == zg[f"shape_{k}"].tolist()
+        assert ops.read_matrix_rowptr(f.name).tolist() == zg[f"rowptr_{k}"].tolist()
+        assert ops.read_matrix_colind(f.name).tolist() == zg[f"colind_{k}"].tolist()
+        assert ops.read_matrix_values(f.name).tolist() == zg[f"values_{k}"].tolist()
+        os.unlink(f.name)
     print("OK mtx")
 if not on_gpu:
     try:

@@ -149,3 +149,50 @@ def test_row_sharded_inference_two_ranks_equals_one_rank(dtype):
     # GEMM library may tile (and so round) differently: 1e-5 relative, the floating-point bar of the path
     assert abs(one[0] - two[0]) <= 1e-5 * abs(one[0]) and abs(one[1] - two[1]) <= 1e-5 * abs(one[1]), (one, two)
     assert abs(acc1[0] - acc2[0]) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["INT8", "INT16", "INT32", "FLT32"])
+def test_quantiser_golden_vectors_on_gpu(name):
+    """tests/golden/quant_gcn_*.npz through the C ABI: the fused call and the three steps"""
+    import os
+
+    from pygim_amd import _lib
+    from pygim_amd.pim_ops import DTYPE_CODE
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"quant_gcn_{name}.npz"))
+    tdt = {"INT8": torch.int8, "INT16": torch.int16, "INT32": torch.int32, "FLT32": torch.float32}[name]
+    n, h = z["x"].shape
+    d = lambda a: torch.from_numpy(a).cuda()
+    rp, cl, x = d(z["rowptr"].astype(np.int32)), d(z["col"].astype(np.int32)), d(z["x"])
+    _lib.init_ranks(1)
+    try:
+        hd = _lib.group_create(_lib.CSR, DTYPE_CODE[tdt], [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [cl.numel()], [1], [h], h)
+        out = torch.empty((n, h), dtype=torch.float32, device="cuda")
+        scale = torch.zeros((), dtype=torch.float32, device="cuda")
+        _lib.quant_spmm_run(hd, x.data_ptr(), h, out.data_ptr(), scale.data_ptr())
+        torch.cuda.synchronize()
+        import oracle
+
+        def same(got, want, unit):
+            # integers: bit-exact.  FLT32 keeps the quantised values as floats: sums of ~2^19-sized integers round, and the
+            # 1200-entry row is summed by a whole wave in another order -> the 1e-5 bound relative to |A| . |x_q|
+            if name != "FLT32":
+                return np.array_equal(got, want)
+            bound = 1e-5 * oracle.spmm_csr(z["rowptr"], z["col"], None, np.abs(z["xq"])).astype(np.float64) * unit
+            return bool(np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= bound))
+
+        assert np.float32(scale.item()) == z["scale"] and same(out.cpu().numpy(), z["out"], float(z["scale"]))
+        bits = torch.zeros(1, dtype=torch.int32, device="cuda")
+        xq = torch.empty((n, h), dtype=tdt, device="cuda")
+        _lib.quant_absmax(x.data_ptr(), h, n, h, bits.data_ptr())
+        _lib.quantize(DTYPE_CODE[tdt], x.data_ptr(), h, n, h, bits.data_ptr(), xq.data_ptr())
+        oq = torch.empty((n, h), dtype=tdt, device="cuda")
+        _lib.spmm_run_group(hd, [xq.data_ptr()], oq.data_ptr())
+        out2 = torch.empty((n, h), dtype=torch.float32, device="cuda")
+        _lib.dequantize(DTYPE_CODE[tdt], oq.data_ptr(), n * h, bits.data_ptr(), out2.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(xq.cpu().numpy(), z["xq"]) and same(oq.cpu().numpy(), z["out_q"], 1.0)
+        assert same(out2.cpu().numpy(), z["out"], float(z["scale"]))
+        _lib.group_free(hd)
+    finally:
+        _lib.release()

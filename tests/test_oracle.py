@@ -125,9 +125,48 @@ def test_golden_vectors():
                 assert np.array_equal(oracle.partition_by_nnz(rp, nparts), z[f"by_nnz_{k}"])
                 assert np.array_equal(oracle.partition_by_row(len(rp) - 1, nparts), z[f"by_row_{k}"])
             continue
+        if not f.startswith("spmm_"):
+            continue  # quant_gcn_* and mtx_ref have their own tests below
         vals = z["vals"] if "vals" in z.files else None
         if str(z["fmt"]) == "CSR":
             y = oracle.spmm_csr(z["rowptr"], z["col"], vals, z["x"])
         else:
             y = oracle.spmm_coo(z["row"], z["col"], vals, z["x"], int(z["nrows"]))
         assert np.array_equal(y, z["y"]), f
+
+
+@pytest.mark.parametrize("name", ["INT8", "INT16", "INT32", "FLT32"])
+def test_quantiser_golden_vectors(name):
+    """quantise -> aggregate -> dequantise of the conv layers with a fixed x: the numpy
+    restatement and the torch statement (pygim_amd.quantize) both reproduce the committed fixture"""
+    from pygim_amd import quantize as qz
+
+    z = np.load(os.path.join(GOLDEN, f"quant_gcn_{name}.npz"))
+    npdt = NP_DTYPES[name]
+    scale, xq = oracle.symmetric_quantize(z["x"], npdt)
+    assert scale == z["scale"] and np.array_equal(xq, z["xq"])
+    out_q = oracle.spmm_csr(z["rowptr"], z["col"], None, xq)
+    assert np.array_equal(out_q, z["out_q"])
+    assert np.array_equal(oracle.symmetric_dequantize(out_q, 1.0, scale), z["out"])
+    tdt = {"INT8": torch.int8, "INT16": torch.int16, "INT32": torch.int32, "FLT32": torch.float32}[name]
+    s_t, xq_t = qz.symmetric_quantize(torch.from_numpy(z["x"]), tdt)
+    assert np.float32(s_t.item()) == z["scale"] and np.array_equal(xq_t.numpy(), z["xq"])
+
+
+def test_matrix_market_reader_against_reference_vectors(tmp_path):
+    """tests/golden/mtx_ref.npz holds outputs of the reference's own readCOOMatrix + coo2csr (utils.hpp:15-127, built in
+    place); the Python registration's reader (pim_ops._read_mtx_csr) reproduces them from the same file text"""
+    from pygim_amd import pim_ops
+
+    z = np.load(os.path.join(GOLDEN, "mtx_ref.npz"))
+    for k in range(int(z["n_cases"])):
+        path = tmp_path / f"case{k}.mtx"
+        path.write_bytes(z[f"text_{k}"].tobytes())
+        m = pim_ops._read_mtx_csr(str(path))
+        assert list(m.shape) == z[f"shape_{k}"].tolist()
+        assert np.array_equal(np.asarray(m.indptr), z[f"rowptr_{k}"]) and np.array_equal(np.asarray(m.indices), z[f"colind_{k}"])
+        assert np.array_equal(np.asarray(m.data), z[f"values_{k}"])
+        if oracle.have_ref_utils():
+            n_, m_, rp_, ci_, va_ = oracle.ref_read_matrix_csr(str(path))
+            assert [n_, m_] == z[f"shape_{k}"].tolist() and np.array_equal(rp_.astype(np.int32), z[f"rowptr_{k}"])
+            assert np.array_equal(ci_.astype(np.int32), z[f"colind_{k}"]) and np.array_equal(va_, z[f"values_{k}"])
