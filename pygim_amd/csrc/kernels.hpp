@@ -605,7 +605,8 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
         load_c = accumulate || !(lf >> 31);
     }
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
-    const bool lane_on = row_ok && f0 < w;
+    // (an empty row under accumulate has nothing to add: its row of C is neither read nor written)
+    const bool lane_on = row_ok && f0 < w && !(len == 0 && accumulate);
     // X is either the caller's row-major matrix (slice_stride = slice width) or the slice-major
     // copy made by k_slice_pack (slice_stride = rows * slice width, ldx = slice width);
     // lanes past the width re-read the first piece of their own slice (same cache line as lane 0)
@@ -998,6 +999,26 @@ __global__ void k_check_sorted_cols(const uint32_t *__restrict__ rowptr, const u
 template <typename T> __global__ void k_check_ones(const T *__restrict__ v, uint32_t n, int *flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && !(v[i] == T(1))) flag[0] = 1;
+}
+// entries whose weight is not 1: count, then append (entry index, column, weight - 1) in any order
+// (the host sorts the few of them); integer types only (modular arithmetic: v*x == x + (v-1)*x exactly)
+template <typename T> __global__ void k_count_non_ones(const T *__restrict__ v, uint32_t n, uint32_t *counter) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = i < n && !(v[i] == T(1));
+    const uint64_t m = __ballot(hit);
+    if (m && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+}
+template <typename T>
+__global__ void k_extract_non_ones(const T *__restrict__ v, const uint32_t *__restrict__ colind, uint32_t n, uint32_t cap,
+                                   uint32_t *counter, uint32_t *__restrict__ out_e, uint32_t *__restrict__ out_col,
+                                   T *__restrict__ out_val) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || v[i] == T(1)) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k >= cap) return;
+    out_e[k] = (uint32_t)i;
+    out_col[k] = colind[i];
+    out_val[k] = from_acc<T>(to_acc<T>(v[i]) - to_acc<T>(T(1)));
 }
 // COO row index -> rowptr (lower bound of each row in the sorted rowind)
 __global__ void k_coo_rowptr(const uint32_t *__restrict__ rowind, uint32_t nnz, uint32_t nrows,

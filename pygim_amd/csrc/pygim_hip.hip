@@ -22,6 +22,7 @@
 #include <set>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 
 using namespace pygim;
@@ -68,6 +69,7 @@ struct Tunables {
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
+    int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
@@ -99,7 +101,12 @@ struct Part {
     std::vector<uint32_t> panel_coop;       // per panel: leading items long enough for the wave-cooperative mode
     uint32_t npanels = 0, panel_cols = 0;
     unsigned short *col16 = nullptr;        // panel-local 16-bit column ids (panels of <= 65536 columns), same order as colind
-    std::vector<int64_t> dense_cols;  // widths of the dense parts paired with this part
+    std::vector<int64_t> dense_cols;
+    // integer weights that are 1 almost everywhere (a coalesced multigraph, backend_pim/spmm.py:40-42): this part keeps
+    // the PATTERN only (unit weights: no value array, no multiplies, packed 8/16-bit sums) and `extra` holds the few
+    // entries with weight v != 1 as (v - 1); A.X = pattern.X + extra.X exactly in modular arithmetic
+    std::unique_ptr<Part> extra;
+    bool is_extra = false;  // widths of the dense parts paired with this part
 };
 
 struct Group {
@@ -118,6 +125,11 @@ struct Group {
     size_t xq_bytes = 0;
     void *oq = nullptr;
     size_t oq_bytes = 0;
+    // slice-major copy made (or reused) by the block product in flight: its correction part (Part::extra) gathers from
+    // the same copy instead of repeating it
+    const void *packed_src = nullptr;
+    void *packed_buf = nullptr;
+    int64_t packed_ld = 0, packed_w = 0;
     void *xcat = nullptr;     // dense windows of one sparse part laid side by side (fused block product)
     size_t xcat_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
@@ -191,19 +203,22 @@ template <typename P> int to_device(const void *src, size_t bytes, P **dst, bool
     return 0;
 }
 
-void free_group(Group *g) {
-    for (auto &p : g->parts) {
-        if (p.own_rowptr && p.rowptr) (void)hipFree(p.rowptr);
-        if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
-        if (p.own_colind && p.colind) (void)hipFree(p.colind);
-        if (p.own_vals && p.vals) (void)hipFree(p.vals);
-        for (LongPlan *lp : {&p.lp_base, &p.lp_panel}) {
-            if (lp->d_tasks) (void)hipFree(lp->d_tasks);
-            if (lp->d_desc) (void)hipFree(lp->d_desc);
-        }
-        if (p.d_items) (void)hipFree(p.d_items);
-        if (p.col16) (void)hipFree(p.col16);
+void free_part(Part &p) {
+    if (p.own_rowptr && p.rowptr) (void)hipFree(p.rowptr);
+    if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
+    if (p.own_colind && p.colind) (void)hipFree(p.colind);
+    if (p.own_vals && p.vals) (void)hipFree(p.vals);
+    for (LongPlan *lp : {&p.lp_base, &p.lp_panel}) {
+        if (lp->d_tasks) (void)hipFree(lp->d_tasks);
+        if (lp->d_desc) (void)hipFree(lp->d_desc);
     }
+    if (p.d_items) (void)hipFree(p.d_items);
+    if (p.col16) (void)hipFree(p.col16);
+    if (p.extra) free_part(*p.extra);
+}
+
+void free_group(Group *g) {
+    for (auto &p : g->parts) free_part(p);
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
@@ -247,8 +262,8 @@ struct KernelTimer {
     Group *g;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    KernelTimer(Group *g_, hipStream_t st_) : g(g_), st(st_) {
-        if (g_tune.kernel_events && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+    KernelTimer(Group *g_, hipStream_t st_, bool on = true) : g(g_), st(st_) {
+        if (on && g_tune.kernel_events && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
             (void)hipEventRecord(a, st);
         else
             a = b = nullptr;
@@ -276,7 +291,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     }
     // COO groups: the panel sweep (through the row pointers derived at create time) when it pays,
     // else the native equal-nnz kernel
-    const bool coo_native = (g->format == PYGIM_COO) && !use_panel && !g_tune.coo_via_rowptr && lanes_needed > 16;
+    const bool coo_native = (g->format == PYGIM_COO) && p.rowind != nullptr && !use_panel && !g_tune.coo_via_rowptr && lanes_needed > 16;
     if (coo_native) {
         // nnz-split kernel + carry fix-up
         if (!accumulate) HIP_TRY(hipMemset2DAsync(C, (size_t)ldc * sizeof(T), 0, (size_t)w * sizeof(T), nrows, st));
@@ -286,7 +301,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
         const size_t need = (size_t)nchunks * 2 * w * sizeof(T);
         if (int rc = ensure(&g->scratch, &g->scratch_bytes, need)) return rc;
         dim3 grid((nchunks + 3) / 4, (lanes_needed + 63) / 64);
-        KernelTimer kt(g, st);
+        KernelTimer kt(g, st, !p.is_extra);
         hipLaunchKernelGGL((k_coo_wide<T, VEC>), grid, dim3(256), 0, st, p.rowind, p.colind, vals,
                            (uint32_t)p.nnz, chunk, X, ldx, C, ldc, w, (T *)g->scratch, accumulate ? 1 : 0);
         kt.stop();
@@ -329,12 +344,15 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             // gather source: slice-major copy (default) or the caller's row-major X
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
-            KernelTimer kt(g, st);
+            KernelTimer kt(g, st, !p.is_extra);
             // (rows of one slice that are already contiguous lines need no copy)
             if (g_tune.panel_pack && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128)) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
                 void *xs_use = nullptr;
-                {
+                if (p.is_extra && g->packed_buf && g->packed_src == (const void *)X && g->packed_ld == ldx &&
+                    g->packed_w == (int64_t)w) {
+                    xs_use = g->packed_buf;  // the pattern product of this very call packed it on this stream
+                } else {
                     std::lock_guard<std::mutex> lk(g_ctx.mu);
                     const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
                                       g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
@@ -358,6 +376,10 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                                                dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)xs_use);
                     }
                 }
+                g->packed_src = X;
+                g->packed_buf = xs_use;
+                g->packed_ld = ldx;
+                g->packed_w = (int64_t)w;
                 Xg = (const T *)xs_use;
                 ldg = F;
                 slice_stride = (int64_t)p.ncols * F;
@@ -417,7 +439,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     if (g_tune.csr_kernel == 1) wide = true;
     if (g_tune.csr_kernel == 2 && lanes_needed <= 32) wide = false;
     if (nrows > 0) {
-        KernelTimer kt(g, st);
+        KernelTimer kt(g, st, !p.is_extra);
         if (wide) {
             dim3 grid((nrows + 3) / 4, (lanes_needed + 63) / 64);
             hipLaunchKernelGGL((k_csr_wide<T, VEC>), grid, dim3(256), 0, st, p.rowptr, p.colind, vals, X, ldx, C,
@@ -452,9 +474,21 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     return launch_block_t<T, 1>(g, p, x, ldx, c, ldc, ww, accumulate, st);
 }
 
+int launch_block_main(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
+                      hipStream_t st);
+
 int launch_block_any(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w,
                      bool accumulate, hipStream_t st) {
     if (w <= 0 || p.nrows == 0) return 0;  // nothing to write
+    g->packed_buf = nullptr;
+    if (int rc = launch_block_main(g, p, X, ldx, C, ldc, w, accumulate, st)) return rc;
+    // the few entries with a weight other than 1, as (weight - 1), added on top of the pattern product
+    if (p.extra) return launch_block_main(g, *p.extra, X, ldx, C, ldc, w, true, st);
+    return 0;
+}
+
+int launch_block_main(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
+                      hipStream_t st) {
     switch (g->dtype) {
         case PYGIM_INT8: return launch_block<int8_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
         case PYGIM_INT16: return launch_block<int16_t>(g, p, X, ldx, C, ldc, w, accumulate, st);
@@ -579,7 +613,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
                 for (size_t r = 0; r < nr; r++) {
                     const uint32_t deg = rp[r + 1] - rp[r];
                     if (heavy[r]) continue;                          // segment kernels
-                    if (hi[r] > lo[r] || (q == 0 && deg == 0)) order.push_back((uint32_t)r);
+                    // (empty rows are items of panel 0: they zero their row of C; a correction part only ever adds, so it has none)
+                    if (hi[r] > lo[r] || (q == 0 && deg == 0 && !p.is_extra)) order.push_back((uint32_t)r);
                 }
                 {   // stable counting sort by item length, longest first (O(items + longest))
                     uint32_t longest = 0;
@@ -647,6 +682,90 @@ static void launch_pack(const void *const *d_ptrs, uint32_t gcount, uint64_t n, 
 //   windows[k]   : dense operand k (flattened over parts when per_part)
 //   ld[k]        : its row stride in elements
 //   per_part     : grande layout (each window holds only the rows of its own sparse part)
+// Integer weights that are 1 except for a few entries (at most nnz / 64): keep the unit-weight pattern in `p` and move
+// the exceptions, as (weight - 1), into p.extra (CSR by rows, entries in stored order).  One-time, at group creation.
+template <typename T>
+int split_unit_pattern_t(Part &p, size_t es, int *d_flag_sorted, uint32_t *d_counter, hipStream_t st) {
+    const uint32_t n = (uint32_t)p.nnz;
+    if (hipMemsetAsync(d_counter, 0, sizeof(uint32_t), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "counter reset");
+    hipLaunchKernelGGL((k_count_non_ones<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const T *)p.vals, n, d_counter);
+    uint32_t cnt = 0;
+    if (hipMemcpy(&cnt, d_counter, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "non-one count");
+    if (cnt == 0 || (uint64_t)cnt * 64 > (uint64_t)n) return 0;  // all ones is handled by the caller; many weights: keep them
+    uint32_t *d_e = nullptr, *d_c = nullptr;
+    T *d_v = nullptr;
+    auto drop = [&]() {
+        if (d_e) (void)hipFree(d_e);
+        if (d_c) (void)hipFree(d_c);
+        if (d_v) (void)hipFree(d_v);
+    };
+    if (hipMalloc((void **)&d_e, (size_t)cnt * 4) != hipSuccess || hipMalloc((void **)&d_c, (size_t)cnt * 4) != hipSuccess ||
+        hipMalloc((void **)&d_v, (size_t)cnt * sizeof(T)) != hipSuccess) {
+        drop();
+        return fail(PYGIM_ERR_HIP, "extra part scratch");
+    }
+    (void)hipMemsetAsync(d_counter, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL((k_extract_non_ones<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const T *)p.vals, p.colind, n, cnt,
+                       d_counter, d_e, d_c, d_v);
+    std::vector<uint32_t> e(cnt), c(cnt), rp((size_t)p.nrows + 1);
+    std::vector<T> v(cnt);
+    const bool ok = hipMemcpy(e.data(), d_e, (size_t)cnt * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(c.data(), d_c, (size_t)cnt * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(v.data(), d_v, (size_t)cnt * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess &&
+                    hipMemcpy(rp.data(), p.rowptr, rp.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    drop();
+    if (!ok) return fail(PYGIM_ERR_HIP, "extra part D2H");
+    // stored order (the append order on the device is arbitrary)
+    std::vector<uint32_t> order(cnt);
+    for (uint32_t k = 0; k < cnt; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e[a] < e[b]; });
+    std::vector<uint32_t> xrp((size_t)p.nrows + 1, 0), xc(cnt);
+    std::vector<T> xv(cnt);
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t src = order[k];
+        const uint32_t row = (uint32_t)(std::upper_bound(rp.begin(), rp.end(), e[src]) - rp.begin()) - 1;
+        xrp[(size_t)row + 1]++;
+        xc[k] = c[src];
+        xv[k] = v[src];
+    }
+    for (int64_t r = 0; r < p.nrows; r++) xrp[(size_t)r + 1] += xrp[(size_t)r];
+    std::unique_ptr<Part> x(new Part);
+    x->is_extra = true;
+    x->nrows = p.nrows;
+    x->ncols = p.ncols;
+    x->nnz = cnt;
+    x->dense_cols = p.dense_cols;
+    x->own_rowptr = x->own_colind = x->own_vals = true;
+    if (hipMalloc((void **)&x->rowptr, xrp.size() * 4) != hipSuccess || hipMalloc((void **)&x->colind, (size_t)cnt * 4) != hipSuccess ||
+        hipMalloc(&x->vals, (size_t)cnt * sizeof(T)) != hipSuccess ||
+        hipMemcpy(x->rowptr, xrp.data(), xrp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(x->colind, xc.data(), (size_t)cnt * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(x->vals, xv.data(), (size_t)cnt * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        free_part(*x);
+        return fail(PYGIM_ERR_HIP, "extra part upload");
+    }
+    if (int rc = build_plans(*x, es, d_flag_sorted, st)) {
+        free_part(*x);
+        return rc;
+    }
+    p.extra = std::move(x);
+    if (p.own_vals) (void)hipFree(p.vals);
+    p.vals = nullptr;
+    p.own_vals = false;
+    return 0;
+}
+
+int split_unit_pattern(Part &p, int dtype, size_t es, int *d_flag_sorted, uint32_t *d_counter, hipStream_t st) {
+    if (!p.vals || p.nnz == 0 || !g_tune.split_unit_pattern) return 0;
+    switch (dtype) {
+        case PYGIM_INT8: return split_unit_pattern_t<int8_t>(p, es, d_flag_sorted, d_counter, st);
+        case PYGIM_INT16: return split_unit_pattern_t<int16_t>(p, es, d_flag_sorted, d_counter, st);
+        case PYGIM_INT32: return split_unit_pattern_t<int32_t>(p, es, d_flag_sorted, d_counter, st);
+        case PYGIM_INT64: return split_unit_pattern_t<int64_t>(p, es, d_flag_sorted, d_counter, st);
+        default: return 0;  // floats keep their weights in the loop (stored-order sums)
+    }
+}
+
 static int run_group_common(Group *g, const void *const *windows, const int64_t *ld, bool per_part, void *out,
                             hipStream_t st) {
     const size_t es = dtype_size(g->dtype);
@@ -951,6 +1070,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
+    else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;
@@ -1067,6 +1187,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.vals = nullptr;
             p.own_vals = false;
         }
+        if (!g->all_ones && (rc = split_unit_pattern(p, dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st))) return bail(rc);
         if ((rc = build_plans(p, es, g->d_flags + 4, st))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));

@@ -227,6 +227,49 @@ def test_panel_kernel_all_types(rng, dt):
         _lib.set_tunable("panel_bytes", old[1])
 
 
+@pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64"])
+@pytest.mark.parametrize("fmt", ["CSR", "COO"])
+def test_mostly_unit_integer_weights_split_into_pattern_plus_corrections(rng, dt, fmt):
+    """a coalesced multigraph's weights (1 almost everywhere, spmm.py:40-42): the group keeps the unit pattern in the hot
+    loop and a small correction part with (weight - 1); exact in modular arithmetic, equal to the unsplit run and the oracle,
+    including weights 0, negative and wrapping ones, rows made only of corrections, and sp_parts > 1"""
+    npdt = NP_DTYPES[dt]
+    nrows, ncols, h = 700, 900, 96
+    rowptr, col = random_csr(rng, nrows, ncols, 40, empty_frac=0.05, long_rows=[(11, 3000)])
+    if fmt == "COO":
+        # strictly increasing columns per row (coalesced pattern)
+        keep = np.ones(len(col), dtype=bool)
+        keep[1:] = (col[1:] != col[:-1]) | np.isin(np.arange(1, len(col)), rowptr[1:-1])
+        rows_of = np.repeat(np.arange(nrows), np.diff(rowptr))[keep]
+        col = col[keep]
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows_of, minlength=nrows))]).astype(np.int32)
+    vals = np.ones(len(col), dtype=npdt)
+    pick = rng.choice(len(col), size=max(len(col) // 200, 3), replace=False)
+    info = np.iinfo(npdt)
+    vals[pick] = rng.choice(np.array([0, 2, 3, -1, -5, info.max, info.min], dtype=npdt), size=len(pick))
+    x = driver_features(rng, ncols, h, npdt)
+    ref = oracle.spmm_csr(rowptr, col, vals, x)
+    rows_of = np.repeat(np.arange(nrows), np.diff(rowptr)).astype(np.int32)
+    outs = {}
+    for split in (1, 0):
+        old = _lib.set_tunable("split_unit_pattern", split)
+        try:
+            outs[split], _ = run_group_host(fmt, [rowptr if fmt == "CSR" else rows_of], [col], [vals], [nrows], [ncols], [x], h)
+        finally:
+            _lib.set_tunable("split_unit_pattern", old)
+        assert np.array_equal(outs[split], ref), (dt, fmt, split)
+    # two sparse parts (column split), device-resident operands
+    step = ncols // 2
+    parts = []
+    for lo, hi in ((0, step), (step, ncols)):
+        k = (col >= lo) & (col < hi)
+        parts.append((np.concatenate([[0], np.cumsum(np.bincount(rows_of[k], minlength=nrows))]).astype(np.int32),
+                      (col[k] - lo).astype(np.int32), rows_of[k], vals[k], hi - lo))
+    out2, _ = run_group_host(fmt, [p[0] if fmt == "CSR" else p[2] for p in parts], [p[1] for p in parts], [p[3] for p in parts],
+                             [nrows, nrows], [p[4] for p in parts], [x], h)
+    assert np.array_equal(out2, ref), (dt, fmt, "two parts")
+
+
 @pytest.mark.parametrize("dt", ALL_DTYPES)
 def test_panel_sweep_with_16bit_panel_local_column_ids(rng, dt):
     """the plan's 16-bit panel-local column ids (tunable panel_col16, default on; panels of <= 65536 columns) against
