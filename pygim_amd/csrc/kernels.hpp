@@ -1114,6 +1114,40 @@ __global__ void k_dequantize(const T *__restrict__ q, uint64_t n, const uint32_t
     }
 }
 
+// ---- merging the sparse parts (column blocks with local ids) of a group into one matrix, one-time --------------
+// cursor[r] starts as the merged row pointer; after part i has been scattered it is advanced by that part's row length
+__global__ void k_merge_count(const uint32_t *__restrict__ rowptr_i, uint32_t nrows, uint32_t *__restrict__ merged_rowptr) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= nrows) merged_rowptr[r] += rowptr_i[r];  // sum of prefix arrays = prefix array of the concatenated rows
+}
+template <typename T>
+__global__ void k_merge_scatter(const uint32_t *__restrict__ rowptr_i, const uint32_t *__restrict__ rowind_i,
+                                const uint32_t *__restrict__ col_i, const T *__restrict__ val_i, uint32_t nrows, uint32_t nnz_i,
+                                uint32_t col_offset, const uint32_t *__restrict__ cursor, uint32_t *__restrict__ out_col,
+                                T *__restrict__ out_val) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz_i) return;
+    uint32_t row;
+    if (rowind_i) {
+        row = rowind_i[e];
+    } else {  // last row whose start is <= e
+        uint32_t lo = 0, hi = nrows;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo + 1) >> 1);
+            if (rowptr_i[mid] <= (uint32_t)e) lo = mid;
+            else hi = mid - 1;
+        }
+        row = lo;
+    }
+    const uint32_t dst = cursor[row] + ((uint32_t)e - rowptr_i[row]);
+    out_col[dst] = col_i[e] + col_offset;
+    if (out_val) out_val[dst] = val_i ? val_i[e] : T(1);
+}
+__global__ void k_merge_advance(const uint32_t *__restrict__ rowptr_i, uint32_t nrows, uint32_t *__restrict__ cursor) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) cursor[r] += rowptr_i[r + 1] - rowptr_i[r];
+}
+
 // 16-bit panel-local column ids for the panel sweep: col16[e] = colind[e] - (first column of e's panel)
 __global__ void k_make_col16(const uint32_t *__restrict__ colind, uint64_t nnz, uint32_t panel_cols,
                              unsigned short *__restrict__ out) {

@@ -69,6 +69,7 @@ struct Tunables {
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
+    int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
@@ -113,6 +114,10 @@ struct Group {
     int format = 0, dtype = 0;
     int64_t h = 0, total_rows = 0, total_cols = 0;
     std::vector<Part> parts;
+    // the sparse parts are column blocks of ONE matrix (spmm.py:127-136) whose partial products are summed: merged here
+    // (global column ids, rows concatenated in block order = sorted) so that the group product is one sweep with the
+    // plan that suits the whole matrix, whatever sp_parts the caller chose (32 parts of Reddit: 10.3 -> 6.8 ms)
+    std::unique_ptr<Part> merged;
     bool all_ones = true;
     // scratch (device), grown on demand
     void *scratch = nullptr;
@@ -219,6 +224,7 @@ void free_part(Part &p) {
 
 void free_group(Group *g) {
     for (auto &p : g->parts) free_part(p);
+    if (g->merged) free_part(*g->merged);
     if (g->scratch) (void)hipFree(g->scratch);
     if (g->stage_in) (void)hipFree(g->stage_in);
     if (g->stage_out) (void)hipFree(g->stage_out);
@@ -766,6 +772,77 @@ int split_unit_pattern(Part &p, int dtype, size_t es, int *d_flag_sorted, uint32
     }
 }
 
+// One-time: the group's sparse parts as one matrix (see Group::merged).
+template <typename T>
+int build_merged_t(Group *g, size_t es, hipStream_t st) {
+    const int64_t nrows = g->total_rows;
+    uint64_t nnz = 0, ncols = 0;
+    bool any_vals = false;
+    for (auto &p : g->parts) {
+        nnz += (uint64_t)p.nnz;
+        ncols += (uint64_t)p.ncols;
+        any_vals = any_vals || p.vals != nullptr;
+    }
+    any_vals = any_vals && !g->all_ones;
+    if (nnz == 0 || nnz > 0xFFFFFFFFull || ncols > 0xFFFFFFFFull) return 0;  // nothing to gain / would not fit 32-bit ids
+    std::unique_ptr<Part> m(new Part);
+    m->nrows = nrows;
+    m->ncols = (int64_t)ncols;
+    m->nnz = (int64_t)nnz;
+    m->dense_cols = g->parts[0].dense_cols;
+    m->own_rowptr = m->own_colind = true;
+    uint32_t *cursor = nullptr;
+    auto fail_free = [&](const char *what) {
+        if (cursor) (void)hipFree(cursor);
+        free_part(*m);
+        return fail(PYGIM_ERR_HIP, what);
+    };
+    const size_t rp_bytes = (size_t)(nrows + 1) * 4;
+    if (hipMalloc((void **)&m->rowptr, rp_bytes) != hipSuccess || hipMalloc((void **)&m->colind, (size_t)nnz * 4) != hipSuccess ||
+        hipMalloc((void **)&cursor, rp_bytes) != hipSuccess)
+        return fail_free("merged matrix alloc");
+    if (any_vals) {
+        if (hipMalloc(&m->vals, (size_t)nnz * es) != hipSuccess) return fail_free("merged values alloc");
+        m->own_vals = true;
+    }
+    if (hipMemsetAsync(m->rowptr, 0, rp_bytes, st) != hipSuccess) return fail_free("merged rowptr reset");
+    const unsigned rgrid = (unsigned)((nrows + 1 + 255) / 256);
+    for (auto &p : g->parts) hipLaunchKernelGGL(k_merge_count, dim3(rgrid), dim3(256), 0, st, p.rowptr, (uint32_t)nrows, m->rowptr);
+    if (hipMemcpyAsync(cursor, m->rowptr, rp_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail_free("cursor copy");
+    uint32_t coff = 0;
+    for (auto &p : g->parts) {
+        if (p.nnz > 0)
+            hipLaunchKernelGGL((k_merge_scatter<T>), dim3((unsigned)((p.nnz + 255) / 256)), dim3(256), 0, st, p.rowptr, p.rowind,
+                               p.colind, (const T *)p.vals, (uint32_t)nrows, (uint32_t)p.nnz, coff, cursor, m->colind, (T *)m->vals);
+        hipLaunchKernelGGL(k_merge_advance, dim3(rgrid), dim3(256), 0, st, p.rowptr, (uint32_t)nrows, cursor);
+        coff += (uint32_t)p.ncols;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail_free("merged matrix build");
+    (void)hipFree(cursor);
+    cursor = nullptr;
+    int rc = 0;
+    if (!g->all_ones) rc = split_unit_pattern(*m, g->dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st);
+    if (!rc) rc = build_plans(*m, es, g->d_flags + 4, st);
+    if (rc) {
+        free_part(*m);
+        return rc;
+    }
+    g->merged = std::move(m);
+    return 0;
+}
+
+int build_merged(Group *g, size_t es, hipStream_t st) {
+    switch (g->dtype) {
+        case PYGIM_INT8: return build_merged_t<int8_t>(g, es, st);
+        case PYGIM_INT16: return build_merged_t<int16_t>(g, es, st);
+        case PYGIM_INT32: return build_merged_t<int32_t>(g, es, st);
+        case PYGIM_INT64: return build_merged_t<int64_t>(g, es, st);
+        case PYGIM_FLT32: return build_merged_t<float>(g, es, st);
+        case PYGIM_DBL64: return build_merged_t<double>(g, es, st);
+    }
+    return 0;
+}
+
 static int run_group_common(Group *g, const void *const *windows, const int64_t *ld, bool per_part, void *out,
                             hipStream_t st) {
     const size_t es = dtype_size(g->dtype);
@@ -829,6 +906,45 @@ static int run_group_common(Group *g, const void *const *windows, const int64_t 
     }
     const double t1 = now_ms();
     // block products: sum over sparse parts, concatenate over dense parts
+    if (g->merged && g_tune.merge_parts && g->parts.size() > 1) {
+        // ... as ONE product with the merged matrix (Group::merged)
+        Part &m = *g->merged;
+        const size_t nd0 = g->parts[0].dense_cols.size();
+        bool in_place = !per_part;  // one window, or windows that sit side by side in one row-major matrix
+        for (size_t j = 1; in_place && j < nd0; j++)
+            in_place = lds[j] == lds[0] && (const char *)dwin[j] == (const char *)dwin[j - 1] + (size_t)widths[j - 1] * es;
+        const char *x = nullptr;
+        int64_t ldx = 0;
+        if (in_place) {
+            x = (const char *)dwin[0];
+            ldx = lds[0];
+        } else {
+            // lay the windows side by side (and, for per-part windows, the parts' row ranges one below the other)
+            const int64_t ldc_el = (int64_t)((((size_t)g->h * es + 15) & ~(size_t)15) / es);
+            const size_t need = (size_t)g->total_cols * ldc_el * es;
+            if (int rc = ensure(&g->xcat, &g->xcat_bytes, std::max<size_t>(need, 256))) return rc;
+            int64_t brow = 0;
+            size_t kbase = 0;
+            for (size_t i = 0; i < g->parts.size(); i++) {
+                Part &p = g->parts[i];
+                int64_t a = 0;
+                for (size_t j = 0; j < p.dense_cols.size(); j++) {
+                    const size_t k = per_part ? kbase + j : j;
+                    const char *src = (const char *)dwin[k] + (per_part ? 0 : (size_t)brow * lds[k] * es);
+                    if (widths[k] > 0 && p.ncols > 0)
+                        HIP_TRY(hipMemcpy2DAsync((char *)g->xcat + ((size_t)brow * ldc_el + (size_t)a) * es, (size_t)ldc_el * es, src,
+                                                 (size_t)lds[k] * es, (size_t)widths[k] * es, (size_t)p.ncols,
+                                                 hipMemcpyDeviceToDevice, st));
+                    a += widths[k];
+                }
+                brow += p.ncols;
+                kbase += p.dense_cols.size();
+            }
+            x = (const char *)g->xcat;
+            ldx = ldc_el;
+        }
+        if (int rc = launch_block_any(g, m, x, ldx, dout, g->h, g->h, /*accumulate=*/false, st)) return rc;
+    } else {
     int64_t brow = 0;
     size_t kbase = 0;
     for (size_t i = 0; i < g->parts.size(); i++) {
@@ -883,6 +999,7 @@ static int run_group_common(Group *g, const void *const *windows, const int64_t 
         }
         brow += p.ncols;
         kbase += p.dense_cols.size();
+    }
     }
     if (!dev_in) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -1071,6 +1188,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
     else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
+    else if (n == "merge_parts") slot = &g_tune.merge_parts;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;
@@ -1178,6 +1296,8 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         return bail(fail(PYGIM_ERR_INVALID, "rowptr is not a non-decreasing prefix array ending at nnz"));
     }
     g->all_ones = (flags[2] == 0);
+    // several sparse parts: also one merged matrix (built from the parts as given, before values are dropped or split)
+    if (n_parts > 1 && g_tune.merge_parts && (rc = build_merged(g, es, st))) return bail(rc);
     // long-row plan needs rowptr on the host
     for (int i = 0; i < n_parts; i++) {
         Part &p = g->parts[i];

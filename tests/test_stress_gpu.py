@@ -85,7 +85,7 @@ def _col_split(rowptr, col, nrows, ncols, parts):
     return out
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_groups(seed):
     """whole groups: sp_parts column blocks (summed) x ds_parts feature blocks (concatenated), default and grande call
     shapes, host operands, against the oracle's group driver (ops.hpp:42-62,97-118 restated)"""
@@ -102,7 +102,8 @@ def test_random_groups(seed):
     vals_full = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else np.ones(len(col), dtype=npdt)
     knobs = {"fuse_windows": int(rng.choice([0, 1])), "panel_mode": int(rng.choice([0, 1, 2])),
              "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20])),
-             "panel_col16": int(rng.choice([0, 1]))}
+             "panel_col16": int(rng.choice([0, 1])), "merge_parts": int(rng.choice([0, 1])),
+             "split_unit_pattern": int(rng.choice([0, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
