@@ -1528,12 +1528,17 @@ int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out
         if (int rc = ensure(&g->stage_out, &g->stage_out_bytes, std::max<size_t>((size_t)g->total_rows * nvec * es, 256))) return rc;
         dout = g->stage_out;
     }
-    int64_t brow = 0;
-    for (size_t i = 0; i < g->parts.size(); i++) {
-        Part &p = g->parts[i];
-        const char *x = (const char *)g->stage_in + (size_t)brow * nvec * es;
-        if (int rc = launch_block_any(g, p, x, (int64_t)nvec, dout, (int64_t)nvec, (int64_t)nvec, i > 0, st)) return rc;
-        brow += p.ncols;
+    if (g->merged && g_tune.merge_parts && g->parts.size() > 1) {
+        if (int rc = launch_block_any(g, *g->merged, g->stage_in, (int64_t)nvec, dout, (int64_t)nvec, (int64_t)nvec, false, st))
+            return rc;
+    } else {
+        int64_t brow = 0;
+        for (size_t i = 0; i < g->parts.size(); i++) {
+            Part &p = g->parts[i];
+            const char *x = (const char *)g->stage_in + (size_t)brow * nvec * es;
+            if (int rc = launch_block_any(g, p, x, (int64_t)nvec, dout, (int64_t)nvec, (int64_t)nvec, i > 0, st)) return rc;
+            brow += p.ncols;
+        }
     }
     if (!dev_out) {
         HIP_TRY(hipStreamSynchronize(st));

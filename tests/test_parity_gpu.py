@@ -227,6 +227,44 @@ def test_panel_kernel_all_types(rng, dt):
         _lib.set_tunable("panel_bytes", old[1])
 
 
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_spmv_group_through_the_c_abi(rng, dt):
+    """pygim_spmv_run_group: `groups` right-hand sides of one column each -> out[nrows, groups]; one and three sparse
+    parts (column blocks, merged or part by part), host and device vectors"""
+    npdt = NP_DTYPES[dt]
+    nrows, ncols = 333, 500
+    rowptr, col = random_csr(rng, nrows, ncols, 9, empty_frac=0.1, long_rows=[(4, 1500)])
+    rows_of = np.repeat(np.arange(nrows), np.diff(rowptr))
+    for groups in (1, 3, 8):
+        x = driver_features(rng, ncols, groups, npdt)
+        ref = oracle.spmm_csr(rowptr, col, None, x)
+        vecs = [np.ascontiguousarray(x[:, j]) for j in range(groups)]
+        for bounds in ([0, ncols], [0, 170, 171, ncols]):
+            rp, cl, nc = [], [], []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                k = (col >= lo) & (col < hi)
+                rp.append(np.concatenate([[0], np.cumsum(np.bincount(rows_of[k], minlength=nrows))]).astype(np.int32))
+                cl.append((col[k] - lo).astype(np.int32))
+                nc.append(hi - lo)
+            n = len(nc)
+            for merge in (1, 0):
+                old = _lib.set_tunable("merge_parts", merge)
+                try:
+                    out, _ = run_group_host("CSR", rp, cl, None, [nrows] * n, nc, vecs, groups, kind="spmv", n_dense=[groups] * n,
+                                            dense_cols=[1] * groups * n)
+                    assert np.array_equal(out, ref), (dt, groups, n, merge, "host")
+                    hd = _lib.group_create(_lib.CSR, CODE_OF_NP[np.dtype(npdt)], [_ptr(a) for a in rp], [_ptr(a) for a in cl], None,
+                                           [nrows] * n, nc, [len(c) for c in cl], [groups] * n, [1] * groups * n, groups)
+                    dv = [torch.from_numpy(v).cuda() for v in vecs]
+                    od = torch.empty((nrows, groups), dtype=dv[0].dtype, device="cuda")
+                    _lib.spmv_run_group(hd, [v.data_ptr() for v in dv], od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    _lib.group_free(hd)
+                    assert np.array_equal(od.cpu().numpy(), ref), (dt, groups, n, merge, "device")
+                finally:
+                    _lib.set_tunable("merge_parts", old)
+
+
 @pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64"])
 @pytest.mark.parametrize("fmt", ["CSR", "COO"])
 def test_mostly_unit_integer_weights_split_into_pattern_plus_corrections(rng, dt, fmt):
