@@ -191,3 +191,31 @@ def test_concurrent_products_on_two_streams_with_different_features():
     finally:
         for hd in hds:
             _lib.group_free(hd)
+
+
+def test_group_create_free_does_not_leak_device_memory():
+    """groups with every optional structure (merged matrix, correction part, 16-bit ids, long-row plans, staging and
+    window buffers) created, run and freed repeatedly: the free device memory comes back"""
+    rng = np.random.default_rng(23)
+    nrows, ncols, h = 3000, 3000, 64
+    rowptr, col = skewed_csr(rng, nrows, ncols, 30, 1.3, False)
+    vals = np.ones(len(col), dtype=np.int32)
+    vals[rng.choice(len(col), size=len(col) // 300, replace=False)] = 3
+    parts = _col_split(rowptr, col, nrows, ncols, 3)
+    x = driver_features(rng, ncols, h, np.int32)
+    chunks = [np.ascontiguousarray(x[:, :40]), np.ascontiguousarray(x[:, 40:])]
+    ref = oracle.spmm_csr(rowptr, col, vals, x)
+
+    def once():
+        out, _ = run_group_host("CSR", [p[0] for p in parts], [p[1] for p in parts], [vals[p[4]] for p in parts], [nrows] * 3,
+                                [p[3] for p in parts], chunks, h)
+        assert np.array_equal(out, ref)
+
+    once()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(30):
+        once()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (32 << 20), (free0, free1)
