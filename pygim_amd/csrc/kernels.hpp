@@ -431,18 +431,6 @@ template <typename T, int J> __device__ __forceinline__ T bcast8_t(T v) {
     }
 }
 
-template <typename T, int VEC, bool OFF32>
-__device__ __forceinline__ void gather_vec(const T *__restrict__ xlane, uint32_t c, int64_t ldx, uint32_t row_bytes,
-                                           T (&out)[VEC]) {
-    if constexpr (OFF32) {
-        // X spans < 4 GiB: 32-bit byte offset on a uniform base -> global_load with saddr
-        const uint32_t off = c * row_bytes;
-        load_vec<T, VEC>(reinterpret_cast<const T *>(reinterpret_cast<const char *>(xlane) + off), out);
-    } else {
-        load_vec<T, VEC>(xlane + (int64_t)c * ldx, out);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Row accumulator of the panel sweep.  Generic form: one wide register per element (AccOf<T>).
 // Packed form (8- and 16-bit integers with unit weights): sums stay packed in 32-bit words and wrap per
