@@ -440,6 +440,9 @@ template <typename T, int J> __device__ __forceinline__ T bcast8_t(T v) {
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4_u __attribute__((ext_vector_type(4), aligned(2)));  // 4 panel-local column ids, any 2-byte alignment
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));  // one gathered 16-byte piece, untyped
+// the same piece at ANY byte alignment (rows of X / C whose stride is not a multiple of 16 bytes: h = 41, 100 int8 ...):
+// still one global_load/store_dwordx4, the memory path takes unaligned addresses
+typedef uint32_t u32x4_b __attribute__((ext_vector_type(4), aligned(1)));
 __device__ __forceinline__ uint32_t add_packed_u16(uint32_t a, uint32_t b) {
     union { uint32_t u; u16x2_t v; } x, y;
     x.u = a;
@@ -537,8 +540,8 @@ template <int AMODE>
 __device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xbase, uint32_t lane_off, uint32_t c,
                                               int64_t row_bytes64, uint32_t row_bytes) {
     if constexpr (AMODE >= 2) return *reinterpret_cast<const u32x4_t *>(xbase + ((c << 7) + lane_off));
-    else if constexpr (AMODE == 1) return *reinterpret_cast<const u32x4_t *>(xbase + (c * row_bytes + lane_off));
-    else return *reinterpret_cast<const u32x4_t *>(xbase + ((int64_t)c * row_bytes64 + lane_off));
+    else if constexpr (AMODE == 1) return *reinterpret_cast<const u32x4_b *>(xbase + (c * row_bytes + lane_off));
+    else return *reinterpret_cast<const u32x4_b *>(xbase + ((int64_t)c * row_bytes64 + lane_off));
 }
 
 // One sweep body, two modes.
@@ -607,7 +610,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     acc.zero();
     if (load_c && lane_on && (!COOP || grp == 0)) {
         if (f0 + VEC <= w) {
-            acc.set_raw(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(crow + f0)));
+            acc.set_raw(__builtin_nontemporal_load(reinterpret_cast<const u32x4_b *>(crow + f0)));
         } else {
 #pragma unroll
             for (int k = 0; k < VEC; k++)
@@ -722,7 +725,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     }
     if (lane_on && (!COOP || grp == 0)) {
         if (f0 + VEC <= w) {
-            __builtin_nontemporal_store(acc.get_raw(), reinterpret_cast<u32x4_t *>(crow + f0));
+            __builtin_nontemporal_store((u32x4_b)acc.get_raw(), reinterpret_cast<u32x4_b *>(crow + f0));
         } else {
 #pragma unroll
             for (int k = 0; k < VEC; k++)
@@ -771,14 +774,17 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
     const uint32_t rem = (uint32_t)(t % per_row);
     const uint32_t sl = rem >> LOG_LPR, li = rem & (LPR - 1);
     const uint32_t f0 = sl * F + li * VEC;
-    T v[VEC];
-    if (f0 + VEC <= w) {
-        load_vec_nt<T, VEC>(X + (int64_t)j * ldx + f0, v);
+    static_assert(VEC * sizeof(T) == 16, "16-byte pieces");
+    T *dst = Xs + ((int64_t)sl * nrows + j) * F + li * VEC;
+    if (f0 + VEC <= w) {  // X rows may sit at any byte alignment; the copy is 16-byte aligned
+        const u32x4_b q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_b *>(X + (int64_t)j * ldx + f0));
+        *reinterpret_cast<u32x4_t *>(dst) = (u32x4_t)q;
     } else {
+        T v[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? X[(int64_t)j * ldx + f0 + k] : T(0);
+        store_vec<T, VEC>(dst, v);
     }
-    store_vec<T, VEC>(Xs + ((int64_t)sl * nrows + j) * F + li * VEC, v);
 }
 
 // panel pointers: pp[p * nrows + i] = first stored entry of sorted row i whose column

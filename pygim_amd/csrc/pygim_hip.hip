@@ -467,10 +467,18 @@ template <typename T>
 int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
                  hipStream_t st) {
     const int vb = pick_vec_bytes(sizeof(T), X, ldx, C, ldc);
-    const int vec = vb / (int)sizeof(T);
+    int vec = vb / (int)sizeof(T);
     const T *x = (const T *)X;
     T *c = (T *)C;
     const uint32_t ww = (uint32_t)w;
+    // The panel sweep moves 16-byte pieces with byte-aligned accesses (kernels.hpp u32x4_b), so it takes rows of
+    // ANY alignment (h = 41 floats, 100 int8 ...); only its long-row side kernels want aligned rows, so parts that
+    // have such rows keep the alignment-matched kernels.
+    if (vb < 16 && g_tune.force_vec_bytes == 0 && p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 32 &&
+        p.lp_panel.n_tasks == 0 &&
+        (g_tune.panel_mode == 1 || p.npanels == 1 ||
+         (double)p.nnz / ((double)p.nrows * p.npanels) >= (double)g_tune.panel_min_seg))
+        vec = 16 / (int)sizeof(T);
 #define CASE(V)                                                               \
     if constexpr (V >= 1 && (size_t)V * sizeof(T) <= 16) {                    \
         if (vec == V) return launch_block_t<T, V>(g, p, x, ldx, c, ldc, ww, accumulate, st); \

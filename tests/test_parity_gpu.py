@@ -228,6 +228,49 @@ def test_panel_kernel_all_types(rng, dt):
 
 
 @pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_panel_sweep_takes_rows_of_any_alignment(rng, dt):
+    """feature widths whose rows are not 16-byte multiples (41, 255, 9 ...), X / C base pointers off by one element,
+    padded strides, accumulation over unmerged sparse parts: the sweep's byte-aligned 16-byte accesses give the oracle's
+    result (these shapes used the row-per-wave kernels before: Reddit f32 h = 255 23 -> 7.7 ms, int8 h = 100 14.8 -> 1.4 ms)"""
+    npdt = NP_DTYPES[dt]
+    tdt = torch.from_numpy(np.zeros(1, dtype=npdt)).dtype
+    nrows, ncols = 400, 600
+    rowptr, col = random_csr(rng, nrows, ncols, 25, empty_frac=0.1, long_rows=[(8, 2500)])
+    vals = rng.integers(-3, 4, size=len(col)).astype(npdt)
+    old = {k: _lib.set_tunable(k, v) for k, v in {"panel_mode": 1, "panel_bytes": 128 * 150, "merge_parts": 0}.items()}
+    try:
+        for h in (9, 41, 255, 33):
+            x = driver_features(rng, ncols, h, npdt)
+            for v in (None, vals):
+                ref = oracle.spmm_csr(rowptr, col, v, x)
+                out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [nrows], [ncols], [x], h)
+                assert np.array_equal(out, ref), (dt, h, v is not None, "host")
+            # device operands inside larger buffers: base off by one element, row strides h + 3 / h + 1
+            ldx, ldc = h + 3, h + 1
+            xb = torch.zeros(ncols * ldx + 1, dtype=tdt, device="cuda")
+            xb[1:].view(ncols, ldx)[:, :h] = torch.from_numpy(x).cuda()
+            cb = torch.full((nrows * ldc + 1,), 7, dtype=tdt, device="cuda")
+            es = xb.element_size()
+            hd = _lib.group_create(_lib.CSR, CODE_OF_NP[np.dtype(npdt)], [_ptr(rowptr)], [_ptr(col)], None, [nrows], [ncols], [len(col)],
+                                   [1], [h], h)
+            try:
+                st = torch.cuda.current_stream().cuda_stream
+                _lib.block_run(hd, 0, xb.data_ptr() + es, ldx, cb.data_ptr() + es, ldc, h, False, st)
+                _lib.block_run(hd, 0, xb.data_ptr() + es, ldx, cb.data_ptr() + es, ldc, h, True, st)   # C += A.X once more
+                torch.cuda.synchronize()
+            finally:
+                _lib.group_free(hd)
+            got = cb[1:].view(nrows, ldc).cpu().numpy()
+            want = oracle.spmm_csr(rowptr, col, None, x)
+            want2 = (want.astype(np.int64) * 2).astype(npdt) if np.issubdtype(npdt, np.integer) else want * 2
+            assert np.array_equal(got[:, :h], want2), (dt, h, "device, strided")
+            assert (got[:, h:] == 7).all() and int(cb[0]) == 7, "wrote outside the window"
+    finally:
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
 def test_spmv_group_through_the_c_abi(rng, dt):
     """pygim_spmv_run_group: `groups` right-hand sides of one column each -> out[nrows, groups]; one and three sparse
     parts (column blocks, merged or part by part), host and device vectors"""
