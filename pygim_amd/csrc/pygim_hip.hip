@@ -282,6 +282,21 @@ struct KernelTimer {
     }
 };
 
+// Does this block product take the panel sweep?  (16-byte pieces at any alignment and any width; narrow or ragged rows
+// whose tail piece would reach past the row stride gather from the padded slice-major copy, which is skipped when
+// that copy would be enormous.)
+template <typename T>
+bool want_panel(const Part &p, uint32_t w, int64_t ldx) {
+    if (p.d_items == nullptr || g_tune.panel_mode == 2 || p.nrows == 0 || w == 0) return false;
+    if (g_tune.panel_mode == 0 && !(p.npanels == 1 || (double)p.nnz / ((double)p.nrows * p.npanels) >= (double)g_tune.panel_min_seg))
+        return false;
+    constexpr uint32_t V = 16 / sizeof(T), F = V * 8;
+    const uint32_t nslices = (w + F - 1) / F;
+    const bool tail_inside = (int64_t)((w + V - 1) / V) * V <= ldx;
+    if (!tail_inside && (uint64_t)p.ncols * nslices * 128ull > (8ull << 30)) return false;
+    return true;
+}
+
 template <typename T, int VEC>
 int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate,
                    hipStream_t st) {
@@ -290,11 +305,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     const uint32_t lanes_needed = (w + VEC - 1) / VEC;
     // L2-blocked panel sweep or row-per-wave kernels?
     bool use_panel = false;
-    if constexpr (VEC * sizeof(T) == 16) {
-        use_panel = p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 32 && nrows > 0;
-        if (use_panel && g_tune.panel_mode == 0)
-            use_panel = p.npanels == 1 || (double)p.nnz / ((double)nrows * p.npanels) >= (double)g_tune.panel_min_seg;
-    }
+    if constexpr (VEC * sizeof(T) == 16) use_panel = want_panel<T>(p, w, ldx);
     // COO groups: the panel sweep (through the row pointers derived at create time) when it pays,
     // else the native equal-nnz kernel
     const bool coo_native = (g->format == PYGIM_COO) && p.rowind != nullptr && !use_panel && !g_tune.coo_via_rowptr && lanes_needed > 16;
@@ -351,8 +362,10 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st, !p.is_extra);
-            // (rows of one slice that are already contiguous lines need no copy)
-            if (g_tune.panel_pack && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128)) {
+            // (rows of one slice that are already contiguous lines need no copy -- as long as the 16-byte piece over
+            // a row's tail stays inside the row stride: gathered pieces must never reach past the end of X)
+            const bool tail_inside = (int64_t)((w + VEC - 1) / VEC) * VEC <= ldx;
+            if ((g_tune.panel_pack || !tail_inside) && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128 && tail_inside)) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
                 void *xs_use = nullptr;
                 if (p.is_extra && g->packed_buf && g->packed_src == (const void *)X && g->packed_ld == ldx &&
@@ -474,10 +487,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     // The panel sweep moves 16-byte pieces with byte-aligned accesses (kernels.hpp u32x4_b), so it takes rows of
     // ANY alignment (h = 41 floats, 100 int8 ...); only its long-row side kernels want aligned rows, so parts that
     // have such rows keep the alignment-matched kernels.
-    if (vb < 16 && g_tune.force_vec_bytes == 0 && p.d_items != nullptr && g_tune.panel_mode != 2 && (size_t)w * sizeof(T) >= 32 &&
-        p.lp_panel.n_tasks == 0 &&
-        (g_tune.panel_mode == 1 || p.npanels == 1 ||
-         (double)p.nnz / ((double)p.nrows * p.npanels) >= (double)g_tune.panel_min_seg))
+    if (vb < 16 && g_tune.force_vec_bytes == 0 && p.lp_panel.n_tasks == 0 && want_panel<T>(p, ww, ldx))
         vec = 16 / (int)sizeof(T);
 #define CASE(V)                                                               \
     if constexpr (V >= 1 && (size_t)V * sizeof(T) <= 16) {                    \
