@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature"])
+    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined"])
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
@@ -214,6 +214,62 @@ def main():
             return (f"sp_parts={world} as an nnz-balanced row split, {self.K} piece(s) per rank on their own streams, each "
                     f"all-gathered (RCCL) as soon as it is done")
 
+    class PipelinedRows:
+        """sp_parts = world as an nnz-balanced row split, one product per rank and step, and the all-gather (RCCL) of
+        step k overlapping the product of step k + 1: two gather buffers, the collective enqueued asynchronously right
+        after the product (RCCL's stream waits for the product, the compute stream does not wait for RCCL until the
+        buffer comes round again).  Every step's gathered C is complete before the closing fence (drain)."""
+
+        def __init__(self, K):
+            self.K = 1
+            self.bounds = [split[r:r + 2] for r in range(world)]
+            c0, c1 = split[rank], split[rank + 1]
+            lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
+            rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
+            col_c = col[lo:hi].contiguous()
+            self.keep = [rp_c, col_c]
+            self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None, [c1 - c0], [n],
+                                              [hi - lo], [1], [h], h)]
+            self.pad_rows = max(max(split[r + 1] - split[r] for r in range(world)), 1)
+            self.bufs = [torch.empty((world, self.pad_rows, h), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.pending = [None, None]
+            self.k = 0
+            self.last = 0
+            self.my_rows, self.my_nnz = c1 - c0, hi - lo
+
+        def step(self, exchange=True):
+            b = self.k & 1
+            self.k += 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()  # the compute stream waits for the gather that last used this buffer
+                self.pending[b] = None
+            g = self.bufs[b]
+            _lib.set_tunable("xs_reuse", 0)
+            _lib.spmm_run_group(self.handles[0], [x.data_ptr()], g[rank].data_ptr(), stream)
+            if exchange and world > 1:
+                self.pending[b] = dist.all_gather_into_tensor(g.view(-1), g[rank].reshape(-1), async_op=True)
+            self.last = b
+
+        def drain(self):
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+
+        def free(self):
+            self.drain()
+            for hd in self.handles:
+                _lib.group_free(hd)
+            self.handles = []
+
+        def full_c(self):
+            g = self.bufs[self.last]
+            return torch.cat([g[r, : split[r + 1] - split[r]] for r in range(world)])
+
+        def describe(self):
+            return (f"sp_parts={world} as an nnz-balanced row split, one product per rank; the all-gather (RCCL) of step k "
+                    f"overlaps the product of step k+1 (two gather buffers), all gathers complete inside the timed region")
+
     class FeaturePieces:
         """ds_parts = world: rank r owns the feature block X[:, r*h/world : (r+1)*h/world] and computes that
         block of C for ALL rows (A replicated), in K nnz-balanced row pieces on their own streams; each piece
@@ -280,7 +336,12 @@ def main():
             return (f"ds_parts={world} as a feature split (A replicated, {self.hw} features per rank), {self.K} row piece(s) "
                     f"per rank on their own streams, each all-gathered (RCCL) along the features and laid row-major")
 
+    live = []  # plans whose asynchronous exchanges must be complete at a fence
+
     def fence():
+        for pl in live:
+            if hasattr(pl, "drain"):
+                pl.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -290,8 +351,12 @@ def main():
     # through a max-reduce): row split (sp_parts) in 1 / 2 / 4 pieces, feature split (ds_parts) in 1 / 2
     feat_ok = h % world == 0 and (h // world) * 4 >= 32
     cands = []
+    if args.partition == "pipelined":
+        cands.append((PipelinedRows, 1))
     if args.partition in ("auto", "row"):
         cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if world == 1 else (1, 2, 4)))]
+        if world > 1 and args.chunks == 0:
+            cands.append((PipelinedRows, 1))
     if args.partition in ("auto", "feature") and feat_ok and (world > 1 or args.partition == "feature"):
         cands += [(FeaturePieces, k) for k in ((args.chunks,) if args.chunks > 0 else (1, 2))]
     assert cands, "no admissible partition"
@@ -301,11 +366,12 @@ def main():
         best = None
         for cls, kk in cands:
             pl = cls(kk)
+            live[:] = [pl]
             for _ in range(2):
                 pl.step()
             fence()
             t_c = time.perf_counter()
-            for _ in range(3):
+            for _ in range(4):
                 pl.step()
             fence()
             tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
@@ -319,6 +385,7 @@ def main():
                 pl.free()
             del pl
         plan = best[1]
+    live[:] = [plan]
     K, step = plan.K, plan.step
     handles = plan.handles
     my_rows, my_nnz = plan.my_rows, plan.my_nnz

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Reddit-shaped CSR h=256 with real-valued weights (a normalised adjacency) against unit weights."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from pygim_amd import _lib, synth
+dev = torch.device("cuda", 0)
+_lib.init_ranks(1)
+n, nnz, dmax = synth.SHAPES["reddit"]
+h = 256
+rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+for dt, code in ((torch.float32, _lib.FLT32), (torch.float64, _lib.DBL64), (torch.int32, _lib.INT32)):
+    x = synth.features(n, h, dt, seed=0, device=dev)
+    out = torch.empty((n, h), dtype=dt, device=dev)
+    for weighted in (False, True):
+        vals = None
+        if weighted:
+            vals = (torch.rand(nnz, device=dev) * 2 - 1).to(dt) if dt.is_floating_point else torch.randint(-3, 4, (nnz,), device=dev, dtype=dt)
+        hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None if vals is None else [vals.data_ptr()], [n], [n], [nnz], [1], [h], h)
+        for _ in range(2): _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); ts = []
+        for _ in range(5):
+            a.record(); _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st); b.record(); b.synchronize(); ts.append(a.elapsed_time(b))
+        print(f"{str(dt):14s} weighted={weighted}: {min(ts):7.3f} ms", flush=True)
+        _lib.group_free(hd)
