@@ -81,3 +81,20 @@ def test_inference_driver_under_the_harness_command_line():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     res = _parse_like_the_harness(r.stdout)
     assert res["repeat"] == 2 and res["infer_time(ms)"] > 0
+
+
+@pytest.mark.parametrize("partition", ["auto", "pipelined", "row", "feature"])
+def test_bench_two_ranks_logic_check(partition):
+    """the N > 1 paths of bench.py with 2 ranks over gloo on this one GPU (a logic check, not a measurement): every
+    partition assembles the exact C on every rank (column-count checksum) and prints one JSON line from rank 0"""
+    env = dict(os.environ, PYGIM_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1",
+           "--master-port=29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "products-mini",
+           "--partition", partition]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["check"].startswith("column-count checksum")
+    assert d["config"]["ms_per_step_products_only"] > 0
