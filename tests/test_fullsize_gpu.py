@@ -105,3 +105,39 @@ def test_products_coo_i32_h256():
             assert np.array_equal(c[r0:r1].cpu().numpy(), ref)
     finally:
         _lib.group_free(hd)
+
+
+@pytest.mark.parametrize("name", ["INT8", "INT16", "INT64", "DBL64"])
+def test_reddit_csr_other_types_h256(name):
+    """the benchmark graph in the other element types: column-count checksum (modulo 2^bits for the integers: int8 /
+    int16 sums of ~500 terms wrap, as val_dt arithmetic does), sampled rows against the oracle, determinism"""
+    dev = torch.device("cuda", 0)
+    tdt = {"INT8": torch.int8, "INT16": torch.int16, "INT64": torch.int64, "DBL64": torch.float64}[name]
+    code = {"INT8": _lib.INT8, "INT16": _lib.INT16, "INT64": _lib.INT64, "DBL64": _lib.DBL64}[name]
+    n, nnz, d_max = synth.SHAPES["reddit"]
+    h = 256
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    x = synth.features(n, h, tdt, seed=3, device=dev)
+    hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+    try:
+        c = run(hd, x, n, h)
+        assert torch.equal(run(hd, x, n, h), c)
+        colcount = torch.bincount(col.long(), minlength=n)
+        if tdt.is_floating_point:
+            assert torch.equal(c.sum(0), colcount.double() @ x)  # small integers: exact
+        else:
+            bits = torch.iinfo(tdt).bits
+            # every row sum wraps modulo 2^bits; so does their sum: compare modulo 2^bits, computed exactly in float64
+            # chunks (|colcount . x| < 2^53)
+            want = (colcount.double() @ x.double())
+            got = c.to(torch.int64).sum(0)
+            if bits < 64:
+                mod = float(2 ** bits)
+                assert torch.equal(torch.remainder(got.double() - want, mod), torch.zeros_like(want))
+            else:
+                assert torch.equal(got.double(), want)
+        deg = (rowptr[1:] - rowptr[:-1]).long()
+        longest = int(torch.argmax(deg))
+        sample_rows_vs_oracle(rowptr, col, None, x, c, [(0, 200), (n - 100, n), (longest, longest + 1)])
+    finally:
+        _lib.group_free(hd)
