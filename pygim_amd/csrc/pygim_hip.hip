@@ -69,6 +69,7 @@ struct Tunables {
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
+    int64_t vec_kernel = 1;             // 1 = rows of X of at most 4 elements (SpMV) take the CSR-vector kernel
     int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
@@ -479,11 +480,33 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
 template <typename T>
 int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
                  hipStream_t st) {
-    const int vb = pick_vec_bytes(sizeof(T), X, ldx, C, ldc);
-    int vec = vb / (int)sizeof(T);
     const T *x = (const T *)X;
     T *c = (T *)C;
     const uint32_t ww = (uint32_t)w;
+    // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
+    if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
+        const double avg = (double)p.nnz / (double)p.nrows;
+        const int log_g = avg >= 96 ? 6 : avg >= 48 ? 5 : avg >= 24 ? 4 : avg >= 10 ? 3 : 2;
+        const uint64_t waves = ((uint64_t)p.nrows + (64u >> log_g) - 1) / (64u >> log_g);
+        KernelTimer kt(g, st, !p.is_extra);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+#define PYGIM_VEC(W)                                                                                                     \
+    if (ww == W) {                                                                                                       \
+        if (p.vals)                                                                                                      \
+            hipLaunchKernelGGL((k_csr_vec<T, W, true>), grid, dim3(256), 0, st, p.rowptr, p.colind, (const T *)p.vals, x, ldx, c, \
+                               ldc, (uint32_t)p.nrows, accumulate ? 1 : 0, log_g);                                      \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_csr_vec<T, W, false>), grid, dim3(256), 0, st, p.rowptr, p.colind, (const T *)nullptr, x, ldx, \
+                               c, ldc, (uint32_t)p.nrows, accumulate ? 1 : 0, log_g);                                   \
+    }
+        PYGIM_VEC(1) PYGIM_VEC(2) PYGIM_VEC(3) PYGIM_VEC(4)
+#undef PYGIM_VEC
+        kt.stop();
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    const int vb = pick_vec_bytes(sizeof(T), X, ldx, C, ldc);
+    int vec = vb / (int)sizeof(T);
     // The panel sweep moves 16-byte pieces with byte-aligned accesses (kernels.hpp u32x4_b), so it takes rows of
     // ANY alignment (h = 41 floats, 100 int8 ...); only its long-row side kernels want aligned rows, so parts that
     // have such rows keep the alignment-matched kernels.
@@ -1207,6 +1230,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
     else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
+    else if (n == "vec_kernel") slot = &g_tune.vec_kernel;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

@@ -271,6 +271,48 @@ def test_panel_sweep_takes_rows_of_any_alignment(rng, dt):
 
 
 @pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_csr_vector_kernel_for_rows_of_one_to_four_elements(rng, dt):
+    """rows of X of 1..4 elements (the SpMV end, k_csr_vec: lanes over a row's entries, fixed butterfly): every lane-group
+    size (picked from the mean degree), weights, empty and very long rows, strided X / C with accumulation, against the
+    sweep and the oracle (driver features: float sums exact in any order)"""
+    npdt = NP_DTYPES[dt]
+    tdt = torch.from_numpy(np.zeros(1, dtype=npdt)).dtype
+    for deg in (3, 12, 30, 60, 150):
+        nrows, ncols = 300, 400
+        rowptr, col = random_csr(rng, nrows, ncols, deg, empty_frac=0.1, long_rows=[(6, 5000)])
+        vals = rng.integers(-3, 4, size=len(col)).astype(npdt)
+        for w in (1, 2, 3, 4):
+            x = driver_features(rng, ncols, w, npdt)
+            for v in (None, vals):
+                ref = oracle.spmm_csr(rowptr, col, v, x)
+                for vk in (1, 0):
+                    old = _lib.set_tunable("vec_kernel", vk)
+                    try:
+                        out, _ = run_group_host("CSR", [rowptr], [col], None if v is None else [v], [nrows], [ncols], [x], w)
+                    finally:
+                        _lib.set_tunable("vec_kernel", old)
+                    assert np.array_equal(out, ref), (dt, deg, w, v is not None, vk)
+            # strided device operands, C += A.X on top of a first product
+            ldx, ldc = w + 2, w + 1
+            xb = torch.zeros((ncols, ldx), dtype=tdt, device="cuda")
+            xb[:, :w] = torch.from_numpy(x).cuda()
+            cb = torch.full((nrows, ldc), 5, dtype=tdt, device="cuda")
+            hd = _lib.group_create(_lib.CSR, CODE_OF_NP[np.dtype(npdt)], [_ptr(rowptr)], [_ptr(col)], None, [nrows], [ncols], [len(col)],
+                                   [1], [w], w)
+            try:
+                st = torch.cuda.current_stream().cuda_stream
+                _lib.block_run(hd, 0, xb.data_ptr(), ldx, cb.data_ptr(), ldc, w, False, st)
+                _lib.block_run(hd, 0, xb.data_ptr(), ldx, cb.data_ptr(), ldc, w, True, st)
+                torch.cuda.synchronize()
+            finally:
+                _lib.group_free(hd)
+            one = oracle.spmm_csr(rowptr, col, None, x)
+            two = (one.astype(np.int64) * 2).astype(npdt) if np.issubdtype(npdt, np.integer) else one * 2
+            got = cb.cpu().numpy()
+            assert np.array_equal(got[:, :w], two) and (got[:, w:] == 5).all(), (dt, deg, w, "strided")
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
 def test_spmv_group_through_the_c_abi(rng, dt):
     """pygim_spmv_run_group: `groups` right-hand sides of one column each -> out[nrows, groups]; one and three sparse
     parts (column blocks, merged or part by part), host and device vectors"""
