@@ -70,6 +70,24 @@ def cpu_baseline(rowptr, col, x, args):
     oracle.spmm_csr_rowpar(rp, cl, None, xh, nthreads=threads, out=out)
     dt = time.perf_counter() - t0
     gflops = 2.0 * nnz * xh.shape[1] / dt / 1e9
+    # an independent library beside the port (SURVEY.md 8d ii): torch's CSR x dense kernel (MKL) on the same sample
+    lib = None
+    try:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(cl.astype(np.int64)),
+                                        torch.ones(nnz, dtype=torch.float32), size=(nrows, xh.shape[0]))
+        xt = torch.from_numpy(xh)
+        y = a @ xt  # warm
+        t1 = time.perf_counter()
+        y = a @ xt
+        dl = time.perf_counter() - t1
+        lib = {"kind": "torch.sparse_csr @ dense (MKL)", "value": round(2.0 * nnz * xh.shape[1] / dl / 1e9, 3), "unit": "GFLOP/s",
+               "threads": torch.get_num_threads(), "seconds": round(dl, 3), "equal_to_port": bool(np.array_equal(y.numpy(), out))}
+    except Exception as e:  # not every build has the CSR kernels
+        lib = {"kind": "torch.sparse_csr @ dense (MKL)", "error": str(e)[:120]}
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -79,7 +97,7 @@ def cpu_baseline(rowptr, col, x, args):
     except OSError:
         pass
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port", "cpu_model": model,
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"),
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"), "library": lib,
             "sample": f"rows [0,{nrows}) of the same graph ({nnz} nnz, h={xh.shape[1]}), "
                       f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
 
