@@ -11,6 +11,10 @@ from pygim_amd import _lib
 from test_parity_gpu import run_group_host
 
 pytestmark = pytest.mark.gpu
+# PYGIM_STRESS_SEEDS=N widens the randomised sweeps (default 24 / 48 cases; a one-off run with 1000 is cheap on the GPU)
+import os as _os
+
+_EXTRA = int(_os.environ.get("PYGIM_STRESS_SEEDS", "0"))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -36,7 +40,7 @@ def skewed_csr(rng, nrows, ncols, mean_deg, sigma, clustered):
     return rowptr.astype(np.int32), col.astype(np.int32)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(max(24, _EXTRA)))
 def test_random_configurations(seed):
     rng = np.random.default_rng(1000 + seed)
     dt = ALL_DTYPES[seed % 6]
@@ -85,7 +89,7 @@ def _col_split(rowptr, col, nrows, ncols, parts):
     return out
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(max(48, _EXTRA)))
 def test_random_groups(seed):
     """whole groups: sp_parts column blocks (summed) x ds_parts feature blocks (concatenated), default and grande call
     shapes, host operands, against the oracle's group driver (ops.hpp:42-62,97-118 restated)"""
