@@ -3,7 +3,7 @@
 a 90 000-entry row (segment kernels), all element types, weights, odd widths -- C-ABI against the CPU oracle (test tooling)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # run as: python tests/check_midsize.py
 import numpy as np, torch
 import oracle
 from pygim_amd import _lib
