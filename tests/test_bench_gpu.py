@@ -7,6 +7,16 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -89,7 +99,7 @@ def test_bench_two_ranks_logic_check(partition):
     partition assembles the exact C on every rank (column-count checksum) and prints one JSON line from rank 0"""
     env = dict(os.environ, PYGIM_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1",
-           "--master-port=29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "products-mini",
+           f"--master-port={_free_port()}", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "products-mini",
            "--partition", partition]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])

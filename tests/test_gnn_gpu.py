@@ -15,6 +15,16 @@ from pygim_amd.sparse_tensor import SparseTensorShim
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 class DenseAdj:
     """reference aggregator: same quantiser, exact integer product with a dense adjacency"""
 
@@ -130,7 +140,7 @@ def _run_inference(world, extra, env_extra=None):
         cmd = [sys.executable, os.path.join(root, "inference.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr=127.0.0.1",
-               "--master-port=29731", os.path.join(root, "inference.py")] + args
+               f"--master-port={_free_port()}", os.path.join(root, "inference.py")] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     sums = [float(ln.split(":")[1]) for ln in r.stdout.splitlines() if ln.startswith("[DATA]logits_checksum")]
@@ -208,7 +218,7 @@ def test_multi_gpu_layer_with_hip_engines_over_gloo(world):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr=127.0.0.1",
-           "--master-port=29751", os.path.join(root, "tests", "dist_driver.py")]
+           f"--master-port={_free_port()}", os.path.join(root, "tests", "dist_driver.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert all(f"OK rank {k}" in r.stdout for k in range(world)), r.stdout[-2000:]
