@@ -7,10 +7,14 @@ One "step" = one pass of the hot path: C = A . X through the C ABI
 (pygim_spmm_run_group) with A, X and C resident in HBM.
 
 N = 1 : whole graph on the one GPU.
-N > 1 : strong scaling of the SAME graph: A is row-split into N nnz-balanced blocks
-        (the reference's partition_by_nnz_csr walk), X is replicated, rank r computes
-        C[rows_r, :] and the row blocks are all-gathered over RCCL so every rank ends
-        the step holding the full C (what the next GCN layer needs).
+N > 1 : strong scaling of the SAME graph with the full C on every rank at the end of every
+        step (what the next GCN layer needs).  Candidates, timed on the node before the
+        warm-up (--partition fixes one): row split (sp_parts: nnz-balanced row blocks, the
+        reference's partition_by_nnz_csr walk, X replicated) in 1 / 2 / 4 pieces with the
+        all-gather of each piece behind the products of the others; the same with the
+        all-gather of step k behind the product of step k + 1 ("pipelined"); feature split
+        (ds_parts: A replicated, h / N features per rank).  All exchanges are RCCL
+        all-gathers and complete inside the timed region.
 
 Launch: python bench.py --gpus 1 --steps 20 --warmup 5
         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
