@@ -1,0 +1,261 @@
+// LDS-staged SpMM prototype (round 2): a workgroup owns R = NWC*8*K rows of one
+// 128-byte feature slice with the accumulators in VGPRs and streams the slice-major X through LDS
+// in double-buffered column chunks; every stored entry becomes one ds_read_b128 per lane instead of
+// one 128-byte L1 request.  Experiment only -- driven by scripts/lds_proto/run_proto.py.
+//
+// Schedule (built on the device by run_proto.py): rows sorted by length, dealt in octets to the
+// consumer waves; for (tile, chunk, wave, j) a segment of `nblk` blocks of 2 steps; one step holds
+// the 8 lane groups' LDS line ids (16 bit; the line KC is all zeros = padding).  Rows keep their
+// stored order (one lane group sums a row sequentially), so floats match the CPU loop bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+extern __shared__ char lds[];
+
+// consumer part of one workgroup: K accumulators per lane group
+template <int K, int NWC>
+__device__ __forceinline__ void consume_tile(uint32_t tile, uint32_t slice, uint32_t wave, int grp, int li,
+                                             const uint32_t *__restrict__ blk_off, const uint8_t *__restrict__ seg_n,
+                                             const uint32_t *__restrict__ rowmap, uint32_t rowmap_base,
+                                             float *__restrict__ C, int64_t ldc, uint32_t nchunks, uint32_t xbuf_bytes,
+                                             uint32_t ids_base, uint32_t idb) {
+    f32x4 acc[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) acc[j] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const uint32_t wg = tile * nchunks + c;
+        const uint32_t wseg = wg * NWC + wave;  // uniform
+        const uint32_t boff = blk_off[wseg] - blk_off[wg * NWC];  // block offset inside this chunk's stream
+        const u32x4 nn = *reinterpret_cast<const u32x4 *>(seg_n + (size_t)wseg * 16);
+        uint32_t ia = ids_base + (c & 1) * idb + (boff * 8 + grp) * 4;
+        const uint32_t lbase = (c & 1) * xbuf_bytes + li * 16;
+        uint32_t q0 = *reinterpret_cast<const uint32_t *>(lds + ia);
+        uint32_t q1 = *reinterpret_cast<const uint32_t *>(lds + ia + 32);
+        ia += 64;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint32_t nj = (nn[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            uint32_t t = 0;
+#pragma nounroll
+            for (; t + 2 <= nj; t += 2) {
+                const uint32_t c0 = q0, c1 = q1;
+                q0 = *reinterpret_cast<const uint32_t *>(lds + ia);
+                q1 = *reinterpret_cast<const uint32_t *>(lds + ia + 32);
+                ia += 64;
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(lds + ((c0 & 0x3ffu) << 7) + lbase);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(lds + ((c0 >> 16) << 7) + lbase);
+                const f32x4 x2 = *reinterpret_cast<const f32x4 *>(lds + ((c1 & 0x3ffu) << 7) + lbase);
+                const f32x4 x3 = *reinterpret_cast<const f32x4 *>(lds + ((c1 >> 16) << 7) + lbase);
+                acc[j] += x0;
+                acc[j] += x1;
+                acc[j] += x2;
+                acc[j] += x3;
+            }
+            if (t < nj) {
+                const uint32_t cur = q0;
+                q0 = q1;
+                q1 = *reinterpret_cast<const uint32_t *>(lds + ia);
+                ia += 32;
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(lds + ((cur & 0x3ffu) << 7) + lbase);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(lds + ((cur >> 16) << 7) + lbase);
+                acc[j] += x0;
+                acc[j] += x1;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint32_t row = rowmap[rowmap_base + ((size_t)wave * K + j) * 8 + grp];
+        if (row != 0xffffffffu)
+            *reinterpret_cast<f32x4 *>(C + (int64_t)row * ldc + slice * 32 + li * 4) = acc[j];
+    }
+}
+
+// Flat variant: one software-pipelined loop over all blocks of a (wave, chunk); the accumulator of a
+// block is named by 4 bits carried in the block's first id (wave-uniform), selected with a scalar switch,
+// so that LDS reads run ahead across segment boundaries.
+template <int K>
+__device__ __forceinline__ void add_sel(f32x4 (&acc)[K], uint32_t j, const f32x4 &x0, const f32x4 &x1) {
+#define CASEJ(n)                      \
+    case n:                           \
+        if constexpr (K > n) {        \
+            acc[n] += x0;             \
+            acc[n] += x1;             \
+        }                             \
+        break;
+    switch (j) {
+        CASEJ(0) CASEJ(1) CASEJ(2) CASEJ(3) CASEJ(4) CASEJ(5) CASEJ(6) CASEJ(7)
+        CASEJ(8) CASEJ(9) CASEJ(10) CASEJ(11) CASEJ(12) CASEJ(13) CASEJ(14) CASEJ(15)
+    }
+#undef CASEJ
+}
+
+template <int K, int NWC>
+__device__ __forceinline__ void consume_tile_flat(uint32_t tile, uint32_t slice, uint32_t wave, int grp, int li,
+                                                  const uint32_t *__restrict__ blk_off,
+                                                  const uint32_t *__restrict__ rowmap, uint32_t rowmap_base,
+                                                  float *__restrict__ C, int64_t ldc, uint32_t nchunks,
+                                                  uint32_t xbuf_bytes, uint32_t ids_base, uint32_t idb) {
+    f32x4 acc[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) acc[j] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const uint32_t wg = tile * nchunks + c;
+        const uint32_t wseg = wg * NWC + wave;  // uniform
+        const uint32_t b0 = blk_off[wseg];
+        const uint32_t nb = blk_off[wseg + 1] - b0;
+        const uint32_t boff = b0 - blk_off[wg * NWC];
+        uint32_t ia = ids_base + (c & 1) * idb + (boff * 8 + grp) * 4;
+        const uint32_t lbase = (c & 1) * xbuf_bytes + li * 16;
+        auto ldid = [&](uint32_t off) { return *reinterpret_cast<const uint32_t *>(lds + ia + off); };
+        auto rd0 = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id & 0x3ffu) << 7) + lbase); };
+        auto rd1 = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id >> 16) << 7) + lbase); };
+        uint32_t cur0 = ldid(0), cur1 = ldid(32);
+        f32x4 a0 = rd0(cur0), a1 = rd1(cur0);
+        for (uint32_t b = 0; b < nb; b += 2) {
+            const uint32_t nx0 = ldid(64), nx1 = ldid(96);
+            ia += 64;
+            const f32x4 b0x = rd0(cur1), b1x = rd1(cur1);
+            add_sel<K>(acc, (__builtin_amdgcn_readfirstlane(cur0) >> 12) & 0xfu, a0, a1);
+            a0 = rd0(nx0);
+            a1 = rd1(nx0);
+            if (b + 1 < nb) add_sel<K>(acc, (__builtin_amdgcn_readfirstlane(cur1) >> 12) & 0xfu, b0x, b1x);
+            cur0 = nx0;
+            cur1 = nx1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint32_t row = rowmap[rowmap_base + ((size_t)wave * K + j) * 8 + grp];
+        if (row != 0xffffffffu)
+            *reinterpret_cast<f32x4 *>(C + (int64_t)row * ldc + slice * 32 + li * 4) = acc[j];
+    }
+}
+
+// tileinfo[t] = {K, rowmap offset}
+template <int NWC, int NWL, int FLAT>
+__global__ __launch_bounds__((NWC + NWL) * 64) void k_lds(const char *__restrict__ Xs, int64_t slice_bytes,
+                                                         const uint32_t *__restrict__ blk_off,
+                                                         const uint8_t *__restrict__ seg_n,
+                                                         const char *__restrict__ stream,
+                                                         const uint32_t *__restrict__ rowmap,
+                                                         const uint32_t *__restrict__ tileinfo, float *__restrict__ C,
+                                                         int64_t ldc, uint32_t nchunks, uint32_t KC, uint32_t idb,
+                                                         uint32_t tile0, uint32_t nslices) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, li = lane & 7;
+    const uint32_t slice = blockIdx.x % nslices;
+    const uint32_t tile = tile0 + blockIdx.x / nslices;
+    const uint32_t xbuf_bytes = (KC + 1) * 128;
+    const uint32_t ids_base = 2 * xbuf_bytes;
+    if (threadIdx.x < 16) {  // the zero lines
+        const uint32_t b = threadIdx.x >> 3;
+        *reinterpret_cast<f32x4 *>(lds + b * xbuf_bytes + KC * 128 + (threadIdx.x & 7) * 16) = f32x4{0, 0, 0, 0};
+    }
+    if (wave >= NWC) {
+        const uint32_t wl = wave - NWC;
+        const char *xsl = Xs + (int64_t)slice * slice_bytes;
+        const uint32_t chunk_bytes = KC * 128;
+        const uint32_t per = chunk_bytes / NWL;  // multiple of 1024
+        auto fill = [&](uint32_t c) {
+            const char *src = xsl + (int64_t)c * chunk_bytes + wl * per + lane * 16;
+            char *dst = lds + (c & 1) * xbuf_bytes + wl * per;
+            for (uint32_t o = 0; o < per; o += 1024)
+                __builtin_amdgcn_global_load_lds((const GLB_AS void *)(src + o), (LDS_AS void *)(dst + o), 16, 0, 0);
+            // the chunk's id stream (all consumer waves, contiguous), 1 KiB pieces dealt to the loader waves
+            const uint32_t wg = tile * nchunks + c;
+            const uint32_t b0 = blk_off[wg * NWC], b1 = blk_off[(wg + 1) * NWC];
+            const uint32_t bytes = (b1 - b0) * 32 + 64;  // + the consumers' look-ahead
+            const char *isrc = stream + (size_t)b0 * 32 + lane * 16;
+            char *idst = lds + ids_base + (c & 1) * idb;
+            for (uint32_t o = wl * 1024; o < bytes; o += NWL * 1024)
+                __builtin_amdgcn_global_load_lds((const GLB_AS void *)(isrc + o), (LDS_AS void *)(idst + o), 16, 0, 0);
+        };
+        fill(0);
+        __syncthreads();
+        for (uint32_t c = 0; c < nchunks; c++) {
+            if (c + 1 < nchunks) fill(c + 1);
+            __syncthreads();
+        }
+        return;
+    }
+    const uint32_t K = tileinfo[2 * tile], rmb = tileinfo[2 * tile + 1];
+    if constexpr (FLAT) {
+#define ARGF tile, slice, wave, grp, li, blk_off, rowmap, rmb, C, ldc, nchunks, xbuf_bytes, ids_base, idb
+        switch (K) {
+        case 1: consume_tile_flat<1, NWC>(ARGF); break;
+        case 2: consume_tile_flat<2, NWC>(ARGF); break;
+        case 4: consume_tile_flat<4, NWC>(ARGF); break;
+        case 8: consume_tile_flat<8, NWC>(ARGF); break;
+        default: consume_tile_flat<16, NWC>(ARGF); break;
+        }
+#undef ARGF
+        return;
+    }
+#define ARGS tile, slice, wave, grp, li, blk_off, seg_n, rowmap, rmb, C, ldc, nchunks, xbuf_bytes, ids_base, idb
+    switch (K) {
+    case 1: consume_tile<1, NWC>(ARGS); break;
+    case 2: consume_tile<2, NWC>(ARGS); break;
+    case 4: consume_tile<4, NWC>(ARGS); break;
+    case 8: consume_tile<8, NWC>(ARGS); break;
+    default: consume_tile<16, NWC>(ARGS); break;
+    }
+#undef ARGS
+}
+
+template <int NWC, int NWL, int FLAT>
+static float launch(const void *Xs, int64_t slice_bytes, const void *blk_off, const void *seg_n, const void *stream,
+                    const void *rowmap, const void *tileinfo, void *C, int64_t ldc, uint32_t nchunks, uint32_t KC,
+                    uint32_t idb, uint32_t tile0, uint32_t ntiles, uint32_t nslices, int iters) {
+    auto kern = k_lds<NWC, NWL, FLAT>;
+    const size_t shmem = 2 * (size_t)(KC + 1) * 128 + 2 * (size_t)idb;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) { printf("attr: %s\n", hipGetErrorString(e)); return -1.f; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    dim3 grid(ntiles * nslices), block((NWC + NWL) * 64);
+    auto go = [&]() {
+        hipLaunchKernelGGL(kern, grid, block, shmem, 0, (const char *)Xs, slice_bytes, (const uint32_t *)blk_off,
+                           (const uint8_t *)seg_n, (const char *)stream, (const uint32_t *)rowmap,
+                           (const uint32_t *)tileinfo, (float *)C, ldc, nchunks, KC, idb, tile0, nslices);
+    };
+    go();
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("run: %s\n", hipGetErrorString(e)); return -1.f; }
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; i++) go();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms / iters;
+}
+
+extern "C" float proto_run(int FLAT, int NWC, int NWL, const void *Xs, int64_t slice_bytes, const void *blk_off,
+                           const void *seg_n, const void *stream, const void *rowmap, const void *tileinfo, void *C,
+                           int64_t ldc, uint32_t nchunks, uint32_t KC, uint32_t idb, uint32_t tile0, uint32_t ntiles,
+                           uint32_t nslices, int iters) {
+#define CASE(c, l)                                                                                               \
+    if (NWC == c && NWL == l)                                                                                    \
+        return FLAT ? launch<c, l, 1>(Xs, slice_bytes, blk_off, seg_n, stream, rowmap, tileinfo, C, ldc, nchunks, KC, idb, tile0, ntiles, nslices, iters) : launch<c, l, 0>(Xs, slice_bytes, blk_off, seg_n, stream, rowmap, tileinfo, C, ldc, nchunks, KC, idb, \
+                            tile0, ntiles, nslices, iters);
+    CASE(14, 2) CASE(15, 1) CASE(12, 4)
+#undef CASE
+    printf("no such variant\n");
+    return -2.f;
+}
