@@ -137,11 +137,16 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
-    if world > 1:
+    # PYGIM_FORCE_COLLECTIVES=1 under torch.distributed.run with ONE rank: the process group is created and every
+    # collective of the N > 1 path really executes (RCCL at world size 1) -- the first-run check of that path on one GPU
+    force = os.environ.get("PYGIM_FORCE_COLLECTIVES", "0") == "1" and "MASTER_ADDR" in os.environ
+    multi = world > 1 or force
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    rccl_world = dist.get_world_size() if multi else 0
 
     n, nnz, d_max = synth.SHAPES[args.shape]
     h = args.hidden
@@ -151,7 +156,6 @@ def main():
     torch.cuda.synchronize()
 
     _lib.init_ranks(world)
-    _lib.set_tunable("kernel_events", 1)
     rowptr_cpu = rowptr.cpu()
     split = nnz_balanced_row_split(rowptr_cpu, world)
     main_stream = torch.cuda.current_stream()
@@ -187,28 +191,25 @@ def main():
                 self.outs.append(g[rank])
                 self.my_rows += c1 - c0
                 self.my_nnz += hi - lo
-            self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if world > 1 else []
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)] if multi else []
 
         def step(self, exchange=True):
             K, handles, outs, gathers, side = self.K, self.handles, self.outs, self.gathers, self.side
-            if world == 1:
+            if not multi:
                 for c in range(K):
-                    _lib.set_tunable("xs_reuse", 1 if c > 0 else 0)
-                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream)
+                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), stream, x_unchanged=c > 0)
                 return
             pending = []
-            _lib.set_tunable("xs_reuse", 0)
             _lib.spmm_run_group(handles[0], [x.data_ptr()], outs[0].data_ptr(), stream)
             ready = torch.cuda.Event()
             ready.record(main_stream)
             if exchange:
                 pending.append(dist.all_gather_into_tensor(gathers[0].view(-1), outs[0].reshape(-1), async_op=True))
-            _lib.set_tunable("xs_reuse", 1)
-            for c in range(1, K):
+            for c in range(1, K):  # the same X: piece 0's slice-major copy is shared (x_unchanged), ordered by `ready`
                 s_c = side[c - 1]
                 s_c.wait_event(ready)
                 with torch.cuda.stream(s_c):
-                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s_c.cuda_stream)
+                    _lib.spmm_run_group(handles[c], [x.data_ptr()], outs[c].data_ptr(), s_c.cuda_stream, x_unchanged=True)
                     if exchange:
                         pending.append(dist.all_gather_into_tensor(gathers[c].view(-1), outs[c].reshape(-1), async_op=True))
             for c, wk in enumerate(pending):
@@ -231,7 +232,7 @@ def main():
                               for r in range(world) for c in range(self.K)])
 
         def describe(self):
-            if world == 1:
+            if not multi:
                 return "single GPU" if self.K == 1 else f"single GPU, {self.K} row pieces"
             return (f"sp_parts={world} as an nnz-balanced row split, {self.K} piece(s) per rank on their own streams, each "
                     f"all-gathered (RCCL) as soon as it is done")
@@ -266,9 +267,8 @@ def main():
                 self.pending[b].wait()  # the compute stream waits for the gather that last used this buffer
                 self.pending[b] = None
             g = self.bufs[b]
-            _lib.set_tunable("xs_reuse", 0)
             _lib.spmm_run_group(self.handles[0], [x.data_ptr()], g[rank].data_ptr(), stream)
-            if exchange and world > 1:
+            if exchange and multi:
                 self.pending[b] = dist.all_gather_into_tensor(g.view(-1), g[rank].reshape(-1), async_op=True)
             self.last = b
 
@@ -316,33 +316,31 @@ def main():
                 self.gathers.append(torch.empty((world, max(c1 - c0, 1), self.hw), dtype=torch.float32, device=dev))
             self.side = [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
 
-        def _piece(self, c, s, exchange=True):
+        def _piece(self, c, s, exchange=True, x_unchanged=False):
             c0, c1 = self.b[c], self.b[c + 1]
             g = self.gathers[c]
             mine = g[rank]
             # product on the strided feature window of X (row stride h): C_block[rows_c, hw]
             _lib.block_run(self.handles[c], 0, x.data_ptr() + 4 * self.f0, h, mine.data_ptr(), self.hw, self.hw, False,
-                           s.cuda_stream)
+                           s.cuda_stream, x_unchanged=x_unchanged)
             if not exchange:
                 return
-            if world > 1:
+            if multi:
                 wk = dist.all_gather_into_tensor(g.view(-1), mine.reshape(-1), async_op=True)
                 wk.wait()
             if c1 > c0:
                 self.C[c0:c1].view(c1 - c0, world, self.hw).copy_(g[:, : c1 - c0].permute(1, 0, 2))
 
         def step(self, exchange=True):
-            _lib.set_tunable("xs_reuse", 0)
             self._piece(0, main_stream, exchange)
             if self.K > 1:
                 ready = torch.cuda.Event()
                 ready.record(main_stream)
-                _lib.set_tunable("xs_reuse", 1)  # same feature window of the same X within this step
-                for c in range(1, self.K):
+                for c in range(1, self.K):  # same feature window of the same X within this step
                     s_c = self.side[c - 1]
                     s_c.wait_event(ready)
                     with torch.cuda.stream(s_c):
-                        self._piece(c, s_c, exchange)
+                        self._piece(c, s_c, exchange, x_unchanged=True)
                 for s_c in self.side:
                     main_stream.wait_stream(s_c)
 
@@ -364,7 +362,7 @@ def main():
         for pl in live:
             if hasattr(pl, "drain"):
                 pl.drain()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -372,16 +370,32 @@ def main():
     # on N > 1, whichever candidate is fastest on THIS node (measured before the warm-up; all ranks agree
     # through a max-reduce): row split (sp_parts) in 1 / 2 / 4 pieces, feature split (ds_parts) in 1 / 2
     feat_ok = h % world == 0 and (h // world) * 4 >= 32
+    from pygim_amd import autotune
+
+    prior, table = autotune.choose(n, n, nnz, h, 4, max(world, 1))
     cands = []
     if args.partition == "pipelined":
         cands.append((PipelinedRows, 1))
-    if args.partition in ("auto", "row"):
-        cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if world == 1 else (1, 2, 4)))]
-        if world > 1 and args.chunks == 0:
+    if args.partition == "row":
+        cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if not multi else (1, 2, 4)))]
+        if multi and args.chunks == 0:
             cands.append((PipelinedRows, 1))
-    if args.partition in ("auto", "feature") and feat_ok and (world > 1 or args.partition == "feature"):
+    if args.partition == "feature" and feat_ok:
         cands += [(FeaturePieces, k) for k in ((args.chunks,) if args.chunks > 0 else (1, 2))]
+    if args.partition == "auto":
+        if not multi:
+            cands.append((Pieces, max(args.chunks, 1)))
+        else:
+            # the chooser's model (pygim_amd/autotune.py, validated against measured per-rank shares in
+            # tests/test_autotune_gpu.py) ranks the two families; the two best arrangements of the preferred family and the
+            # best of the other are timed on the node (3 candidates instead of 6)
+            kk = (args.chunks,) if args.chunks > 0 else (1,)
+            row_first = prior.feat_parts == 1 or not feat_ok or world == 1
+            fam_row = [(PipelinedRows, 1), (Pieces, kk[0])]
+            fam_feat = [(FeaturePieces, kk[0])] if feat_ok and world > 1 else []
+            cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + [(FeaturePieces, 2)] + fam_row[:1])
     assert cands, "no admissible partition"
+    timed = {}
     if len(cands) == 1:
         plan = cands[0][0](cands[0][1])
     else:
@@ -397,8 +411,9 @@ def main():
                 pl.step()
             fence()
             tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
-            if world > 1:
+            if multi:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            timed[f"{cls.__name__}:{kk}"] = round(float(tt.item()) / 4 * 1e3, 4)
             if best is None or float(tt.item()) < best[0]:
                 if best is not None:
                     best[1].free()
@@ -410,6 +425,8 @@ def main():
     live[:] = [plan]
     K, step = plan.K, plan.step
     handles = plan.handles
+    for hd in handles:
+        _lib.group_kernel_events(hd, True)  # HIP events around the dominant kernel of every product, on its launch stream
     my_rows, my_nnz = plan.my_rows, plan.my_nnz
     my_h = getattr(plan, "hw", h)
 
@@ -418,24 +435,29 @@ def main():
     fence()
     for hd in handles:
         _lib.group_kernel_ms(hd, reset=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record(main_stream)
         step()
+    marks[args.steps].record(main_stream)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else 0.0
     k_ms_sum, k_count = 0.0, 0
     for hd in handles:
         ms_c, cnt_c = _lib.group_kernel_ms(hd, reset=True)
         k_ms_sum += ms_c
         k_count = max(k_count, cnt_c)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     # for reading the scaling: the same step without the exchange (each rank's products only), outside the timed region
     products_only_ms = None
-    if world > 1:
+    if multi:
         fence()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -456,22 +478,25 @@ def main():
     alg_bytes = synth.algorithmic_bytes(my_rows, n, my_nnz, my_h, 4, "CSR", with_values=True)
     k_ms = k_ms_sum / max(k_count, 1)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = None
+    # HBM traffic per product: NOT measured in this run (PMC passes need rocprofv3); it is replayed from the committed
+    # summary of the last counter run of this same command, and labelled as such
+    traffic, traffic_source = None, None
     if world == 1 and K == 1 and os.path.exists(args.traffic_json):
         try:
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_product")
+            tj = json.load(open(args.traffic_json))
+            traffic = tj.get("hbm_bytes_per_product")
+            traffic_source = {"replayed_from": os.path.relpath(args.traffic_json, ROOT), "collected": tj.get("collected"),
+                              "box": tj.get("box"), "command": tj.get("command"), "kernel_ms_then": tj.get("kernel_ms")}
         except Exception:
             traffic = None
-    info = _lib.group_info(handles[0])
-    n_panels = int(info["n_panels"])
+    plan_info = _lib.group_plan(handles[0])
+    n_panels = int(plan_info["n_panels"])
     # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
-    col16 = _lib.set_tunable("panel_col16", 1)
-    _lib.set_tunable("panel_col16", col16)
-    amode = 3 if (col16 and n / max(n_panels, 1) <= 65536) else 2
+    amode = 3 if plan_info["col16"] else 2
     kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false> x {n_panels} panel launches per product" if n_panels
              else "k_csr_wide<float,4>")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kname, "kernel_ms": round(k_ms, 4), "products_timed": k_count,
                 "launches_per_product": max(n_panels, 1),
                 "algorithmic_bytes": alg_bytes,
@@ -481,10 +506,14 @@ def main():
     result = {
         "metric": "SpMM GFLOP/s, Reddit-shaped CSR h=256 fp32", "value": round(gflops, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_median": round(median_ms, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.shape}-shaped CSR SpMM (configs[1])", "N": n, "nnz": nnz, "h": h,
                    "columns": "clustered" if args.clustered else "uniform",
-                   "partition": plan.describe(),
+                   "partition": plan.describe(), "candidate": f"{type(plan).__name__}:{plan.K}",
+                   "candidates_timed_ms": timed, "rccl_world": rccl_world, "backend": backend if multi else None,
+                   "model_prior": {"row_parts": prior.row_parts, "feat_parts": prior.feat_parts,
+                                   "predicted_ms": round(prior.seconds * 1e3, 4)},
                    **({"ms_per_step_products_only": products_only_ms} if products_only_ms is not None else {})},
         "roofline": roofline,
     }
@@ -495,7 +524,36 @@ def main():
         if not args.no_check:
             got = plan.full_c()[: cpu_out.shape[0]].cpu().numpy()
             result["check"] = "bit-exact vs oracle on the sampled rows" if np.array_equal(got, cpu_out) else "MISMATCH"
-    if world > 1:
+            # real-valued features, whole graph (exercises the floating-point bar of north_star: 1e-5 relative): the same
+            # product on X ~ U(-1, 1) against the oracle's row-parallel loop; error relative to |result| and to |A|.|x|
+            import oracle
+
+            xr = synth.features(n, h, torch.float32, seed=1, device=dev, kind="uniform")
+            cr = torch.empty((my_rows, h), dtype=torch.float32, device=dev)
+            ca = torch.empty_like(cr)
+            _lib.spmm_run_group(handles[0], [xr.data_ptr()], cr.data_ptr(), stream)
+            xa = xr.abs()
+            _lib.spmm_run_group(handles[0], [xa.data_ptr()], ca.data_ptr(), stream)
+            torch.cuda.synchronize()
+            if K == 1 and my_rows == n:
+                nr = cpu_out.shape[0]
+                ref = np.zeros((nr, h), dtype=np.float32)
+                oracle.spmm_csr_rowpar(rowptr[: nr + 1].cpu().numpy().astype(np.uint32), col[: int(rowptr[nr])].cpu().numpy().astype(np.uint32),
+                                       None, xr.cpu().numpy(), nthreads=oracle.max_threads(), out=ref)
+                got_r = cr[:nr].cpu().numpy().astype(np.float64)
+                err = np.abs(got_r - ref.astype(np.float64))
+                mag = np.abs(ref.astype(np.float64))
+                bound = ca[:nr].cpu().numpy().astype(np.float64)
+                nz = mag > 0
+                result["check_uniform_f32"] = {
+                    "rows": int(nr), "bit_identical_elements": float(np.mean(got_r == ref)),
+                    "max_err_rel_result": float(np.max(err[nz] / mag[nz])) if nz.any() else 0.0,
+                    "max_err_rel_absAx": float(np.max(err / np.maximum(bound, 1e-30))),
+                    "elements_over_1e-5_of_result": int(np.sum(err[nz] > 1e-5 * mag[nz])),
+                    "bar": "1e-5 relative (BASELINE.json north_star); |A||x| is the backward-stable scale of a 500-term sum"}
+                if result["check_uniform_f32"]["max_err_rel_absAx"] > 1e-5:
+                    result["check"] = "MISMATCH"
+    if multi:
         # every rank now holds every block: column-count checksum of the assembled C (exact: small integers)
         full = plan.full_c()
         colcount = torch.bincount(col.long(), minlength=n).double()
@@ -509,7 +567,7 @@ def main():
         print(f"[DATA]pim_time_spmm(ms):  {ms_per_step}", file=sys.stderr)
         print(f"[DATA]kernel_time(ms):  {k_ms}", file=sys.stderr)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if result.get("check") == "MISMATCH":
         raise SystemExit("bench result differs from the oracle")

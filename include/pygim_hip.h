@@ -20,10 +20,14 @@
  * spmm_default/pytorch_api.cpp:152) the library holds one device context per
  * process; calls are not re-entrant for the same group handle.  The tunables are
  * process-global.  The slice-major copy of X that the panel sweep gathers from lives in
- * one buffer per launch stream, so products on different streams do not disturb each
- * other; with tunable "xs_reuse" = 1 the caller vouches that X is unchanged since the
- * most recent product (on whichever stream) and orders the streams itself (an event
- * after the first product, as bench.py does): the copy is then shared, not repeated.
+ * one buffer per (device, launch stream), so products on different streams do not
+ * disturb each other; at most four are kept (least recently used goes first) and all
+ * are freed with the last group.  A caller that runs several products on the SAME
+ * unchanged X says so per call (the x_unchanged argument of pygim_spmm_run_group_x /
+ * pygim_block_run_x): the copy made by the most recent product on exactly that operand
+ * (pointer, stride, shape) is then shared instead of repeated; the caller orders the
+ * streams itself (an event after the first product, as bench.py does) and must not
+ * pass the flag after writing to X.
  * Scratch buffers are sized on first use (hipMalloc), so capture a product into a hipGraph only after one warm-up call.
  */
 #ifndef PYGIM_HIP_H
@@ -124,6 +128,10 @@ int pygim_group_free(int64_t handle);
  * call only enqueues work; with host pointers it returns after the result has
  * been copied back.                                                           */
 int pygim_spmm_run_group(int64_t handle, const void *const *B_parts, void *out, void *stream);
+/* the same with x_unchanged (see "Threading" above): 1 = B_parts hold exactly what the most
+ * recent product on the same pointers held, its slice-major copy may be reused.   */
+int pygim_spmm_run_group_x(int64_t handle, const void *const *B_parts, void *out, int x_unchanged,
+                           void *stream);
 int pygim_grande_run_group(int64_t handle, const void *const *B_windows, const int64_t *window_ld,
                            void *out, void *stream);
 int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out, void *stream);
@@ -134,6 +142,8 @@ int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out
  * be device pointers.                                                         */
 int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc,
                     int64_t width, int accumulate, void *stream);
+int pygim_block_run_x(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc,
+                      int64_t width, int accumulate, int x_unchanged, void *stream);
 
 /* ---- quantise -> aggregate -> dequantise (the step either side of the product in every conv layer,
  * models/pyg_gcn_conv.py:130-137 with models/quantize.py:20-42), on device in one call:
@@ -171,10 +181,16 @@ int pygim_group_info(int64_t handle, int64_t out[8]);
  * This call waits for the pending pairs and returns the accumulated milliseconds and the
  * number of launches since the last reset.                                      */
 int pygim_group_kernel_ms(int64_t handle, double *sum_ms, int64_t *count, int reset);
+/* the same switch for ONE group (what bench.py uses; the tunable is the process-wide default for A/B scripts) */
+int pygim_group_kernel_events(int64_t handle, int on);
+/* plan of the matrix the run entry points sweep (the merged matrix of a multi-part group, else part 0):
+ * column panels (0 = no panel plan), columns per panel, work items, 16-bit panel-local column ids built (0/1),
+ * wave-cooperative (long) items, segment-kernel tasks, merged (0/1), has a non-unit-weight correction part (0/1) */
+int pygim_group_plan(int64_t handle, int64_t out[8]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
- * "split_unit_pattern", "merge_parts", "vec_kernel", "xs_reuse", "kernel_events"};
+ * "split_unit_pattern", "merge_parts", "vec_kernel", "kernel_events"};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, merge_parts at creation) are read when a group is created; the others per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

@@ -28,7 +28,7 @@ def test(args, model, data):
     labels, logits): the time is the slowest rank's, checksum and accuracy are summed over the ranks"""
     import torch.distributed as dist
 
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_available() and dist.is_initialized()
     model.eval()
     if data["x"].is_cuda:
         torch.cuda.synchronize()
@@ -80,14 +80,30 @@ def get_args():
 def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    # PYGIM_FORCE_COLLECTIVES=1 under torch.distributed.run with ONE rank: the row-sharded multi-GPU path with every
+    # collective executing at world size 1 (first-run check of the RCCL path on one GPU)
+    sharded = world > 1 or (os.environ.get("PYGIM_FORCE_COLLECTIVES", "0") == "1" and "MASTER_ADDR" in os.environ
+                            and args.version != "cpu")
+    if sharded:
         import torch.distributed as dist
 
         backend = os.environ.get("PYGIM_BENCH_BACKEND", "nccl")  # gloo = logic check with several ranks on one GPU
         lr = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(lr if backend == "nccl" else lr % torch.cuda.device_count())
-        dist.init_process_group(backend)
+        idx = lr if backend == "nccl" else lr % torch.cuda.device_count()
+        torch.cuda.set_device(idx)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", idx))
+        else:
+            dist.init_process_group(backend)
         args.device = "cuda"
+        if rank == 0:
+            from pygim_amd import autotune
+
+            n0, nnz0, _ = DATASETS[args.dataset]
+            best, _tab = autotune.choose(n0, n0, nnz0, args.hidden_size, 4, world)
+            print(f"[DATA]rccl_world: {dist.get_world_size()}", flush=True)
+            print(f"[DATA]partition_prior(row x feature): {best.row_parts} x {best.feat_parts}  (used: row-sharded "
+                  f"{world} x 1, the arrangement the dense layers need)", flush=True)
     n, nnz, dmax = DATASETS[args.dataset]
     gen = "cuda" if torch.cuda.is_available() else "cpu"
     rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=gen)
@@ -99,7 +115,7 @@ def main(args):
     if args.version == "cpu":
         data["adj_t"] = adj_t
         data["x"], data["y"] = x, y
-    elif world > 1:
+    elif sharded:
         # sp_parts = world as a row split with row-SHARDED activations (pygim_amd/dist.py RowShardAdj)
         from pygim_amd.dist import RowShardAdj
 
@@ -123,8 +139,12 @@ def main(args):
         acc = test(args, model, data)
         if rank == 0:
             print(f"Test_acc: {acc:.4f}")
-    if args.version != "cpu" and world == 1:
+    if args.version != "cpu" and not sharded:
         torch.ops.pim_ops.dpu_release()
+    if sharded:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

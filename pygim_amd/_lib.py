@@ -16,7 +16,8 @@ EXPORTS = [
     "pygim_device_info", "pygim_group_create", "pygim_group_free", "pygim_spmm_run_group",
     "pygim_grande_run_group", "pygim_spmv_run_group", "pygim_block_run", "pygim_group_timers",
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
-    "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize",
+    "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
+    "pygim_group_kernel_events", "pygim_group_plan",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -57,12 +58,16 @@ def lib():
                                          p_i64]
         L.pygim_group_free.argtypes = [c_i64]
         L.pygim_spmm_run_group.argtypes = [c_i64, vp, vp, vp]
+        L.pygim_spmm_run_group_x.argtypes = [c_i64, vp, vp, c_int, vp]
         L.pygim_grande_run_group.argtypes = [c_i64, vp, p_i64, vp, vp]
         L.pygim_spmv_run_group.argtypes = [c_i64, vp, vp, vp]
         L.pygim_block_run.argtypes = [c_i64, c_int, vp, c_i64, vp, c_i64, c_i64, c_int, vp]
+        L.pygim_block_run_x.argtypes = [c_i64, c_int, vp, c_i64, vp, c_i64, c_i64, c_int, c_int, vp]
         L.pygim_group_timers.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double)]
         L.pygim_group_info.argtypes = [c_i64, p_i64]
         L.pygim_group_kernel_ms.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double), p_i64, c_int]
+        L.pygim_group_kernel_events.argtypes = [c_i64, c_int]
+        L.pygim_group_plan.argtypes = [c_i64, p_i64]
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_absmax.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
         L.pygim_quantize.argtypes = [c_int, vp, c_i64, c_i64, c_i64, vp, vp, vp, vp]
@@ -130,9 +135,11 @@ def group_free(handle):
     check(lib().pygim_group_free(int(handle)))
 
 
-def spmm_run_group(handle, b_ptrs, out_ptr, stream=0):
-    check(lib().pygim_spmm_run_group(int(handle), ptr_array(b_ptrs), ctypes.c_void_p(out_ptr),
-                                     ctypes.c_void_p(stream or None)))
+def spmm_run_group(handle, b_ptrs, out_ptr, stream=0, x_unchanged=False):
+    """``x_unchanged``: the dense parts hold exactly what the most recent product on the same pointers held
+    (include/pygim_hip.h, "Threading"): its slice-major copy is reused instead of being made again."""
+    check(lib().pygim_spmm_run_group_x(int(handle), ptr_array(b_ptrs), ctypes.c_void_p(out_ptr),
+                                       1 if x_unchanged else 0, ctypes.c_void_p(stream or None)))
 
 
 def grande_run_group(handle, b_ptrs, lds, out_ptr, stream=0):
@@ -145,15 +152,27 @@ def spmv_run_group(handle, b_ptrs, out_ptr, stream=0):
                                      ctypes.c_void_p(stream or None)))
 
 
-def block_run(handle, part, x_ptr, ldx, c_ptr, ldc, width, accumulate=False, stream=0):
-    check(lib().pygim_block_run(int(handle), int(part), ctypes.c_void_p(x_ptr), int(ldx), ctypes.c_void_p(c_ptr),
-                                int(ldc), int(width), 1 if accumulate else 0, ctypes.c_void_p(stream or None)))
+def block_run(handle, part, x_ptr, ldx, c_ptr, ldc, width, accumulate=False, stream=0, x_unchanged=False):
+    check(lib().pygim_block_run_x(int(handle), int(part), ctypes.c_void_p(x_ptr), int(ldx), ctypes.c_void_p(c_ptr),
+                                  int(ldc), int(width), 1 if accumulate else 0, 1 if x_unchanged else 0,
+                                  ctypes.c_void_p(stream or None)))
 
 
 def group_timers(handle):
     out = (ctypes.c_double * 5)()
     check(lib().pygim_group_timers(int(handle), out))
     return list(out)
+
+
+def group_kernel_events(handle, on=True):
+    check(lib().pygim_group_kernel_events(int(handle), 1 if on else 0))
+
+
+def group_plan(handle):
+    out = (ctypes.c_int64 * 8)()
+    check(lib().pygim_group_plan(int(handle), out))
+    keys = ["n_panels", "panel_cols", "n_items", "col16", "n_coop_items", "n_segment_tasks", "merged", "has_extra"]
+    return dict(zip(keys, [int(v) for v in out]))
 
 
 def group_info(handle):

@@ -508,6 +508,11 @@ template <typename T, int J> __device__ __forceinline__ T bcast8_t(T v) {
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4_u __attribute__((ext_vector_type(4), aligned(2)));  // 4 panel-local column ids, any 2-byte alignment
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));  // one gathered 16-byte piece, untyped
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// scale of the conv layers' symmetric quantiser (models/quantize.py:22-30): abs_max * 2 / 2^k
+__device__ __forceinline__ float quant_scale(uint32_t absmax_bits, int log2_range) {
+    return __uint_as_float(absmax_bits) * 2.0f / (float)(1u << log2_range);
+}
 // the same piece at ANY byte alignment (rows of X / C whose stride is not a multiple of 16 bytes: h = 41, 100 int8 ...):
 // still one global_load/store_dwordx4, the memory path takes unaligned addresses
 typedef uint32_t u32x4_b __attribute__((ext_vector_type(4), aligned(1)));
@@ -618,14 +623,18 @@ __device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xbase, ui
 //                 and the partial sums are added across the groups at the end (integers: exact; floats:
 //                 a different summation order, inside the 1e-5 bound).  Keeps long rows inside the L2-blocked
 //                 sweep instead of leaving one lane group with a serial chain of thousands of gathers.
-template <typename T, int VEC, int AMODE, bool HAS_VALS, bool COOP>
+//   DEQ = true (the conv layers' fused quantise -> aggregate -> dequantise, models/quantize.py:20-42): an item that is
+//   the LAST of its row (bit 30 of its length word: no later panel holds entries of the row) stores
+//   float(sum) * scale to the float matrix Cf instead of the running sum to C.
+template <typename T, int VEC, int AMODE, bool HAS_VALS, bool COOP, bool DEQ>
 __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__restrict__ item_row,
                                             const uint32_t *__restrict__ item_begin,
                                             const uint32_t *__restrict__ item_len, uint32_t nitems,
                                             const uint32_t *__restrict__ colind, const T *__restrict__ vals,
                                             const T *__restrict__ X, int64_t ldx, int64_t slice_stride,
                                             T *__restrict__ C, int64_t ldc, uint32_t w, uint32_t nslices,
-                                            int accumulate, uint32_t col_base) {
+                                            int accumulate, uint32_t col_base, float *__restrict__ Cf, int64_t ldcf,
+                                            const uint32_t *__restrict__ absmax_bits, int log2_range) {
     static_assert(VEC * sizeof(T) == 16, "the sweep gathers 16-byte pieces");
     constexpr bool PACKED = !HAS_VALS && sizeof(T) < 4;
     constexpr int LPR = 8;   // lanes per 128-byte slice of a row
@@ -655,13 +664,14 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     // work item = (row, first entry, length | FIRST flag): the part of one row that falls into
     // this launch's column panel; FIRST = no earlier panel holds entries of the row
     uint32_t s = 0, len = 0, row = 0;
-    bool load_c = false;
+    bool load_c = false, last = false;
     if (row_ok) {
         row = item_row[i];
         s = item_begin[i];
         const uint32_t lf = item_len[i];
-        len = lf & 0x7FFFFFFFu;
+        len = lf & 0x3FFFFFFFu;
         load_c = accumulate || !(lf >> 31);
+        last = (lf >> 30) & 1u;
     }
     const uint32_t f0 = slice * (LPR * VEC) + li * VEC;
     // (an empty row under accumulate has nothing to add: its row of C is neither read nor written)
@@ -792,6 +802,29 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
         for (int off = 8; off < 64; off <<= 1) acc.merge_xor(off);
     }
     if (lane_on && (!COOP || grp == 0)) {
+        if constexpr (DEQ) {
+            if (last) {
+                // scale_edge (1.) * scale_x, as k_dequantize
+                const float scale = 1.0f * quant_scale(*absmax_bits, log2_range);
+                float *frow = Cf + (int64_t)row * ldcf + f0;
+                if (f0 + VEC <= w && ((reinterpret_cast<uintptr_t>(frow) & 15u) == 0)) {
+#pragma unroll
+                    for (int k = 0; k < VEC; k += 4) {
+                        f32x4_t o;
+                        o.x = (float)acc.get(k) * scale;
+                        o.y = (float)acc.get(k + 1) * scale;
+                        o.z = (float)acc.get(k + 2) * scale;
+                        o.w = (float)acc.get(k + 3) * scale;
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(frow + k));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; k++)
+                        if (f0 + k < w) frow[k] = (float)acc.get(k) * scale;
+                }
+                return;
+            }
+        }
         if (f0 + VEC <= w) {
             __builtin_nontemporal_store((u32x4_b)acc.get_raw(), reinterpret_cast<u32x4_b *>(crow + f0));
         } else {
@@ -804,7 +837,7 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
 
 // One launch per column panel: the first coop_grid blocks take the panel's LONG items (one wave each,
 // dispatched first), the rest the ordinary items (one lane group each).
-template <typename T, int VEC, int LOG_LPR, int AMODE, bool HAS_VALS>
+template <typename T, int VEC, int LOG_LPR, int AMODE, bool HAS_VALS, bool DEQ = false>
 __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
                                                    const uint32_t *__restrict__ item_begin,
                                                    const uint32_t *__restrict__ item_len, uint32_t nitems,
@@ -815,14 +848,17 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                                                    const T *__restrict__ vals, const T *__restrict__ X,
                                                    int64_t ldx, int64_t slice_stride, T *__restrict__ C,
                                                    int64_t ldc, uint32_t w, uint32_t nslices, int accumulate,
-                                                   uint32_t col_base) {
+                                                   uint32_t col_base, float *__restrict__ Cf, int64_t ldcf,
+                                                   const uint32_t *__restrict__ absmax_bits, int log2_range) {
     static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     if (blockIdx.x < coop_grid)
-        panel_sweep<T, VEC, AMODE, HAS_VALS, true>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
-                                                   ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base);
+        panel_sweep<T, VEC, AMODE, HAS_VALS, true, DEQ>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
+                                                        ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base, Cf, ldcf,
+                                                        absmax_bits, log2_range);
     else
-        panel_sweep<T, VEC, AMODE, HAS_VALS, false>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
-                                                    colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base);
+        panel_sweep<T, VEC, AMODE, HAS_VALS, false, DEQ>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
+                                                         colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate,
+                                                         col_base, Cf, ldcf, absmax_bits, log2_range);
 }
 
 // Slice-major copy of X for the panel sweep: Xs[s][j][0:F] = X[j][s*F : (s+1)*F] (zero padded past
@@ -853,6 +889,43 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
         for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? X[(int64_t)j * ldx + f0 + k] : T(0);
         store_vec<T, VEC>(dst, v);
     }
+}
+
+// The same copy for the fused quantised aggregation: reads the FLOAT features, quantises them as k_quantize does
+// (round-half-even of the true quotient v / scale, models/quantize.py:31-33) and writes the slice-major copy in the
+// adjacency type -- the row-major quantised matrix is never materialised.
+template <typename T, int VEC, int LOG_LPR>
+__global__ void k_slice_pack_quant(const float *__restrict__ X, int64_t ldx, uint32_t nrows, uint32_t w, uint32_t nslices,
+                                   const uint32_t *__restrict__ absmax_bits, int log2_range, T *__restrict__ Xs,
+                                   float *__restrict__ scale_out) {
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr uint32_t F = LPR * VEC;
+    static_assert(VEC * sizeof(T) == 16 && VEC % 4 == 0, "16-byte pieces of at least four elements");
+    const float scale = quant_scale(*absmax_bits, log2_range);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && scale_out) *scale_out = scale;
+    const uint64_t per_row = (uint64_t)nslices * LPR;
+    const uint64_t j = t / per_row;
+    if (j >= nrows) return;
+    const uint32_t rem = (uint32_t)(t % per_row);
+    const uint32_t sl = rem >> LOG_LPR, li = rem & (LPR - 1);
+    const uint32_t f0 = sl * F + li * VEC;
+    const float *src = X + (int64_t)j * ldx + f0;
+    T v[VEC];
+    if (f0 + VEC <= w && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
+#pragma unroll
+        for (int k = 0; k < VEC; k += 4) {
+            const f32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + k));
+            v[k] = (T)rintf(q.x / scale);
+            v[k + 1] = (T)rintf(q.y / scale);
+            v[k + 2] = (T)rintf(q.z / scale);
+            v[k + 3] = (T)rintf(q.w / scale);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? (T)rintf(src[k] / scale) : T(0);
+    }
+    store_vec<T, VEC>(Xs + ((int64_t)sl * nrows + j) * F + li * VEC, v);
 }
 
 // panel pointers: pp[p * nrows + i] = first stored entry of sorted row i whose column
@@ -1112,7 +1185,6 @@ __global__ void k_pack_vectors(const T *const *__restrict__ vecs, uint32_t g, ui
 // ---------------------------------------------------------------------------
 // max |x| as the bit pattern of a non-negative float (orders like an unsigned integer)
 // FLAT = the matrix is one contiguous, 16-byte aligned array whose length is a multiple of 4: float4 accesses
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <bool FLAT>
 __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w, uint32_t *out) {
     const uint64_t total = rows * w;
@@ -1131,9 +1203,6 @@ __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-__device__ __forceinline__ float quant_scale(uint32_t absmax_bits, int log2_range) {
-    return __uint_as_float(absmax_bits) * 2.0f / (float)(1u << log2_range);
 }
 template <typename T> struct Pack4 { T v[4]; } __attribute__((aligned(sizeof(T) * 4)));
 template <typename T, bool FLAT>

@@ -28,7 +28,7 @@ namespace {
 struct Meta {
     at::ScalarType dtype;
     int64_t rows, cols, h;
-    std::vector<int64_t> n_dense, dense_cols;
+    std::vector<int64_t> n_dense, dense_cols, part_cols;
     std::vector<at::Tensor> keep;  // device arrays are used in place by the library
 };
 std::unordered_map<int64_t, Meta> g_meta;
@@ -89,6 +89,7 @@ int64_t to_device_group(int format, std::vector<at::Tensor> idx0, std::vector<at
     m.h = h_size;
     m.n_dense = n_dense;
     m.dense_cols = dense_cols;
+    m.part_cols = ncols;
     g_meta[handle] = std::move(m);
     return handle;
 }
@@ -128,16 +129,42 @@ void log_timers(int64_t handle, bool on_host) {
 
 at::Tensor run_common(int64_t handle, std::vector<at::Tensor> &parts, int kind) {
     const Meta &m = meta(handle);
+    // same checks as the Python registration (pim_ops.py _check_dense and the per-op shape checks): the C side indexes
+    // its window table by the group's own counts and gathers rows of B up to the group's column count
+    int64_t expect = 0;
+    if (kind == 1)
+        for (auto v : m.n_dense) expect += v;
+    else
+        expect = m.n_dense.empty() ? 0 : m.n_dense[0];
+    TORCH_CHECK((int64_t)parts.size() == expect, "expected ", expect, " dense parts, got ", parts.size());
     TORCH_CHECK(!parts.empty(), "no dense parts");
     std::vector<const void *> ptrs;
     std::vector<int64_t> lds;
+    size_t k = 0, part = 0;
+    int64_t in_part = 0;
     for (auto &p : parts) {
         TORCH_CHECK(p.scalar_type() == m.dtype, "expected scalar type ", m.dtype, " but found ", p.scalar_type());
+        TORCH_CHECK(p.device() == parts[0].device(), "dense parts must live on one device");
+        if (kind == 2) {
+            TORCH_CHECK(p.numel() == m.cols, "vector ", k, " has ", p.numel(), " elements, expected ", m.cols);
+        } else if (kind == 0) {
+            TORCH_CHECK(p.dim() == 2 && p.size(0) == m.cols && p.size(1) == m.dense_cols[k], "dense part ", k, " has shape ",
+                        p.sizes(), ", expected (", m.cols, ", ", m.dense_cols[k], ")");
+        } else {
+            // grande: window k belongs to sparse part `part` and holds that part's rows of B
+            TORCH_CHECK(p.dim() == 2 && p.size(0) == m.part_cols[part] && p.size(1) >= m.dense_cols[k], "window ", k,
+                        " has shape ", p.sizes(), ", expected (", m.part_cols[part], ", >= ", m.dense_cols[k], ")");
+            if (++in_part == m.n_dense[part]) {
+                part++;
+                in_part = 0;
+            }
+        }
         p = p.contiguous();
         ptrs.push_back(p.data_ptr());
         lds.push_back(p.dim() == 2 ? p.size(1) : 1);
+        k++;
     }
-    const int64_t out_cols = kind == 2 ? (int64_t)parts.size() : m.h;
+    const int64_t out_cols = kind == 2 ? m.n_dense[0] : m.h;
     // host operands: the result lives in page-locked host memory (torch's caching host allocator), so the device-to-host
     // copy runs at PCIe speed instead of faulting fresh pages in; PYGIM_PINNED_OUT=0 gives pageable memory
     const char *po = std::getenv("PYGIM_PINNED_OUT");

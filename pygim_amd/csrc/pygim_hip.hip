@@ -74,7 +74,6 @@ struct Tunables {
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
-    int64_t xs_reuse = 0;               // 1 = the caller vouches that X is unchanged since the last product: reuse its slice-major copy
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
 } g_tune;
 
@@ -136,6 +135,18 @@ struct Group {
     const void *packed_src = nullptr;
     void *packed_buf = nullptr;
     int64_t packed_ld = 0, packed_w = 0;
+    // per-call options of the entry point in flight (a group serves one call at a time)
+    bool x_unchanged = false;        // the caller vouches: same X, same contents as the product that last packed it
+    const void *pre_xs = nullptr;    // slice-major copy already made by the caller of launch_block_any (fused quantiser)
+    float *deq_out = nullptr;        // fused dequantisation: rows' LAST items store float(sum) * scale here
+    int64_t deq_ld = 0;
+    const uint32_t *deq_amax = nullptr;
+    int deq_log2 = 0;
+    // pinned pointer tables of the SpMV pack (two slots, each guarded by an event)
+    void **h_ptrs = nullptr;
+    size_t h_ptrs_n = 0;
+    hipEvent_t ev_ptrs[2] = {nullptr, nullptr};
+    int ptr_slot = 0;
     void *xcat = nullptr;     // dense windows of one sparse part laid side by side (fused block product)
     size_t xcat_bytes = 0;
     void **d_ptrs = nullptr;  // device array of pointers (spmv pack)
@@ -147,6 +158,7 @@ struct Group {
     double timers[5] = {0, 0, 0, 0, 0};
     // HIP-event pairs around the dominant kernel (tunable kernel_events), resolved on query
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    bool kernel_events = false;  // pygim_group_kernel_events
     double ev_ms = 0;
     int64_t ev_count = 0;
 };
@@ -158,16 +170,56 @@ struct Context {
     int64_t nr_ranks = 0;
     std::set<Group *> groups;
     std::mutex mu;
-    // slice-major copies of X for the panel sweep: one buffer per launch stream (products on different streams
-    // never share a buffer), plus a record of the most recent copy for callers that vouch "same X" (xs_reuse)
-    struct XsBuf { void *ptr = nullptr; size_t bytes = 0; };
-    std::map<hipStream_t, XsBuf> xs_by_stream;
-    void *xs = nullptr;  // the most recent copy (whichever stream made it)
-
-    const void *xs_src = nullptr;
-    int64_t xs_ld = 0, xs_rows = 0, xs_w = 0;
-    size_t xs_es = 0;
+    // slice-major copies of X for the panel sweep: one buffer per (device, launch stream) -- products on different
+    // streams never share a buffer -- each with a record of what it holds, for callers that pass x_unchanged.
+    // At most XS_MAX buffers are kept (least recently used goes first); all are freed with the last group.
+    struct XsBuf {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        const void *src = nullptr;  // what the buffer holds: X pointer, stride, rows, width, element size
+        int64_t ld = 0, rows = 0, w = 0;
+        size_t es = 0;
+        uint64_t stamp = 0;
+    };
+    static constexpr size_t XS_MAX = 4;
+    std::map<std::pair<int, hipStream_t>, XsBuf> xs_bufs;
+    uint64_t xs_clock = 0;
 } g_ctx;
+
+void free_xs_buffers_locked() {
+    for (auto &kv : g_ctx.xs_bufs)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_ctx.xs_bufs.clear();
+}
+
+// the slice-major buffer of (current device, stream), at least `need` bytes; evicts the least recently used buffer
+// when more than XS_MAX exist.  Caller holds g_ctx.mu.
+int xs_buffer_locked(hipStream_t st, size_t need, Context::XsBuf **out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(dev, st);
+    if (!g_ctx.xs_bufs.count(key) && g_ctx.xs_bufs.size() >= Context::XS_MAX) {
+        auto victim = g_ctx.xs_bufs.begin();
+        for (auto it = g_ctx.xs_bufs.begin(); it != g_ctx.xs_bufs.end(); ++it)
+            if (it->second.stamp < victim->second.stamp) victim = it;
+        if (victim->second.ptr) (void)hipFree(victim->second.ptr);  // hipFree waits for the work that uses it
+        g_ctx.xs_bufs.erase(victim);
+    }
+    Context::XsBuf &b = g_ctx.xs_bufs[key];
+    if (b.bytes < need) {
+        if (b.ptr) (void)hipFree(b.ptr);
+        b = Context::XsBuf();
+        if (hipMalloc(&b.ptr, need) != hipSuccess) {
+            (void)hipGetLastError();
+            g_ctx.xs_bufs.erase(key);
+            return fail(PYGIM_ERR_HIP, "slice-major buffer alloc");
+        }
+        b.bytes = need;
+    }
+    b.stamp = ++g_ctx.xs_clock;
+    *out = &b;
+    return 0;
+}
 
 bool is_device_ptr(const void *p) {
     if (!p) return false;
@@ -233,6 +285,9 @@ void free_group(Group *g) {
     if (g->xq) (void)hipFree(g->xq);
     if (g->oq) (void)hipFree(g->oq);
     if (g->d_ptrs) (void)hipFree(g->d_ptrs);
+    if (g->h_ptrs) (void)hipHostFree(g->h_ptrs);
+    for (hipEvent_t e : g->ev_ptrs)
+        if (e) (void)hipEventDestroy(e);
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->side) (void)hipStreamDestroy(g->side);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -270,7 +325,7 @@ struct KernelTimer {
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
     KernelTimer(Group *g_, hipStream_t st_, bool on = true) : g(g_), st(st_) {
-        if (on && g_tune.kernel_events && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+        if (on && (g_tune.kernel_events || g->kernel_events) && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
             (void)hipEventRecord(a, st);
         else
             a = b = nullptr;
@@ -293,10 +348,18 @@ bool want_panel(const Part &p, uint32_t w, int64_t ldx) {
         return false;
     constexpr uint32_t V = 16 / sizeof(T), F = V * 8;
     const uint32_t nslices = (w + F - 1) / F;
-    const bool tail_inside = (int64_t)((w + V - 1) / V) * V <= ldx;
+    const bool tail_inside = (w % V) == 0;  // no partial 16-byte piece: nothing is read past a row's width
+    (void)ldx;
     if (!tail_inside && (uint64_t)p.ncols * nslices * 128ull > (8ull << 30)) return false;
     return true;
 }
+
+// element types of the conv layers' quantiser (models/quantize.py:22-30): the fused store exists for these
+template <typename T> struct DeqType { static constexpr bool ok = false; };
+template <> struct DeqType<int8_t> { static constexpr bool ok = true; };
+template <> struct DeqType<int16_t> { static constexpr bool ok = true; };
+template <> struct DeqType<int32_t> { static constexpr bool ok = true; };
+template <> struct DeqType<float> { static constexpr bool ok = true; };
 
 template <typename T, int VEC>
 int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate,
@@ -363,10 +426,16 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st, !p.is_extra);
-            // (rows of one slice that are already contiguous lines need no copy -- as long as the 16-byte piece over
-            // a row's tail stays inside the row stride: gathered pieces must never reach past the end of X)
-            const bool tail_inside = (int64_t)((w + VEC - 1) / VEC) * VEC <= ldx;
-            if ((g_tune.panel_pack || !tail_inside) && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128 && tail_inside)) {
+            // (rows of one slice that are already contiguous lines need no copy -- as long as no 16-byte piece is
+            // partial: X may be a window that ends at the end of an allocation (pygim_block_run on x + f0), so a
+            // piece over a ragged tail must never be read from the caller's matrix; those go to the padded copy)
+            const bool tail_inside = (w % VEC) == 0;
+            if (g->pre_xs) {
+                // the caller packed (and quantised) the features slice-major on this stream already
+                Xg = (const T *)g->pre_xs;
+                ldg = F;
+                slice_stride = (int64_t)p.ncols * F;
+            } else if ((g_tune.panel_pack || !tail_inside) && !(nslices == 1 && (size_t)ldx * sizeof(T) <= 128 && tail_inside)) {
                 const size_t need = (size_t)p.ncols * nslices * F * sizeof(T);
                 void *xs_use = nullptr;
                 if (p.is_extra && g->packed_buf && g->packed_src == (const void *)X && g->packed_ld == ldx &&
@@ -374,22 +443,31 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                     xs_use = g->packed_buf;  // the pattern product of this very call packed it on this stream
                 } else {
                     std::lock_guard<std::mutex> lk(g_ctx.mu);
-                    const bool same = g_tune.xs_reuse && g_ctx.xs && g_ctx.xs_src == (const void *)X && g_ctx.xs_ld == ldx &&
-                                      g_ctx.xs_rows == p.ncols && g_ctx.xs_w == (int64_t)w && g_ctx.xs_es == sizeof(T);
-                    if (same) {
-                        xs_use = g_ctx.xs;
-                    } else {
-                        Context::XsBuf &b = g_ctx.xs_by_stream[st];
-                        if (int rc = ensure(&b.ptr, &b.bytes, std::max<size_t>(need, 256))) return rc;
-                        xs_use = b.ptr;
-                        g_ctx.xs = b.ptr;
-                        g_ctx.xs_src = X;
-                        g_ctx.xs_ld = ldx;
-                        g_ctx.xs_rows = p.ncols;
-                        g_ctx.xs_w = (int64_t)w;
-                        g_ctx.xs_es = sizeof(T);
+                    if (g->x_unchanged) {
+                        // the most recent copy of exactly this operand on this device, whichever stream made it
+                        int dev = 0;
+                        (void)hipGetDevice(&dev);
+                        Context::XsBuf *hit = nullptr;
+                        for (auto &kv : g_ctx.xs_bufs) {
+                            Context::XsBuf &b = kv.second;
+                            if (kv.first.first == dev && b.ptr && b.src == (const void *)X && b.ld == ldx && b.rows == p.ncols &&
+                                b.w == (int64_t)w && b.es == sizeof(T) && (!hit || b.stamp > hit->stamp))
+                                hit = &b;
+                        }
+                        if (hit) {
+                            hit->stamp = ++g_ctx.xs_clock;
+                            xs_use = hit->ptr;
+                        }
                     }
-                    if (!same) {
+                    if (!xs_use) {
+                        Context::XsBuf *b = nullptr;
+                        if (int rc = xs_buffer_locked(st, std::max<size_t>(need, 256), &b)) return rc;
+                        xs_use = b->ptr;
+                        b->src = X;
+                        b->ld = ldx;
+                        b->rows = p.ncols;
+                        b->w = (int64_t)w;
+                        b->es = sizeof(T);
                         const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
                         if (threads > 0)
                             hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)),
@@ -430,15 +508,25 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t coop_grid = ncoop ? 8u * ns * ((coop_blocks + 7) / 8) : 0u;
                 const uint32_t norm_grid = nnorm ? 8u * ns * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
-#define PYGIM_LAUNCH_PANEL(AM, HV)                                                                          \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,       \
+#define PYGIM_LAUNCH_PANEL_D(AM, HV, DQ)                                                                    \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV, DQ>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,   \
                        ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid,                           \
                        (AM == 3 ? (const uint32_t *)p.col16 : p.colind), vals, Xs0, ldg,                                  \
-                       slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0, q * p.panel_cols)
+                       slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0, q * p.panel_cols,                              \
+                       g->deq_out ? g->deq_out + (size_t)s0 * F : nullptr, g->deq_ld, g->deq_amax, g->deq_log2)
+#define PYGIM_LAUNCH_PANEL(AM, HV) PYGIM_LAUNCH_PANEL_D(AM, HV, false)
                 // addressing mode of the gathers (kernels.hpp gather_raw): 128-byte rows of the slice-major copy
                 // (with 16-bit panel-local column ids when the plan has them), any stride below 4 GiB, or 64-bit
                 int amode = !off32 ? 0 : ((size_t)ldg * sizeof(T) == 128 ? 2 : 1);
                 if (amode == 2 && p.col16 && g_tune.panel_col16) amode = 3;
+                if constexpr (DeqType<T>::ok) {
+                    if (g->deq_out && amode >= 2 && !vals) {
+                        if (amode == 3) PYGIM_LAUNCH_PANEL_D(3, false, true);
+                        else PYGIM_LAUNCH_PANEL_D(2, false, true);
+                        continue;
+                    }
+                }
+                if (g->deq_out) return fail(PYGIM_ERR_INVALID, "internal: fused dequantisation on an unsupported sweep");
                 if (amode == 3 && vals) PYGIM_LAUNCH_PANEL(3, true);
                 else if (amode == 3) PYGIM_LAUNCH_PANEL(3, false);
                 else if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, true);
@@ -448,6 +536,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 else if (vals) PYGIM_LAUNCH_PANEL(0, true);
                 else PYGIM_LAUNCH_PANEL(0, false);
 #undef PYGIM_LAUNCH_PANEL
+#undef PYGIM_LAUNCH_PANEL_D
             }
             }
             kt.stop();
@@ -679,8 +768,9 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
                 for (uint32_t r : order) {
                     rows_v.push_back(r);
                     beg_v.push_back(lo[r]);
-                    const uint32_t first = (lo[r] == rp[r]) ? 0x80000000u : 0u;  // no entries in earlier panels
-                    len_v.push_back((hi[r] - lo[r]) | first);
+                    const uint32_t first = (lo[r] == rp[r]) ? 0x80000000u : 0u;     // no entries in earlier panels
+                    const uint32_t last = (hi[r] == rp[r + 1]) ? 0x40000000u : 0u;  // none in later panels
+                    len_v.push_back((hi[r] - lo[r]) | first | last);
                 }
                 p.panel_off.push_back(rows_v.size());
             }
@@ -1109,17 +1199,68 @@ static int quant_log2_range(int dtype) {  // ranges of models/quantize.py:22-30
     }
 }
 
+// Can the group's product run as ONE sweep that reads a caller-made slice-major copy and dequantises in its last
+// store?  (unit weights, one matrix -- a single part or the merged one --, a panel plan without segment-kernel rows)
+template <typename T>
+static Part *fusable_part(Group *g) {
+    if (!g->all_ones || !g_tune.fuse_windows || g_tune.panel_mode == 2 || g->h <= 4) return nullptr;
+    Part *p = nullptr;
+    if (g->parts.size() == 1) p = &g->parts[0];
+    else if (g->merged && g_tune.merge_parts) p = g->merged.get();
+    if (!p || p->vals || p->extra || !p->d_items || p->lp_panel.n_tasks > 0 || p->nrows == 0 || p->ncols == 0) return nullptr;
+    if (!want_panel<T>(*p, (uint32_t)g->h, g->h)) return nullptr;
+    constexpr uint32_t F = 128 / sizeof(T);
+    const uint64_t nslices = ((uint64_t)g->h + F - 1) / F;
+    if (((uint64_t)p->ncols * 128ull + 128ull) >= (1ull << 32)) return nullptr;  // the fused store rides the 32-bit gather modes
+    if ((uint64_t)p->ncols * nslices * 128ull > (8ull << 30)) return nullptr;
+    return p;
+}
+
 template <typename T>
 static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float *scale_out, int log2_range, hipStream_t st) {
     const uint64_t rows = (uint64_t)g->total_cols, orows = (uint64_t)g->total_rows;
     const uint32_t h = (uint32_t)g->h;
-    if (int rc = ensure(&g->xq, &g->xq_bytes, std::max<size_t>(rows * h * sizeof(T), 256))) return rc;
-    if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
     uint32_t *amax = (uint32_t *)(g->d_flags + 3);
     HIP_TRY(hipMemsetAsync(amax, 0, sizeof(uint32_t), st));
     if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
-    if (int rc = launch_quantize<T>(X, ldx, rows, h, amax, log2_range, (T *)g->xq, scale_out, st)) return rc;
     if (rows * h == 0 && scale_out) HIP_TRY(hipMemsetAsync(scale_out, 0, sizeof(float), st));
+    if (Part *p = fusable_part<T>(g)) {
+        // FUSED: |max| reduction, then the slice-major copy is written quantised straight from the float features,
+        // and every row's last panel item stores float(sum) * scale (no row-major quantised matrix, no integer result,
+        // no separate quantise / dequantise passes)
+        constexpr int VEC = 16 / (int)sizeof(T), LOG_LPR = 3;
+        constexpr uint32_t F = VEC << LOG_LPR;
+        const uint32_t nslices = (h + F - 1) / F;
+        const size_t need = (size_t)p->ncols * nslices * F * sizeof(T);
+        void *xs = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx.mu);
+            Context::XsBuf *b = nullptr;
+            if (int rc = xs_buffer_locked(st, std::max<size_t>(need, 256), &b)) return rc;
+            b->src = nullptr;  // holds quantised values of a float matrix: never matched by x_unchanged
+            xs = b->ptr;
+        }
+        const uint64_t threads = (uint64_t)p->ncols * nslices * (1u << LOG_LPR);
+        hipLaunchKernelGGL((k_slice_pack_quant<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
+                           (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out);
+        HIP_TRY(hipGetLastError());
+        // running sums between panels (rows whose entries span several panels) live in the group's integer buffer
+        if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
+        g->pre_xs = xs;
+        g->deq_out = out;
+        g->deq_ld = (int64_t)h;
+        g->deq_amax = amax;
+        g->deq_log2 = log2_range;
+        g->packed_buf = nullptr;
+        const int rc = launch_block_main(g, *p, xs /* unused: pre_xs */, (int64_t)h, g->oq, (int64_t)h, (int64_t)h, false, st);
+        g->pre_xs = nullptr;
+        g->deq_out = nullptr;
+        return rc;
+    }
+    // unfused: quantise -> product -> dequantise as three steps
+    if (int rc = ensure(&g->xq, &g->xq_bytes, std::max<size_t>(rows * h * sizeof(T), 256))) return rc;
+    if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
+    if (int rc = launch_quantize<T>(X, ldx, rows, h, amax, log2_range, (T *)g->xq, scale_out, st)) return rc;
     // the group's own dense split, as windows into the row-major quantised matrix
     const size_t nd = g->parts[0].dense_cols.size();
     std::vector<const void *> win(nd);
@@ -1181,12 +1322,10 @@ int pygim_release(void) {
     }
     if (g_ctx.inited) (void)hipDeviceSynchronize();
     for (Group *g : gs) free_group(g);
-    for (auto &kv : g_ctx.xs_by_stream)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    g_ctx.xs_by_stream.clear();
-    g_ctx.xs = nullptr;
-
-    g_ctx.xs_src = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        free_xs_buffers_locked();
+    }
     g_ctx.inited = false;
     return 0;
 }
@@ -1224,7 +1363,6 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "panel_pack") slot = &g_tune.panel_pack;
     else if (n == "panel_coop") slot = &g_tune.panel_coop;
     else if (n == "panel_block") slot = &g_tune.panel_block;
-    else if (n == "xs_reuse") slot = &g_tune.xs_reuse;
     else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
@@ -1365,12 +1503,18 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
 int pygim_group_free(int64_t handle) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    bool last = false;
     {
         std::lock_guard<std::mutex> lk(g_ctx.mu);
         g_ctx.groups.erase(g);
+        last = g_ctx.groups.empty();
     }
     (void)hipDeviceSynchronize();
     free_group(g);
+    if (last) {  // the slice-major copies belong to the products of live groups: none left, none kept
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        free_xs_buffers_locked();
+    }
     return 0;
 }
 
@@ -1465,6 +1609,30 @@ int pygim_group_kernel_ms(int64_t handle, double *sum_ms, int64_t *count, int re
     return 0;
 }
 
+int pygim_group_kernel_events(int64_t handle, int on) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    g->kernel_events = on != 0;
+    return 0;
+}
+
+int pygim_group_plan(int64_t handle, int64_t out[8]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    int64_t ncoop = 0;
+    for (auto c : p.panel_coop) ncoop += c;
+    out[0] = p.d_items ? (int64_t)p.npanels : 0;
+    out[1] = p.panel_cols;
+    out[2] = (int64_t)p.n_items;
+    out[3] = p.col16 ? 1 : 0;
+    out[4] = ncoop;
+    out[5] = p.lp_panel.n_tasks;
+    out[6] = (g->merged && g->parts.size() > 1) ? 1 : 0;
+    out[7] = p.extra ? 1 : 0;
+    return 0;
+}
+
 int pygim_group_info(int64_t handle, int64_t out[8]) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
@@ -1481,25 +1649,40 @@ int pygim_group_info(int64_t handle, int64_t out[8]) {
     return 0;
 }
 
-int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t width,
-                    int accumulate, void *stream) {
+int pygim_block_run_x(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t width,
+                      int accumulate, int x_unchanged, void *stream) {
     if (int rc = need_init()) return rc;
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     if (part < 0 || part >= (int)g->parts.size()) return fail(PYGIM_ERR_INVALID, "part index out of range");
     if (!X || !C || width <= 0 || ldx < width || ldc < width) return fail(PYGIM_ERR_INVALID, "bad X/C/width/stride");
     if (!is_device_ptr(X) || !is_device_ptr(C)) return fail(PYGIM_ERR_INVALID, "pygim_block_run needs device pointers");
-    return launch_block_any(g, g->parts[part], X, ldx, C, ldc, width, accumulate != 0, (hipStream_t)stream);
+    g->x_unchanged = x_unchanged != 0;
+    const int rc = launch_block_any(g, g->parts[part], X, ldx, C, ldc, width, accumulate != 0, (hipStream_t)stream);
+    g->x_unchanged = false;
+    return rc;
 }
 
-int pygim_spmm_run_group(int64_t handle, const void *const *B_parts, void *out, void *stream) {
+int pygim_block_run(int64_t handle, int part, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t width,
+                    int accumulate, void *stream) {
+    return pygim_block_run_x(handle, part, X, ldx, C, ldc, width, accumulate, 0, stream);
+}
+
+int pygim_spmm_run_group_x(int64_t handle, const void *const *B_parts, void *out, int x_unchanged, void *stream) {
     if (int rc = need_init()) return rc;
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     for (auto &p : g->parts)
         if (p.dense_cols != g->parts[0].dense_cols)
             return fail(PYGIM_ERR_INVALID, "spmm_run_group needs the same dense split for every sparse part");
-    return run_group_common(g, B_parts, nullptr, false, out, (hipStream_t)stream);
+    g->x_unchanged = x_unchanged != 0;
+    const int rc = run_group_common(g, B_parts, nullptr, false, out, (hipStream_t)stream);
+    g->x_unchanged = false;
+    return rc;
+}
+
+int pygim_spmm_run_group(int64_t handle, const void *const *B_parts, void *out, void *stream) {
+    return pygim_spmm_run_group_x(handle, B_parts, out, 0, stream);
 }
 
 int pygim_grande_run_group(int64_t handle, const void *const *B_windows, const int64_t *window_ld, void *out,
@@ -1538,12 +1721,25 @@ int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out
     const size_t need_in = panel_bytes + (dev_in ? 0 : vec_bytes * nvec);
     if (int rc = ensure(&g->stage_in, &g->stage_in_bytes, std::max<size_t>(need_in, 256))) return rc;
     if (g->d_ptrs_n < nvec) {
-        if (g->d_ptrs) HIP_TRY(hipFree(g->d_ptrs));
+        if (g->d_ptrs) HIP_TRY(hipFree(g->d_ptrs));  // (waits for earlier packs)
         g->d_ptrs = nullptr;
-        HIP_TRY(hipMalloc((void **)&g->d_ptrs, nvec * sizeof(void *)));
+        HIP_TRY(hipMalloc((void **)&g->d_ptrs, 2 * nvec * sizeof(void *)));
         g->d_ptrs_n = nvec;
     }
-    std::vector<const void *> src(nvec);
+    // pointer table of the pack kernel: page-locked host memory, two slots used in turn, each released by an event
+    // recorded behind the pack kernel that read it -- device-pointer calls only enqueue work (no host sync)
+    if (g->h_ptrs_n < nvec) {
+        if (g->h_ptrs) HIP_TRY(hipHostFree(g->h_ptrs));
+        g->h_ptrs = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&g->h_ptrs, 2 * nvec * sizeof(void *), hipHostMallocDefault));
+        g->h_ptrs_n = nvec;
+        for (hipEvent_t &e : g->ev_ptrs)
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = g->ptr_slot;
+    g->ptr_slot ^= 1;
+    HIP_TRY(hipEventSynchronize(g->ev_ptrs[slot]));  // (a never-recorded event is complete)
+    const void **src = (const void **)(g->h_ptrs + (size_t)slot * g->h_ptrs_n);
     const double t0 = now_ms();
     for (size_t j = 0; j < nvec; j++) {
         if (dev_in) {
@@ -1554,17 +1750,17 @@ int pygim_spmv_run_group(int64_t handle, const void *const *B_vectors, void *out
             src[j] = d;
         }
     }
-    // pointer table is consumed by the pack kernel before this function can be re-entered
-    // on the same group; a synchronous copy keeps the host vector alive long enough
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(g->d_ptrs, src.data(), nvec * sizeof(void *), hipMemcpyHostToDevice));
+    if (!dev_in) HIP_TRY(hipStreamSynchronize(st));  // host mode: the upload time is reported
+    HIP_TRY(hipMemcpyAsync(g->d_ptrs + (size_t)slot * nvec, src, nvec * sizeof(void *), hipMemcpyHostToDevice, st));
     const double t1 = now_ms();
+    const void *const *tab = (const void *const *)(g->d_ptrs + (size_t)slot * nvec);
     switch (es) {
-        case 1: launch_pack<int8_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
-        case 2: launch_pack<int16_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
-        case 4: launch_pack<int32_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
-        case 8: launch_pack<int64_t>((const void *const *)g->d_ptrs, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 1: launch_pack<int8_t>(tab, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 2: launch_pack<int16_t>(tab, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 4: launch_pack<int32_t>(tab, (uint32_t)nvec, n, g->stage_in, st); break;
+        case 8: launch_pack<int64_t>(tab, (uint32_t)nvec, n, g->stage_in, st); break;
     }
+    HIP_TRY(hipEventRecord(g->ev_ptrs[slot], st));
     void *dout = out;
     if (!dev_out) {
         if (int rc = ensure(&g->stage_out, &g->stage_out_bytes, std::max<size_t>((size_t)g->total_rows * nvec * es, 256))) return rc;

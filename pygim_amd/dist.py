@@ -77,6 +77,15 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _collect(world):
+    """Do the collectives run?  Always on several ranks; on ONE rank only when a process group exists and
+    PYGIM_FORCE_COLLECTIVES=1 (the first-run check of the RCCL path on a single GPU: every all-gather / all-reduce of the
+    N > 1 code really executes at world size 1, tests/test_rccl_gpu.py)."""
+    import os
+
+    return world > 1 or (dist.is_initialized() and os.environ.get("PYGIM_FORCE_COLLECTIVES", "0") == "1")
+
+
 class RowSplitSpMM:
     def __init__(self, rowptr, col, values, ncols, dtype, h, group=None, balance="nnz", engine_factory=HipEngine):
         self.group = group
@@ -102,7 +111,7 @@ class RowSplitSpMM:
         buf = torch.empty((self.world, self.max_rows, self.h), dtype=self.dtype, device=x_full.device)
         mine = buf[self.rank]
         self.engine.run(x_full, mine[: self.r1 - self.r0])
-        if self.world > 1:
+        if _collect(self.world):
             dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self.group)
         if all(self.split[i + 1] - self.split[i] == self.max_rows for i in range(self.world)):
             return buf.view(self.world * self.max_rows, self.h)
@@ -119,7 +128,7 @@ class ColSplitSpMM:
     def mul(self, x_local_rows: torch.Tensor, reduce_scatter: bool = False) -> torch.Tensor:
         """partial = A[:, cols_r] . X[cols_r, :]; summed over ranks (spmm_mul_csr.c:491-502)."""
         part = self.engine.run(x_local_rows)
-        if self.world == 1:
+        if not _collect(self.world):
             return part
         if reduce_scatter and part.size(0) % self.world == 0:
             out = torch.empty((part.size(0) // self.world, part.size(1)), dtype=part.dtype, device=part.device)
@@ -150,7 +159,7 @@ class FeatureSplitSpMM:
     def gather(self, c_block: torch.Tensor) -> torch.Tensor:
         """Full C on every rank: all-gather of the feature blocks (staged [world, N, wmax], then
         laid side by side)."""
-        if self.world == 1:
+        if not _collect(self.world):
             return c_block
         wmax = max(self.widths)
         stage = torch.zeros((self.world, self.nrows, wmax), dtype=c_block.dtype, device=c_block.device)
@@ -195,7 +204,7 @@ class GridSpMM:
 
     def gather(self, c_block: torch.Tensor) -> torch.Tensor:
         """full C on every rank: one all-gather of padded [max_rows, max_width] tiles, then laid out"""
-        if self.world == 1:
+        if not _collect(self.world):
             return c_block
         mr = max(max(self.split[a + 1] - self.split[a] for a in range(self.row_parts)), 1)
         mw = max(self.widths)
@@ -238,7 +247,7 @@ class RowSplitAdj:
         self.max_rows = max(self.split[i + 1] - self.split[i] for i in range(self.world))
 
     def _gather(self, buf):
-        if self.world > 1:
+        if _collect(self.world):
             dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), group=self.group)
         if self.world == 1 or all(self.split[i + 1] - self.split[i] == self.max_rows for i in range(self.world)):
             return buf.view(self.world * self.max_rows, -1)[: self.nrows]
@@ -325,6 +334,8 @@ class RowShardAdj:
     compaction pass is needed.  Every output row is summed by one GPU in stored order: integers bit-exact and
     floats bit-identical to the one-GPU result, whatever the world size."""
 
+    row_sharded = True  # quantize.message_and_aggregate: x is a row block, the scale is global
+
     def __init__(self, rowptr, col, ncols, dtype, h, group=None, engine_factory=HipShardEngine):
         self.group = group
         self.world, self.rank = _world(group)
@@ -349,7 +360,7 @@ class RowShardAdj:
         return t[self.r0:self.r1]
 
     def _exchange(self, buf):
-        if self.world > 1:
+        if _collect(self.world):
             dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), group=self.group)
         return buf.view(self.world * self.max_rows, self.hidden_size)
 
@@ -364,7 +375,7 @@ class RowShardAdj:
         e = self.engine
         x_local = x_local.contiguous()
         bits = e.absmax_bits(x_local)
-        if self.world > 1:
+        if _collect(self.world):
             dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
         buf = self._buffer(self.dtype)
         e.quantize(x_local, bits, buf[self.rank][: self.my_rows])

@@ -95,7 +95,8 @@ def _to_device_group(fmt, idx0, colind, values, nrows, ncols, n_dense, dense_col
     # Python wrapper's self.csr / self.row_indices for the same purpose, spmm.py:52, 89-91)
     _groups[handle] = dict(keep=(idx0, colind, vals) if dev.type != "cpu" else (), dtype=dt,
                            rows=int(nrows[0]), cols=int(sum(ncols)), h=int(h_size),
-                           n_dense=[int(x) for x in n_dense], dense_cols=[int(x) for x in dense_cols])
+                           n_dense=[int(x) for x in n_dense], dense_cols=[int(x) for x in dense_cols],
+                           part_cols=[int(x) for x in ncols])
     return handle
 
 
@@ -191,9 +192,11 @@ def _grande_run_group(handle, B_parts):
     g = _group(handle)
     dev = _check_dense(g, B_parts, sum(g["n_dense"]))
     parts = [b.contiguous() for b in B_parts]
+    owner = [i for i, nd in enumerate(g["n_dense"]) for _ in range(nd)]  # sparse part of every window
     for k, b in enumerate(parts):
-        if b.dim() != 2 or b.size(1) < g["dense_cols"][k]:
-            raise RuntimeError(f"window {k} has shape {tuple(b.shape)}, narrower than its {g['dense_cols'][k]} columns")
+        if b.dim() != 2 or b.size(0) != g["part_cols"][owner[k]] or b.size(1) < g["dense_cols"][k]:
+            raise RuntimeError(f"window {k} has shape {tuple(b.shape)}, expected ({g['part_cols'][owner[k]]}, "
+                               f">= {g['dense_cols'][k]})")
     out = _new_out((g["rows"], g["h"]), g["dtype"], dev)
     _lib.grande_run_group(handle, [b.data_ptr() for b in parts], [b.size(1) for b in parts], out.data_ptr(),
                           _stream_of(out))

@@ -38,6 +38,14 @@ def message_and_aggregate(adj_t, x, fused=True):
     if isinstance(adj_t, SparseTensor):
         scale, x_q = symmetric_quantize(x, dtype=adj_t.dtype)
         return symmetric_dequantize(matmul(adj_t, x_q), 1., scale)
+    if getattr(adj_t, "row_sharded", False):
+        # row-sharded activations (pygim_amd.dist.RowShardAdj): x is this rank's row block, so the scale must be the
+        # GLOBAL max|x| (MAX all-reduce inside mul_quantized) -- quantising the local block on its own would give every
+        # rank a different scale.  Always the device quantiser, whatever `fused` says.
+        if adj_t.dtype not in (torch.int8, torch.int16, torch.int32, torch.float32):
+            raise RuntimeError(f"row-sharded aggregation needs an INT8/INT16/INT32/FLT32 adjacency, not {adj_t.dtype}")
+        out, _ = adj_t.mul_quantized(x)
+        return out
     if fused and x.is_cuda and x.dtype == torch.float32 and hasattr(adj_t, "mul_quantized") and \
             adj_t.dtype in (torch.int8, torch.int16, torch.int32, torch.float32):
         out, _ = adj_t.mul_quantized(x)

@@ -31,18 +31,15 @@ for K, nstreams in ((1, 1), (2, 1), (4, 1), (2, 2), (4, 2), (4, 4)):
     def step():
         if nstreams == 1:
             for c in range(K):
-                _lib.set_tunable("xs_reuse", 1 if c else 0)
-                _lib.spmm_run_group(hs[c], [x.data_ptr()], outs[c].data_ptr(), main.cuda_stream)
+                _lib.spmm_run_group(hs[c], [x.data_ptr()], outs[c].data_ptr(), main.cuda_stream, x_unchanged=c > 0)
             return
         # piece 0 packs X on the main stream; the other pieces wait for it, then run on side streams
-        _lib.set_tunable("xs_reuse", 0)
         _lib.spmm_run_group(hs[0], [x.data_ptr()], outs[0].data_ptr(), main.cuda_stream)
         ev = torch.cuda.Event(); ev.record(main)   # (conservative: after piece 0 entirely)
-        _lib.set_tunable("xs_reuse", 1)
         for c in range(1, K):
             s = streams[c % nstreams]
             s.wait_event(ev)
-            _lib.spmm_run_group(hs[c], [x.data_ptr()], outs[c].data_ptr(), s.cuda_stream)
+            _lib.spmm_run_group(hs[c], [x.data_ptr()], outs[c].data_ptr(), s.cuda_stream, x_unchanged=True)
         for s in streams:
             main.wait_stream(s)
     for _ in range(3):

@@ -15,8 +15,14 @@ import oracle  # noqa: E402
 from conftest import driver_features, random_csr  # noqa: E402
 from pygim_amd import dist as pd  # noqa: E402
 
-torch.cuda.set_device(0)
-dist.init_process_group("gloo")
+backend = os.environ.get("PYGIM_BENCH_BACKEND", "gloo")
+if backend == "nccl":  # RCCL: one rank per GPU (on a one-GPU box: one rank, collectives forced on by PYGIM_FORCE_COLLECTIVES=1)
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(lr)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+else:
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
 world, rank = dist.get_world_size(), dist.get_rank()
 rng = np.random.default_rng(321)
 n, h = 1500, 96
@@ -44,6 +50,10 @@ loc.sort_indices()
 cs = pd.ColSplitSpMM(torch.from_numpy(loc.indptr.astype(np.int32)), torch.from_numpy(loc.indices.astype(np.int32)),
                      torch.from_numpy(loc.data.astype(np.int32)), n, c1 - c0, torch.int32, h)
 assert np.array_equal(cs.mul(xd[c0:c1].contiguous()).cpu().numpy(), ref), "column split"
+if n % world == 0 and backend == "nccl":  # (gloo has no reduce_scatter_tensor)
+    part = cs.mul(xd[c0:c1].contiguous(), reduce_scatter=True)  # reduce-scatter form of the same merge
+    r0 = rank * (n // world)
+    assert np.array_equal(part.cpu().numpy(), ref[r0:r0 + n // world]), "column split, reduce-scatter"
 xf = rng.standard_normal((n, h)).astype(np.float32)
 for tdt, npdt in ((torch.int8, np.int8), (torch.int32, np.int32)):
     s_ref, xq_ref = oracle.symmetric_quantize(xf, npdt)

@@ -1,0 +1,74 @@
+"""pygim_amd/autotune.py against measurement: the per-GPU product times the chooser prices -- row
+shares 1/1, 1/2, 1/4, 1/8 of the Reddit-shaped graph at h = 256 (sp_parts as a row split) and feature windows of
+128 / 64 / 32 features (ds_parts) -- are timed on this GPU and must be within 25 % of `product_seconds`.  The reference's
+autotuner (utils/autotuner.py:263-343) prices from calibration constants in the same way; its constants are UPMEM's."""
+import os
+import sys
+
+import pytest
+import torch
+
+from pygim_amd import _lib, autotune, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _time_product(hd, x, out, reps=8):
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        a.record()
+        _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st)
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2] * 1e-3
+
+
+def test_product_model_within_25_percent_of_measured_shares(capsys):
+    from bench import nnz_balanced_row_split
+
+    dev = torch.device("cuda", 0)
+    n, nnz, dmax = synth.SHAPES["reddit"]
+    rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
+    rp_cpu = rowptr.cpu()
+    _lib.init_ranks(1)
+    rows = []
+    try:
+        cases = [("rows 1/%d, h=256" % f, f, 256) for f in (1, 2, 4, 8)] + [("all rows, h=%d" % h, 1, h) for h in (128, 64, 32)]
+        for name, frac, h in cases:
+            top = nnz_balanced_row_split(rp_cpu, frac)[1]
+            m = int(rp_cpu[top])
+            x = synth.features(n, h, torch.float32, seed=0, device=dev)
+            out = torch.empty((top, h), dtype=torch.float32, device=dev)
+            hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [top], [n], [m], [1], [h], h)
+            t = _time_product(hd, x, out)
+            _lib.group_free(hd)
+            pred, _panel = autotune.product_seconds(top, n, m, h, 4)
+            rows.append((name, t, pred))
+    finally:
+        _lib.release()
+    with capsys.disabled():
+        for name, t, pred in rows:
+            print(f"\\n[autotune] {name:22s} measured {t * 1e3:7.3f} ms   model {pred * 1e3:7.3f} ms   ratio {pred / t:5.2f}", end="")
+        print()
+    for name, t, pred in rows:
+        assert abs(pred - t) <= 0.25 * t, (name, t, pred)
+
+
+def test_choice_follows_the_measured_ranking():
+    """with products alone (no collective), 8 GPUs: papers100M-shaped h = 128 prefers a grid that keeps gathered rows at
+    128 bytes or more over the 1 x 8 feature split; Reddit h = 256 prefers splitting rows (panel sweep keeps its rate)"""
+    n, nnz, _ = synth.SHAPES["ogbn-papers100M"]
+    best, table = autotune.choose(n, n, nnz, 128, 4, 8)
+    assert best.feat_parts <= 4, [(c.row_parts, c.feat_parts, round(c.seconds * 1e3, 2)) for c in table]
+    n, nnz, _ = synth.SHAPES["reddit"]
+    best, table = autotune.choose(n, n, nnz, 256, 4, 8)
+    assert best.row_parts * best.feat_parts == 8

@@ -141,3 +141,60 @@ def test_reddit_csr_other_types_h256(name):
         sample_rows_vs_oracle(rowptr, col, None, x, c, [(0, 200), (n - 100, n), (longest, longest + 1)])
     finally:
         _lib.group_free(hd)
+
+
+def sample_rows_compact(rowptr, col, x, out, rows):
+    """sampled row ranges against the oracle, with only the gathered rows of X copied to the host (X may be many GB)"""
+    for r0, r1 in rows:
+        lo, hi = int(rowptr[r0]), int(rowptr[r1])
+        sub_rp = (rowptr[r0:r1 + 1].to(torch.int64) - lo).cpu().numpy().astype(np.int32)
+        uniq, inv = torch.unique(col[lo:hi].long(), return_inverse=True)
+        ref = oracle.spmm_csr(sub_rp, inv.cpu().numpy().astype(np.int32), None, x[uniq].cpu().numpy())
+        assert np.array_equal(out[r0:r1].cpu().numpy(), ref), (r0, r1)
+
+
+def test_papers100m_per_gpu_slices_f32():
+    """configs[4] (ogbn-papers100M CSR, h = 128, FLT32 over 8 GPUs), the work of ONE GPU at full size:
+    (a) ds_parts = 8 feature split: all 111 M rows x 16 of the 128 features (64-byte rows: one panel, gathers straight
+        from the row-major X, 7.1 GB -> 64-bit gather offsets, AMODE 0);
+    (b) the 2 x 4 grid pygim_amd.autotune prefers: the first nnz-balanced half of the rows x 32 features (128-byte rows,
+        14.2 GB of X -> 64-bit offsets again).
+    Checked through size-independent properties: column-count checksum (exact: integer-valued features), determinism,
+    sampled rows against the oracle (first / last / longest rows), real-valued features within 1e-5 on sampled rows."""
+    from bench import nnz_balanced_row_split
+
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["ogbn-papers100M"]
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    deg = (rowptr[1:] - rowptr[:-1])
+    longest = int(torch.argmax(deg))
+    colcount = torch.bincount(col.long(), minlength=n).double()
+    quarters = nnz_balanced_row_split(rowptr.cpu(), 4)
+    half, quarter = quarters[2], quarters[1]
+    # (c) a 4 x 2 grid share: a quarter of the rows x 64 features = two 128-byte slices; the slice-major copy (28 GB) is
+    #     far beyond the 640 MiB slice group, so the slices are swept one launch at a time -- with 64-bit offsets
+    for name, nrows, h in (("1x8 feature split", n, 16), ("2x4 grid", half, 32), ("4x2 grid", quarter, 64)):
+        m = int(rowptr[nrows])
+        x = synth.features(n, h, torch.float32, seed=0, device=dev)
+        assert n * h * 4 > 2 ** 32, "this case is about operands beyond 4 GiB"
+        hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [nrows], [n], [m], [1], [h], h)
+        try:
+            plan = _lib.group_plan(hd)
+            assert plan["n_panels"] == 1 and plan["n_segment_tasks"] == 0, (name, plan)  # 14.5 entries per row: one-panel sweep
+            c = run(hd, x, nrows, h)
+            cc = colcount if nrows == n else torch.bincount(col[:m].long(), minlength=n).double()
+            assert torch.equal(c.double().sum(0), cc @ x.double()), name
+            assert torch.equal(run(hd, x, nrows, h), c), name
+            picks = [(0, 200), (nrows - 200, nrows)] + ([(longest, longest + 1)] if longest < nrows else [])
+            sample_rows_compact(rowptr, col, x, c, picks)
+            del c
+            xr = synth.features(n, h, torch.float32, seed=1, device=dev, kind="uniform")
+            cr = run(hd, xr, nrows, h)
+            for r in (0, nrows // 3, nrows - 1) + ((longest,) if longest < nrows else ()):
+                cols = col[int(rowptr[r]):int(rowptr[r + 1])].long()
+                ref = xr[cols].double().sum(0)
+                assert torch.all((cr[r].double() - ref).abs() <= 1e-5 * ref.abs() + 1e-6 * xr[cols].double().abs().sum(0)), (name, r)
+            del xr, cr
+        finally:
+            _lib.group_free(hd)
+        del x

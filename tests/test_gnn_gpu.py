@@ -222,3 +222,115 @@ def test_multi_gpu_layer_with_hip_engines_over_gloo(world):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert all(f"OK rank {k}" in r.stdout for k in range(world)), r.stdout[-2000:]
+
+
+class _Capture:
+    """adjacency wrapper that keeps what every aggregation saw and returned"""
+
+    def __init__(self, adj):
+        self.adj, self.dtype, self.calls = adj, adj.dtype, []
+
+    def mul_quantized(self, x):
+        out, scale = self.adj.mul_quantized(x)
+        self.calls.append((x.detach().clone(), out.detach().clone()))
+        return out, scale
+
+
+def test_reddit_gcn_three_layers_h256_flt32_full_size():
+    """configs[3] on one rank at full size: Reddit-shaped graph (232 965 nodes, 114.6 M edges), 3-layer GCN, h = 256, FLT32
+    adjacency.  Every layer's aggregation -- quantise (values kept as floats) -> A . x_q -> dequantise, one fused device
+    call -- is compared on sampled rows (first, last, longest) with the oracle's quantiser and CSR loop, within the
+    floating-point bar of the path (1e-5 of |A| . |x_q| . scale: sums of ~500 terms of size 2^19 round in float)."""
+    import oracle
+    from pygim_amd import synth
+    from pygim_amd.dist import RowSplitAdj
+
+    dev = torch.device("cuda", 0)
+    n, nnz, dmax = synth.SHAPES["reddit"]
+    h, fin, ncls = 256, 128, 41
+    rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
+    adj = _Capture(RowSplitAdj(rowptr, col, n, torch.float32, h))
+    try:
+        torch.manual_seed(1)
+        model = gnn.GCN(fin, h, ncls, num_layers=3).to(dev).eval()
+        torch.manual_seed(0)
+        x = torch.randn(n, fin, device=dev)
+        with torch.no_grad():
+            logits = model(x, adj, None)
+            again = model(x, _Capture(adj.adj), None)
+        assert logits.shape == (n, ncls) and torch.isfinite(logits).all()
+        assert torch.equal(logits, again)  # deterministic end to end
+        assert len(adj.calls) == 3
+        deg = (rowptr[1:] - rowptr[:-1])
+        longest = int(torch.argmax(deg))
+        rp = rowptr.to(torch.int64)
+        for layer, (xin, out) in enumerate(adj.calls):
+            s_ref, xq = oracle.symmetric_quantize(xin.cpu().numpy(), np.float32)
+            for r0, r1 in ((0, 64), (n - 64, n), (longest, longest + 1)):
+                lo, hi = int(rp[r0]), int(rp[r1])
+                sub_rp = (rp[r0:r1 + 1] - lo).cpu().numpy().astype(np.int32)
+                sub_col = col[lo:hi].cpu().numpy()
+                want = oracle.symmetric_dequantize(oracle.spmm_csr(sub_rp, sub_col, None, xq), 1.0, s_ref)
+                bound = 1e-5 * oracle.spmm_csr(sub_rp, sub_col, None, np.abs(xq)).astype(np.float64) * float(s_ref)
+                got = out[r0:r1].cpu().numpy().astype(np.float64)
+                assert np.all(np.abs(got - want.astype(np.float64)) <= bound + 1e-30), (layer, r0)
+    finally:
+        adj.adj._lib.release()
+
+
+def test_reddit_gcn_h256_flt32_two_ranks_equal_one_rank():
+    """configs[3], the sp_parts row split: inference.py on the Reddit-shaped graph, GCN 3 layers, h = 256, FLT32, with 2 ranks
+    (gloo, both on this GPU: row-sharded activations, MAX all-reduce of the scale, all-gather of the quantised blocks)
+    gives the one-rank logits"""
+    common = ["--dataset=Reddit", "--hidden_size=256", "--data_type=FLT32", "--version=spmm",
+              "--lib_path=./backend_pim/spmm_default/build/libbackend_pim.so"]
+    one, _ = _run_inference(1, common)
+    two, _ = _run_inference(2, common, {"PYGIM_BENCH_BACKEND": "gloo"})
+    assert abs(one[0] - two[0]) <= 1e-5 * abs(one[0]) and abs(one[1] - two[1]) <= 1e-5 * abs(one[1]), (one, two)
+
+
+@pytest.mark.parametrize("tdt", [torch.int8, torch.int16, torch.int32, torch.float32])
+@pytest.mark.parametrize("h", [256, 100, 37])
+def test_fused_quantised_aggregation_equals_the_three_steps(rng, tdt, h):
+    """pygim_quant_spmm_run on a graph with several column panels, wave-cooperative (long) items and empty rows: the fused
+    path (absmax -> quantising slice-major pack -> sweep whose last item per row dequantises) against the unfused three
+    steps (panel_mode = 2 at run time keeps the group's plan but sends the call down quantise / product / dequantise) --
+    bit for bit for the integer types; FLT32 sums round, so there the bar is 1e-5 of |A| . |x_q| . scale"""
+    from pygim_amd import _lib
+    from pygim_amd.pim_ops import DTYPE_CODE
+
+    n = 9000
+    rowptr, col = random_csr(rng, n, n, 30, long_rows=[(5, 6000), (77, 900), (n - 1, 2500)], empty_frac=0.05)
+    _lib.init_ranks(1)
+    old = _lib.set_tunable("panel_bytes", 128 * 1024)  # 1024 columns per panel -> 9 panels on this small graph
+    force = _lib.set_tunable("panel_mode", 1)
+    try:
+        rp, cl = torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda()
+        hd = _lib.group_create(_lib.CSR, DTYPE_CODE[tdt], [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [cl.numel()], [1], [h], h)
+        plan = _lib.group_plan(hd)
+        assert plan["n_panels"] >= 8 and plan["n_coop_items"] > 0
+        x = torch.from_numpy(rng.standard_normal((n, h + 3)).astype(np.float32) * 2.5).cuda()[:, :h]  # strided rows
+        out = torch.full((n, h), float("nan"), dtype=torch.float32, device="cuda")
+        scale = torch.zeros((), dtype=torch.float32, device="cuda")
+        _lib.quant_spmm_run(hd, x.data_ptr(), x.stride(0), out.data_ptr(), scale.data_ptr())
+        torch.cuda.synchronize()
+        _lib.set_tunable("panel_mode", 2)  # unfused: three steps
+        ref = torch.full((n, h), float("nan"), dtype=torch.float32, device="cuda")
+        scale2 = torch.zeros((), dtype=torch.float32, device="cuda")
+        _lib.quant_spmm_run(hd, x.data_ptr(), x.stride(0), ref.data_ptr(), scale2.data_ptr())
+        torch.cuda.synchronize()
+        _lib.set_tunable("panel_mode", 1)
+        assert torch.equal(scale, scale2) and not torch.isnan(out).any()
+        if tdt != torch.float32:
+            assert torch.equal(out, ref)
+        else:
+            import oracle
+
+            s_ref, xq = oracle.symmetric_quantize(x.cpu().numpy(), np.float32)
+            bound = 1e-5 * oracle.spmm_csr(rowptr, col, None, np.abs(xq)).astype(np.float64) * float(s_ref)
+            assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) <= 2 * bound + 1e-30)
+        _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("panel_bytes", old)
+        _lib.set_tunable("panel_mode", force)
+        _lib.release()

@@ -1,0 +1,90 @@
+"""First-run proof of the RCCL path on ONE GPU: bench.py, inference.py and pygim_amd/dist.py under
+torch.distributed.run with one rank, backend "nccl" (= RCCL) and PYGIM_FORCE_COLLECTIVES=1, so that the process group is
+created and every collective of the N > 1 code (all_gather_into_tensor, all_reduce MAX / SUM, reduce_scatter, barrier)
+really executes -- at world size 1.  Child processes only (no re-exec after GPU initialisation)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _torchrun(script, args, timeout=900):
+    env = dict(os.environ, PYGIM_FORCE_COLLECTIVES="1", PYGIM_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr=127.0.0.1",
+           f"--master-port={_free_port()}", os.path.join(ROOT, script)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return r.stdout
+
+
+def _bench_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("partition", ["pipelined", "row", "feature"])
+def test_bench_one_rank_over_rccl(partition):
+    """every exchange scheme of bench.py with its collectives running on RCCL: the gathered C is exact, the JSON line says
+    how many ranks RCCL saw and which candidate ran"""
+    d = _bench_line(_torchrun("bench.py", ["--gpus", "1", "--steps", "5", "--warmup", "2", "--partition", partition,
+                                           "--chunks", "2" if partition != "pipelined" else "0", "--no-cpu-baseline"]))
+    assert d["n_gpus"] == 1 and d["config"]["rccl_world"] == 1 and d["config"]["backend"] == "nccl"
+    assert d["check"].startswith("column-count checksum"), d.get("check")
+    assert d["config"]["ms_per_step_products_only"] > 0
+    assert d["config"]["candidate"].split(":")[0] in ("PipelinedRows", "Pieces", "FeaturePieces")
+
+
+def test_bench_torchrun_number_equals_plain_number():
+    """the N = 1 number under torch.distributed.run + RCCL (auto partition: the model's prior, then the node-timed choice)
+    against the plain `python bench.py`: same products (within 2 %), and the whole step -- which now includes an
+    all-gather of the 239 MB result at world size 1 -- within 10 %"""
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    p = _bench_line(plain.stdout)
+    t = _bench_line(_torchrun("bench.py", ["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]))
+    assert p["config"]["rccl_world"] == 0 and t["config"]["rccl_world"] == 1
+    assert t["config"]["candidates_timed_ms"], "auto partition timed its candidates"
+    assert abs(t["config"]["ms_per_step_products_only"] - p["ms_per_step"]) <= 0.02 * p["ms_per_step"], (t, p)
+    assert abs(t["ms_per_step"] - p["ms_per_step"]) <= 0.10 * p["ms_per_step"], (t["ms_per_step"], p["ms_per_step"])
+    assert abs(t["roofline"]["kernel_ms"] - p["roofline"]["kernel_ms"]) <= 0.02 * p["roofline"]["kernel_ms"]
+
+
+@pytest.mark.parametrize("dtype", ["INT8", "FLT32"])
+def test_inference_one_rank_over_rccl_equals_the_plain_run(dtype):
+    """inference.py row-sharded over RCCL at world size 1 (MAX all-reduce of the scale, all-gather of the quantised block,
+    SUM all-reduce of the statistics) gives the logits of the plain one-GPU run"""
+    args = ["--dataset=PubMed", "--model=gcn", "--num_layers=3", "--hidden_size=64", "--repeat=2", "--version=spmm",
+            f"--data_type={dtype}", "--lib_path=./backend_pim/spmm_default/build/libbackend_pim.so"]
+    out = _torchrun("inference.py", args)
+    assert "[DATA]rccl_world: 1" in out, out[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py")] + args, capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    get = lambda s: [float(ln.split(":")[1]) for ln in s.splitlines() if ln.startswith("[DATA]logits_checksum")]
+    a, b = get(out), get(r.stdout)
+    assert len(a) == 2 and len(b) == 2
+    assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, b)), (a, b)
+
+
+def test_dist_layer_one_rank_over_rccl():
+    """pygim_amd/dist.py (row / column / feature split, grid, row-sharded quantised aggregation) with its collectives on
+    RCCL at world size 1, against the oracle"""
+    out = _torchrun(os.path.join("tests", "dist_driver.py"), [])
+    assert "OK rank 0" in out, out[-2000:]
