@@ -815,7 +815,8 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
                         o.y = (float)acc.get(k + 1) * scale;
                         o.z = (float)acc.get(k + 2) * scale;
                         o.w = (float)acc.get(k + 3) * scale;
-                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(frow + k));
+                        if constexpr (VEC == 4) __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(frow + k));
+                        else *reinterpret_cast<f32x4_t *>(frow + k) = o;  // lines completed by several stores: let L2 merge them
                     }
                 } else {
 #pragma unroll
@@ -1202,7 +1203,15 @@ __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per BLOCK (thousands of same-address atomics serialise in L2: 0.38 ms for 60 M floats before, 0.05 after)
+    __shared__ uint32_t wmax[16];
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wmax[wv] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t k = 1; k < (blockDim.x + 63) / 64; k++) m = max(m, wmax[k]);
+        if (m) atomicMax(out, m);
+    }
 }
 template <typename T> struct Pack4 { T v[4]; } __attribute__((aligned(sizeof(T) * 4)));
 template <typename T, bool FLAT>

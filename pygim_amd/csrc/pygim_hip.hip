@@ -1159,7 +1159,7 @@ static int launch_absmax(const float *X, int64_t ldx, uint64_t rows, uint32_t w,
     if (!total) return 0;
     const bool flat = flat4(X, ldx, rows, w);
     const uint64_t work = flat ? total / 4 : total;
-    const unsigned grid = (unsigned)std::min<uint64_t>((work + 255) / 256, 8192);
+    const unsigned grid = (unsigned)std::min<uint64_t>((work + 255) / 256, 2048);  // 8 blocks per CU, grid-stride loop
     if (flat) hipLaunchKernelGGL(k_absmax_bits<true>, dim3(grid), dim3(256), 0, st, X, ldx, rows, w, amax);
     else hipLaunchKernelGGL(k_absmax_bits<false>, dim3(grid), dim3(256), 0, st, X, ldx, rows, w, amax);
     HIP_TRY(hipGetLastError());

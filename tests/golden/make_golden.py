@@ -58,8 +58,38 @@ def cross_check(fmt, rowptr, row, col, vals, x, y, exact):
             assert np.all(np.abs(y - yt) <= 1e-5 * scale + 1e-30)
 
 
+def torch_sparse_pin(fmt, rowptr, row, col, vals, x, y, exact):
+    """The reference's real version=cpu call (spmm_test.py:25: ``torch_sparse.matmul(adj_t, x)``), when that package can be
+    imported in the build container: returns "torch_sparse <version>" after checking the vector against it, else None
+    (then the fixture records pinned_by = "unpinned: ..." and DESIGN.md section 2 keeps saying so)."""
+    try:
+        import torch_sparse  # noqa: F401  (un-vendored, version-unpinned dependency of the reference, Libs/install_libs.sh:13)
+    except Exception:
+        return None
+    n = y.shape[0]
+    if fmt == "CSR":
+        r = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr.astype(np.int64)))
+    else:
+        r = row.astype(np.int64)
+    v = None if vals is None else torch.from_numpy(vals)
+    a = torch_sparse.SparseTensor(row=torch.from_numpy(r), col=torch.from_numpy(col.astype(np.int64)), value=v,
+                                  sparse_sizes=(n, x.shape[0]))
+    yt = torch_sparse.matmul(a, torch.from_numpy(x)).numpy()
+    if exact:
+        assert np.array_equal(y, yt.astype(y.dtype)), "oracle != torch_sparse.matmul"
+    else:
+        assert np.allclose(y, yt, rtol=1e-5, atol=0), "oracle vs torch_sparse.matmul beyond 1e-5 relative"
+    return f"torch_sparse {getattr(torch_sparse, '__version__', '?')}"
+
+
+PINNED_BY = {"last": None}
+
+
 def save(name, **kw):
     path = os.path.join(HERE, name + ".npz")
+    if name.startswith("spmm_"):
+        kw["pinned_by"] = PINNED_BY["last"] or ("unpinned: torch_sparse not importable in the build container; accepted on "
+                                                 "agreement of the oracle with scipy.sparse and torch.sparse.mm")
     np.savez_compressed(path, **kw)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -69,6 +99,7 @@ def emit(name, fmt, rowptr, col, x, vals=None, exact=True):
     if fmt == "CSR":
         y = oracle.spmm_csr(rowptr, col, vals, x)
         cross_check("CSR", rowptr, None, col, vals, x, y, exact)
+        PINNED_BY["last"] = torch_sparse_pin("CSR", rowptr, None, col, vals, x, y, exact)
         kw = dict(fmt="CSR", rowptr=rowptr, col=col, x=x, y=y)
         if vals is not None:
             kw["vals"] = vals
@@ -78,6 +109,7 @@ def emit(name, fmt, rowptr, col, x, vals=None, exact=True):
             v = (v * 0 + 1).astype(npdt) * vals[: len(v)]
         y = oracle.spmm_coo(r, c, v, x, len(rowptr) - 1)
         cross_check("COO", None, r, c, v, x, y, exact)
+        PINNED_BY["last"] = torch_sparse_pin("COO", None, r, c, v, x, y, exact)
         kw = dict(fmt="COO", row=r, col=c, vals=v, x=x, y=y, nrows=len(rowptr) - 1)
     save(name, **kw)
 
