@@ -165,6 +165,9 @@ int pygim_quant_absmax(const float *X, int64_t ldx, int64_t rows, int64_t width,
 int pygim_quantize(int dtype, const float *X, int64_t ldx, int64_t rows, int64_t width, const uint32_t *absmax_bits,
                    void *Xq, float *scale_out, void *stream);
 int pygim_dequantize(int dtype, const void *Q, int64_t n, const uint32_t *absmax_bits, float *out, void *stream);
+/* the last two of those steps in one sweep: out = float(A . Xq) * scale, Xq [total_cols, h] already quantised in the
+ * group's type (row stride ldx), the dequantisation done by the sweep's last store per row (no integer result matrix). */
+int pygim_spmm_run_dequant(int64_t handle, const void *Xq, int64_t ldx, float *out, const uint32_t *absmax_bits, void *stream);
 
 /* ---- introspection -----------------------------------------------------------
  * Milliseconds of the last host-pointer run, in the reference's Timer buckets

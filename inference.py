@@ -14,12 +14,12 @@ import os
 
 import torch
 
-from pygim_amd import gnn, pim_ops, synth
+from pygim_amd import gnn, pim_ops
 from pygim_amd.backend_pim.grande import prepare_pim_spmm_grande
 from pygim_amd.backend_pim.spmm import prepare_pim_spmm
 from pygim_amd.backend_pim.spmv import prepare_pim_spmv
 from pygim_amd.sparse_tensor import SparseTensor
-from spmm_test import DATASETS, TORCH_TYPES, load_ops
+from spmm_test import DATASETS, TORCH_TYPES, load_adjacency, load_ops
 
 
 @torch.no_grad()
@@ -104,14 +104,12 @@ def main(args):
             print(f"[DATA]rccl_world: {dist.get_world_size()}", flush=True)
             print(f"[DATA]partition_prior(row x feature): {best.row_parts} x {best.feat_parts}  (used: row-sharded "
                   f"{world} x 1, the arrangement the dense layers need)", flush=True)
-    n, nnz, dmax = DATASETS[args.dataset]
-    gen = "cuda" if torch.cuda.is_available() else "cpu"
-    rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=gen)
+    rowptr, col, n = load_adjacency(args)  # --datadir when the raw files are there, else the seeded synthetic graph
     torch.manual_seed(0)
     x = torch.randn(n, args.in_features)
     y = torch.randint(0, args.num_classes, (n,))
     data = {"x": x.to(args.device), "y": y.to(args.device), "edge_attr": None}
-    adj_t = SparseTensor(rowptr=rowptr.cpu().long(), col=col.cpu().long(), sparse_sizes=(n, n))
+    adj_t = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
     if args.version == "cpu":
         data["adj_t"] = adj_t
         data["x"], data["y"] = x, y
@@ -119,7 +117,7 @@ def main(args):
         # sp_parts = world as a row split with row-SHARDED activations (pygim_amd/dist.py RowShardAdj)
         from pygim_amd.dist import RowShardAdj
 
-        shard = RowShardAdj(rowptr.cpu(), col.cpu(), n, args.data_type, args.hidden_size)
+        shard = RowShardAdj(rowptr, col, n, args.data_type, args.hidden_size)
         data["adj_t"] = shard
         data["x"], data["y"] = shard.local_rows(data["x"]).contiguous(), shard.local_rows(data["y"]).contiguous()
     else:

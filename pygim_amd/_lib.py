@@ -17,7 +17,7 @@ EXPORTS = [
     "pygim_grande_run_group", "pygim_spmv_run_group", "pygim_block_run", "pygim_group_timers",
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
-    "pygim_group_kernel_events", "pygim_group_plan",
+    "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -72,6 +72,7 @@ def lib():
         L.pygim_quant_absmax.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
         L.pygim_quantize.argtypes = [c_int, vp, c_i64, c_i64, c_i64, vp, vp, vp, vp]
         L.pygim_dequantize.argtypes = [c_int, vp, c_i64, vp, vp, vp]
+        L.pygim_spmm_run_dequant.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_set_tunable.argtypes = [ctypes.c_char_p, c_i64]
         L.pygim_set_tunable.restype = c_i64
         _lib = L
@@ -209,6 +210,11 @@ def quantize(dtype, x_ptr, ldx, rows, width, bits_ptr, xq_ptr, scale_ptr=0, stre
 def dequantize(dtype, q_ptr, n, bits_ptr, out_ptr, stream=0):
     check(lib().pygim_dequantize(int(dtype), ctypes.c_void_p(q_ptr or None), int(n), ctypes.c_void_p(bits_ptr),
                                  ctypes.c_void_p(out_ptr or None), ctypes.c_void_p(stream or None)))
+
+
+def spmm_run_dequant(handle, xq_ptr, ldx, out_ptr, bits_ptr, stream=0):
+    check(lib().pygim_spmm_run_dequant(int(handle), ctypes.c_void_p(xq_ptr), int(ldx), ctypes.c_void_p(out_ptr),
+                                       ctypes.c_void_p(bits_ptr), ctypes.c_void_p(stream or None)))
 
 
 def quant_spmm_run(handle, x_ptr, ldx, out_ptr, scale_ptr=0, stream=0):

@@ -1274,6 +1274,39 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     return launch_dequantize<T>((const T *)g->oq, orows * h, amax, log2_range, out, st);
 }
 
+// A . Xq on ALREADY quantised features with the dequantisation in the sweep's last store (row-sharded multi-GPU
+// aggregation: the quantised blocks were exchanged between the ranks, pygim_amd/dist.py RowShardAdj)
+template <typename T>
+static int dequant_run_t(Group *g, const void *Xq, int64_t ldx, float *out, const uint32_t *amax, int log2_range, hipStream_t st) {
+    const uint64_t orows = (uint64_t)g->total_rows;
+    const uint32_t h = (uint32_t)g->h;
+    if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
+    Part *p = fusable_part<T>(g);
+    // the dequantising store rides the sweep's slice-major gather modes: whole 16-byte pieces (so that the copy is made from
+    // rows that are never over-read) and not the narrow-row shortcut that gathers from the caller's row-major matrix
+    constexpr uint32_t V = 16 / sizeof(T), F = V * 8;
+    const bool narrow_rowmajor = (h + F - 1) / F == 1 && (size_t)ldx * sizeof(T) < 128;
+    if (p && h % V == 0 && g_tune.panel_pack && !narrow_rowmajor) {
+        g->deq_out = out;
+        g->deq_ld = (int64_t)h;
+        g->deq_amax = amax;
+        g->deq_log2 = log2_range;
+        const int rc = launch_block_any(g, *p, Xq, ldx, g->oq, (int64_t)h, (int64_t)h, false, st);
+        g->deq_out = nullptr;
+        return rc;
+    }
+    const size_t nd = g->parts[0].dense_cols.size();
+    std::vector<const void *> win(nd);
+    std::vector<int64_t> lds(nd, ldx);
+    int64_t off = 0;
+    for (size_t j = 0; j < nd; j++) {
+        win[j] = (const char *)Xq + (size_t)off * sizeof(T);
+        off += g->parts[0].dense_cols[j];
+    }
+    if (int rc = run_group_common(g, win.data(), lds.data(), false, g->oq, st)) return rc;
+    return launch_dequantize<T>((const T *)g->oq, orows * h, amax, log2_range, out, st);
+}
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -1534,6 +1567,26 @@ int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out
         case PYGIM_INT32: return quant_run_t<int32_t>(g, X, ldx, out, scale_out, 20, st);
         case PYGIM_FLT32: return quant_run_t<float>(g, X, ldx, out, scale_out, 20, st);
         default: return fail(PYGIM_ERR_INVALID, "quantised run: group type must be INT8/INT16/INT32/FLT32");
+    }
+}
+
+int pygim_spmm_run_dequant(int64_t handle, const void *Xq, int64_t ldx, float *out, const uint32_t *absmax_bits, void *stream) {
+    if (int rc = need_init()) return rc;
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if (!Xq || !out || !absmax_bits || ldx < g->h) return fail(PYGIM_ERR_INVALID, "bad Xq / out / absmax / ldx");
+    if (!is_device_ptr(Xq) || !is_device_ptr(out) || !is_device_ptr(absmax_bits))
+        return fail(PYGIM_ERR_INVALID, "pygim_spmm_run_dequant needs device pointers");
+    for (auto &p : g->parts)
+        if (p.dense_cols != g->parts[0].dense_cols) return fail(PYGIM_ERR_INVALID, "needs one dense split for all parts");
+    const int k = quant_log2_range(g->dtype);
+    hipStream_t st = (hipStream_t)stream;
+    switch (g->dtype) {
+        case PYGIM_INT8: return dequant_run_t<int8_t>(g, Xq, ldx, out, absmax_bits, k, st);
+        case PYGIM_INT16: return dequant_run_t<int16_t>(g, Xq, ldx, out, absmax_bits, k, st);
+        case PYGIM_INT32: return dequant_run_t<int32_t>(g, Xq, ldx, out, absmax_bits, k, st);
+        case PYGIM_FLT32: return dequant_run_t<float>(g, Xq, ldx, out, absmax_bits, k, st);
+        default: return fail(PYGIM_ERR_INVALID, "dequantising run: group type must be INT8/INT16/INT32/FLT32");
     }
 }
 

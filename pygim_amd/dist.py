@@ -313,6 +313,10 @@ class HipShardEngine:
     def dequantize(self, q, bits, out):
         self._lib.dequantize(self.code, q.data_ptr(), q.numel(), bits.data_ptr(), out.data_ptr(), self._st())
 
+    def product_dequantized(self, xq_full, bits, out):
+        """out = float(A . xq) * scale in one sweep (the last store of every row dequantises)"""
+        self._lib.spmm_run_dequant(self.handle, xq_full.data_ptr(), xq_full.size(1), out.data_ptr(), bits.data_ptr(), self._st())
+
     def free(self):
         self._lib.group_free(self.handle)
 
@@ -380,10 +384,13 @@ class RowShardAdj:
         buf = self._buffer(self.dtype)
         e.quantize(x_local, bits, buf[self.rank][: self.my_rows])
         xq = self._exchange(buf)
-        out_q = e.empty((self.my_rows, self.hidden_size), self.dtype)
-        e.product(xq, out_q)
         out = e.empty((self.my_rows, self.hidden_size), torch.float32)
-        e.dequantize(out_q, bits, out)
+        if hasattr(e, "product_dequantized"):
+            e.product_dequantized(xq, bits, out)
+        else:  # engines without the fused sweep (the CPU test engine): product, then dequantise
+            out_q = e.empty((self.my_rows, self.hidden_size), self.dtype)
+            e.product(xq, out_q)
+            e.dequantize(out_q, bits, out)
         return out, bits
 
     def mul(self, x_local):

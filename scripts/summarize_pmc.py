@@ -42,7 +42,13 @@ if dom and (dom, "WRITE_SIZE") in agg:
     launches_per_product = int(os.environ.get("LAUNCHES_PER_PRODUCT", "0")) or (max(1, round(f_n / packs[0])) if packs else 1)
     hit = agg.get((dom, "TCC_HIT_sum"), [0, 1])
     miss = agg.get((dom, "TCC_MISS_sum"), [0, 1])
-    rec = {"kernel": dom, "hbm_bytes_per_launch": per_launch, "launches_per_product": launches_per_product,
+    import datetime
+    import socket
+
+    rec = {"collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "box": socket.gethostname(),
+           "command": "rocprofv3 --pmc <one counter group per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                      "(scripts/profile_pmc.sh)",
+           "kernel": dom, "hbm_bytes_per_launch": per_launch, "launches_per_product": launches_per_product,
            "hbm_bytes_per_product": per_launch * launches_per_product,
            "fetch_size_kib_avg": f_tot / f_n, "write_size_kib_avg": w_tot / w_n,
            "l2_hit_rate": hit[0] / max(hit[0] + miss[0], 1),

@@ -33,11 +33,27 @@ def ms_since(t0):
     return (datetime.datetime.now() - t0).total_seconds() * 1000
 
 
-def load_graph(args):
+def load_adjacency(args):
+    """adj_t as (rowptr, col, n) on the CPU: read from --datadir when the dataset's raw files are there (the layout the
+    reference's load_datasets roots produce, spmm_test.py:40-50; pygim_amd/datasets.py), else the seeded synthetic graph
+    with the dataset's node / edge counts"""
+    from pygim_amd import datasets
+
+    got = datasets.load_adjacency(args.datadir, args.dataset)
+    if got is not None:
+        rowptr, col, n = got
+        print(f"[INFO] {args.dataset}: adj_t read from {os.path.join(args.datadir, args.dataset)} ({n} nodes, {len(col)} edges)",
+              flush=True)
+        return torch.from_numpy(rowptr), torch.from_numpy(col), n
     n, nnz, dmax = DATASETS[args.dataset]
     gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
     rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=gen_dev)
-    adj_t = SparseTensor(rowptr=rowptr.cpu().long(), col=col.cpu().long(), sparse_sizes=(n, n))
+    return rowptr.cpu().long(), col.cpu().long(), n
+
+
+def load_graph(args):
+    rowptr, col, n = load_adjacency(args)
+    adj_t = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
     x = torch.randint(-2 ^ 6, 2 ^ 6, (n, args.hidden_size), dtype=args.data_type)  # the reference's generator, verbatim
     return adj_t, x
 

@@ -329,6 +329,20 @@ def test_fused_quantised_aggregation_equals_the_three_steps(rng, tdt, h):
             s_ref, xq = oracle.symmetric_quantize(x.cpu().numpy(), np.float32)
             bound = 1e-5 * oracle.spmm_csr(rowptr, col, None, np.abs(xq)).astype(np.float64) * float(s_ref)
             assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) <= 2 * bound + 1e-30)
+        # the two-step form used between ranks: quantise (exchange) -> product with the dequantising store
+        bits = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.quant_absmax(x.data_ptr(), x.stride(0), n, h, bits.data_ptr())
+        xq = torch.empty((n, h), dtype=tdt, device="cuda")
+        _lib.quantize(DTYPE_CODE[tdt], x.data_ptr(), x.stride(0), n, h, bits.data_ptr(), xq.data_ptr())
+        out3 = torch.full((n, h), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.spmm_run_dequant(hd, xq.data_ptr(), h, out3.data_ptr(), bits.data_ptr())
+        torch.cuda.synchronize()
+        if tdt != torch.float32:
+            assert torch.equal(out3, ref)
+        elif h % 4 == 0:
+            assert torch.equal(out3, out)  # same quantiser, same sweep order as the one-call form
+        else:
+            assert np.all(np.abs(out3.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) <= 2 * bound + 1e-30)
         _lib.group_free(hd)
     finally:
         _lib.set_tunable("panel_bytes", old)
