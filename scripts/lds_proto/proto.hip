@@ -80,58 +80,61 @@ __device__ __forceinline__ void consume_tile(uint32_t tile, uint32_t slice, uint
     }
 }
 
-// Flat variant: one software-pipelined loop over all blocks of a (wave, chunk); the accumulator of a
-// block is named by 4 bits carried in the block's first id (wave-uniform), selected with a scalar switch,
-// so that LDS reads run ahead across segment boundaries.
-template <int K>
-__device__ __forceinline__ void add_sel(f32x4 (&acc)[K], uint32_t j, const f32x4 &x0, const f32x4 &x1) {
-#define CASEJ(n)                      \
-    case n:                           \
-        if constexpr (K > n) {        \
-            acc[n] += x0;             \
-            acc[n] += x1;             \
-        }                             \
-        break;
-    switch (j) {
-        CASEJ(0) CASEJ(1) CASEJ(2) CASEJ(3) CASEJ(4) CASEJ(5) CASEJ(6) CASEJ(7)
-        CASEJ(8) CASEJ(9) CASEJ(10) CASEJ(11) CASEJ(12) CASEJ(13) CASEJ(14) CASEJ(15)
+// Window variant: the 8 lane groups of a wave no longer share ONE accumulator index.  During phase j a group works on its
+// row j or already on its row j + 1 (bit 15 of the step's id says which), so a group that finishes row j early does not wait
+// for the slowest one; a phase ends when every group has finished row j.  One 16-bit id per group and step.
+// exec-masked adds (the empty asm statements keep the compiler from turning the branch into two sums and eight selects)
+#define ADD_SEL(ID, X)                  \
+    if ((ID) & 0x8000u) {               \
+        asm volatile("" ::: "memory"); \
+        acc[j + 1] += (X);              \
+    } else {                            \
+        asm volatile("" ::: "memory"); \
+        acc[j] += (X);                  \
     }
-#undef CASEJ
-}
-
 template <int K, int NWC>
-__device__ __forceinline__ void consume_tile_flat(uint32_t tile, uint32_t slice, uint32_t wave, int grp, int li,
-                                                  const uint32_t *__restrict__ blk_off,
-                                                  const uint32_t *__restrict__ rowmap, uint32_t rowmap_base,
-                                                  float *__restrict__ C, int64_t ldc, uint32_t nchunks,
-                                                  uint32_t xbuf_bytes, uint32_t ids_base, uint32_t idb) {
-    f32x4 acc[K];
+__device__ __forceinline__ void consume_tile_win(uint32_t tile, uint32_t slice, uint32_t wave, int grp, int li,
+                                                 const uint32_t *__restrict__ blk_off, const uint8_t *__restrict__ seg_n,
+                                                 const uint32_t *__restrict__ rowmap, uint32_t rowmap_base,
+                                                 float *__restrict__ C, int64_t ldc, uint32_t nchunks,
+                                                 uint32_t xbuf_bytes, uint32_t ids_base, uint32_t idb) {
+    f32x4 acc[K + 1];
 #pragma unroll
-    for (int j = 0; j < K; j++) acc[j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j <= K; j++) acc[j] = f32x4{0, 0, 0, 0};
     __syncthreads();
     for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t wg = tile * nchunks + c;
         const uint32_t wseg = wg * NWC + wave;  // uniform
-        const uint32_t b0 = blk_off[wseg];
-        const uint32_t nb = blk_off[wseg + 1] - b0;
-        const uint32_t boff = b0 - blk_off[wg * NWC];
-        uint32_t ia = ids_base + (c & 1) * idb + (boff * 8 + grp) * 4;
+        const uint32_t boff = blk_off[wseg] - blk_off[wg * NWC];  // step offset inside this chunk's stream
+        const u32x4 nn = *reinterpret_cast<const u32x4 *>(seg_n + (size_t)wseg * 16);
+        uint32_t ia = ids_base + (c & 1) * idb + (boff * 8 + grp) * 2;
         const uint32_t lbase = (c & 1) * xbuf_bytes + li * 16;
-        auto ldid = [&](uint32_t off) { return *reinterpret_cast<const uint32_t *>(lds + ia + off); };
-        auto rd0 = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id & 0x3ffu) << 7) + lbase); };
-        auto rd1 = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id >> 16) << 7) + lbase); };
-        uint32_t cur0 = ldid(0), cur1 = ldid(32);
-        f32x4 a0 = rd0(cur0), a1 = rd1(cur0);
-        for (uint32_t b = 0; b < nb; b += 2) {
-            const uint32_t nx0 = ldid(64), nx1 = ldid(96);
-            ia += 64;
-            const f32x4 b0x = rd0(cur1), b1x = rd1(cur1);
-            add_sel<K>(acc, (__builtin_amdgcn_readfirstlane(cur0) >> 12) & 0xfu, a0, a1);
-            a0 = rd0(nx0);
-            a1 = rd1(nx0);
-            if (b + 1 < nb) add_sel<K>(acc, (__builtin_amdgcn_readfirstlane(cur1) >> 12) & 0xfu, b0x, b1x);
-            cur0 = nx0;
-            cur1 = nx1;
+        auto ldid = [&](uint32_t off) { return (uint32_t) * reinterpret_cast<const uint16_t *>(lds + ia + off); };
+        auto rdx = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id & 0x3ffu) << 7) + lbase); };
+        uint32_t q0 = ldid(0), q1 = ldid(16);
+        ia += 32;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const uint32_t nj = (nn[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            uint32_t t = 0;
+#pragma nounroll
+            for (; t + 2 <= nj; t += 2) {
+                const uint32_t c0 = q0, c1 = q1;
+                q0 = ldid(0);
+                q1 = ldid(16);
+                ia += 32;
+                const f32x4 x0 = rdx(c0), x1 = rdx(c1);
+                ADD_SEL(c0, x0)
+                ADD_SEL(c1, x1)
+            }
+            if (t < nj) {
+                const uint32_t c0 = q0;
+                q0 = q1;
+                q1 = ldid(0);
+                ia += 16;
+                const f32x4 x0 = rdx(c0);
+                ADD_SEL(c0, x0)
+            }
         }
         __syncthreads();
     }
@@ -177,8 +180,9 @@ __global__ __launch_bounds__((NWC + NWL) * 64) void k_lds(const char *__restrict
             // the chunk's id stream (all consumer waves, contiguous), 1 KiB pieces dealt to the loader waves
             const uint32_t wg = tile * nchunks + c;
             const uint32_t b0 = blk_off[wg * NWC], b1 = blk_off[(wg + 1) * NWC];
-            const uint32_t bytes = (b1 - b0) * 32 + 64;  // + the consumers' look-ahead
-            const char *isrc = stream + (size_t)b0 * 32 + lane * 16;
+            const uint32_t unit = FLAT ? 16u : 32u;  // bytes per stream unit: one step (window variant) or a block of two
+            const uint32_t bytes = (b1 - b0) * unit + 64;  // + the consumers' look-ahead
+            const char *isrc = stream + (size_t)b0 * unit + lane * 16;
             char *idst = lds + ids_base + (c & 1) * idb;
             for (uint32_t o = wl * 1024; o < bytes; o += NWL * 1024)
                 __builtin_amdgcn_global_load_lds((const GLB_AS void *)(isrc + o), (LDS_AS void *)(idst + o), 16, 0, 0);
@@ -193,13 +197,13 @@ __global__ __launch_bounds__((NWC + NWL) * 64) void k_lds(const char *__restrict
     }
     const uint32_t K = tileinfo[2 * tile], rmb = tileinfo[2 * tile + 1];
     if constexpr (FLAT) {
-#define ARGF tile, slice, wave, grp, li, blk_off, rowmap, rmb, C, ldc, nchunks, xbuf_bytes, ids_base, idb
+#define ARGF tile, slice, wave, grp, li, blk_off, seg_n, rowmap, rmb, C, ldc, nchunks, xbuf_bytes, ids_base, idb
         switch (K) {
-        case 1: consume_tile_flat<1, NWC>(ARGF); break;
-        case 2: consume_tile_flat<2, NWC>(ARGF); break;
-        case 4: consume_tile_flat<4, NWC>(ARGF); break;
-        case 8: consume_tile_flat<8, NWC>(ARGF); break;
-        default: consume_tile_flat<16, NWC>(ARGF); break;
+        case 1: consume_tile_win<1, NWC>(ARGF); break;
+        case 2: consume_tile_win<2, NWC>(ARGF); break;
+        case 4: consume_tile_win<4, NWC>(ARGF); break;
+        case 8: consume_tile_win<8, NWC>(ARGF); break;
+        default: consume_tile_win<16, NWC>(ARGF); break;
         }
 #undef ARGF
         return;

@@ -34,7 +34,7 @@ def plan_tiles(deg_sorted, n, KC, NWC, target, kmax=16):
     return tiles
 
 
-def build_schedule(rowptr, col, n, KC, NWC, target=44, kmax=16):
+def build_schedule(rowptr, col, n, KC, NWC, target=44, kmax=16, window=False):
     dev = col.device
     rp = rowptr.to(torch.int64)
     deg = rp[1:] - rp[:-1]
@@ -79,40 +79,72 @@ def build_schedule(rowptr, col, n, KC, NWC, target=44, kmax=16):
     del rk, start, first, e, row
     nseg = ntiles * nchunks * NWC * 16
     cnt = torch.bincount(key, minlength=nseg * 8).view(nseg, 8)
-    nsteps = cnt.max(1).values
-    del cnt
-    nblk = (nsteps + 1) // 2
-    assert int(nblk.max()) < 256
-    blk_start = torch.cumsum(nblk, 0) - nblk
-    total_blk = int(nblk.sum())
-    # every block's first id carries its accumulator index j in bits 12..15 (flat kernel variant)
-    jseg = torch.arange(nseg, device=dev) % 16
-    blk_j = torch.repeat_interleave(jseg, nblk)
-    blk_j = torch.cat([blk_j, torch.zeros(256, dtype=torch.int64, device=dev)])
-    def wrap16(v):
-        return (((v + 32768) % 65536) - 32768).to(torch.int16)
-    stream = torch.empty(((total_blk + 256), 8, 2), dtype=torch.int16, device=dev)
-    stream[:, :, 1] = KC
-    stream[:, :, 0] = wrap16(KC + (blk_j << 12))[:, None]
-    stream = stream.view(-1)
-    spos = ((blk_start[seg] + t // 2) * 8 + (key % 8)) * 2 + (t % 2)
-    idv = col.to(torch.int64) - chunk * KC
-    idv = torch.where(t % 2 == 0, idv + ((seg % 16) << 12), idv)
-    stream[spos] = wrap16(idv)
-    del idv, blk_j, jseg
-    del spos, t, key, seg, chunk
-    segn = nblk.view(-1, 16).to(torch.uint8).contiguous()
-    blk_off = torch.cat([blk_start.view(-1, 16)[:, 0], torch.tensor([total_blk], device=dev)]).contiguous()
+    if window:
+        # window schedule: during phase j a lane group works on its row j or already on row j + 1
+        c3 = cnt.view(-1, 16, 8)
+        nw = c3.shape[0]
+        F = torch.zeros((nw, 8), dtype=torch.int64, device=dev)
+        Pm1 = torch.zeros(nw, dtype=torch.int64, device=dev)
+        Pm2 = torch.zeros(nw, dtype=torch.int64, device=dev)
+        S_all = torch.empty((nw, 16, 8), dtype=torch.int64, device=dev)
+        P_all = torch.empty((nw, 16), dtype=torch.int64, device=dev)
+        for jj in range(16):
+            S = torch.maximum(F, Pm2[:, None])
+            F = S + c3[:, jj, :]
+            P = torch.maximum(Pm1, F.max(1).values)
+            S_all[:, jj] = S
+            P_all[:, jj] = P
+            Pm2, Pm1 = Pm1, P
+        del cnt, c3
+        nph = P_all.clone()
+        nph[:, 1:] -= P_all[:, :-1]
+        assert int(nph.max()) < 256
+        total_w = P_all[:, 15]
+        step_base = torch.cumsum(total_w, 0) - total_w
+        total_steps = int(total_w.sum())
+        stream = torch.full(((total_steps + 512), 8), KC, dtype=torch.int16, device=dev).view(-1)
+        wseg_e = seg // 16
+        j_e = seg % 16
+        g_e = key % 8
+        t_abs = S_all.view(-1)[seg * 8 + g_e] + t
+        prevP = torch.where(j_e > 0, P_all.view(-1)[wseg_e * 16 + torch.clamp(j_e - 1, min=0)], torch.zeros_like(t_abs))
+        bit = (t_abs < prevP).to(torch.int64)
+        idv = (col.to(torch.int64) - chunk * KC) + (bit << 15)
+        stream[(step_base[wseg_e] + t_abs) * 8 + g_e] = (((idv + 32768) % 65536) - 32768).to(torch.int16)
+        del idv, t_abs, prevP, bit, wseg_e, j_e, g_e, t, key, seg, chunk
+        segn = nph.to(torch.uint8).contiguous()
+        blk_off = torch.cat([step_base, torch.tensor([total_steps], device=dev)]).contiguous()
+        nblk = nph  # per-tile statistics below count steps
+        total_blk = total_steps
+        unit_steps, unit_bytes = 1, 16
+    else:
+        unit_steps, unit_bytes = 2, 32
+        nsteps = cnt.max(1).values
+        del cnt
+        nblk = (nsteps + 1) // 2
+        assert int(nblk.max()) < 256
+        blk_start = torch.cumsum(nblk, 0) - nblk
+        total_blk = int(nblk.sum())
+        # every block's first id carries its accumulator index j in bits 12..15 (flat kernel variant)
+        stream = torch.empty(((total_blk + 256), 8, 2), dtype=torch.int16, device=dev)
+        stream[:, :, 1] = KC
+        stream[:, :, 0] = KC
+        stream = stream.view(-1)
+        spos = ((blk_start[seg] + t // 2) * 8 + (key % 8)) * 2 + (t % 2)
+        stream[spos] = (col.to(torch.int64) - chunk * KC).to(torch.int16)
+        del spos, t, key, seg, chunk
+        segn = nblk.view(-1, 16).to(torch.uint8).contiguous()
+        blk_off = torch.cat([blk_start.view(-1, 16)[:, 0], torch.tensor([total_blk], device=dev)]).contiguous()
     assert total_blk < 2 ** 32
     per_wg = blk_off[::NWC]
     per_wg = per_wg[1:] - per_wg[:-1]
     stats = {
-        "ntiles": ntiles, "nchunks": nchunks, "total_steps": total_blk * 2,
-        "slot_eff": nnz / (total_blk * 2 * 8.0),
-        "steps_per_tile": (nblk.view(ntiles, -1).sum(1) * 2).tolist(),
+        "ntiles": ntiles, "nchunks": nchunks, "total_steps": total_blk * unit_steps,
+        "slot_eff": nnz / (total_blk * unit_steps * 8.0),
+        "steps_per_tile": (nblk.view(ntiles, -1).sum(1) * unit_steps).tolist(),
         "nnz_per_tile": torch.bincount(tile_e, minlength=ntiles).tolist(),
         "K": [t[1] for t in tiles],
-        "max_ids_bytes": int(per_wg.max()) * 32 + 64,
+        "max_ids_bytes": int(per_wg.max()) * unit_bytes + 64,
     }
     return (blk_off.to(torch.uint32), segn, stream, rowmap.to(torch.int32), tileinfo, stats)
 
@@ -141,7 +173,7 @@ def main():
     X = synth.features(n, h, torch.float32, seed=0, device=dev)
     KC, NWC, NWL = args.kc, args.nwc, args.nwl
     t0 = time.time()
-    blk_off, segn, stream, rowmap, tileinfo, st = build_schedule(rowptr, col, n, KC, NWC, args.target, args.kmax)
+    blk_off, segn, stream, rowmap, tileinfo, st = build_schedule(rowptr, col, n, KC, NWC, args.target, args.kmax, window=bool(args.flat))
     torch.cuda.synchronize()
     print(f"schedule: {time.time() - t0:.1f}s tiles {st['ntiles']} chunks {st['nchunks']} max ids bytes {st['max_ids_bytes']} "
           f"steps {st['total_steps']} slot efficiency {st['slot_eff']:.3f} stream {stream.numel() * 2 / 1e6:.0f} MB")
