@@ -95,5 +95,38 @@ else:
     ops.dpu_init_ranks(8)
     A = spmv.prepare_pim_spmv(adj, types.SimpleNamespace(data_type=torch.int32, sp_format="COO", sp_parts=1, ds_parts=8))
     assert np.array_equal(A.mul(x).numpy(), ref) and np.array_equal(A.mul(x.cuda()).cpu().numpy(), ref)
+
+
+# the shim validates what it hands to the C side (round-1 advisor finding: part count / shapes were unchecked there)
+def must_raise(fn, what):
+    try:
+        fn()
+    except RuntimeError as e:
+        assert what in str(e), (what, str(e)[:300])
+        return
+    raise SystemExit(f"no error for: {what}")
+
+
+xd = x.cuda()
+if variant == "spmm":
+    blocks = list(torch.chunk(xd, 2, dim=1))
+    must_raise(lambda: ops.spmm_coo_run_group(A.sp_info_ptr, blocks[:1]), "expected 2 dense parts, got 1")
+    must_raise(lambda: ops.spmm_coo_run_group(A.sp_info_ptr, [blocks[0], blocks[1][:-7]]), "dense part 1 has shape")
+    must_raise(lambda: ops.spmm_coo_run_group(A.sp_info_ptr, [blocks[0], blocks[1][:, :-1]]), "dense part 1 has shape")
+    must_raise(lambda: ops.spmm_coo_run_group(A.sp_info_ptr, [blocks[0], blocks[1].long()]), "expected scalar type")
+elif variant == "grande":
+    wins = []
+    for i, block in enumerate(torch.split(xd, [p.size(1) for p in A.csr], dim=0)):
+        wins += grande.dense_split(block, A.dense_ncols[i])
+    assert np.array_equal(ops.spmm_csr_run_group(A.sp_info_ptr, wins).cpu().numpy(), ref)
+    must_raise(lambda: ops.spmm_csr_run_group(A.sp_info_ptr, wins[:-1]), "dense parts, got")
+    must_raise(lambda: ops.spmm_csr_run_group(A.sp_info_ptr, wins[:-1] + [wins[-1][:-3]]), "has shape")
+else:
+    want = A.coo[0].size(1)
+    vecs = [torch.zeros(want, 1, dtype=torch.int32, device="cuda") for _ in range(8)]
+    must_raise(lambda: ops.spmv_coo_run_group(A.sp_info_ptr, vecs[:5]), "expected 8 dense parts, got 5")
+    must_raise(lambda: ops.spmv_coo_run_group(A.sp_info_ptr, vecs[:7] + [vecs[7][:-2]]), "elements, expected")
+    out = ops.spmv_coo_run_group(A.sp_info_ptr, vecs)
+    assert tuple(out.shape) == (A.coo[0].size(0), 8)
 ops.dpu_release()
 print("OK gpu")

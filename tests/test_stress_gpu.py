@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import ALL_DTYPES, NP_DTYPES, coalesce, driver_features
+from conftest import ALL_DTYPES, NP_DTYPES, coalesce, driver_features, random_csr
 from pygim_amd import _lib
 from test_parity_gpu import run_group_host
 
@@ -223,3 +223,43 @@ def test_group_create_free_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (32 << 20), (free0, free1)
+
+
+def test_more_streams_than_slice_major_buffers(rng):
+    """the slice-major copies live in at most four per-(device, stream) buffers (least recently used goes first): products on
+    six streams in turn, each on its own X, stay correct; then the explicit x_unchanged argument shares one stream's copy with
+    another stream (ordered by an event) and a product on a REWRITTEN X without the flag sees the new contents"""
+    n, h = 3000, 256
+    rowptr, col = random_csr(rng, n, n, 40, long_rows=[(11, 5000)])
+    rp, cl = torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda()
+    if True:
+        hd = _lib.group_create(_lib.CSR, _lib.INT32, [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [cl.numel()], [1], [h], h)
+        streams = [torch.cuda.Stream() for _ in range(6)]
+        xs = [torch.from_numpy(driver_features(rng, n, h, np.int32)).cuda() for _ in range(6)]
+        refs = [oracle.spmm_csr(rowptr, col, None, x.cpu().numpy()) for x in xs]
+        outs = [torch.empty((n, h), dtype=torch.int32, device="cuda") for _ in range(6)]
+        torch.cuda.synchronize()
+        for rnd in range(3):
+            for k in range(6):
+                with torch.cuda.stream(streams[k]):
+                    _lib.spmm_run_group(hd, [xs[k].data_ptr()], outs[k].data_ptr(), streams[k].cuda_stream)
+                torch.cuda.synchronize()  # one group serves one call at a time
+                assert np.array_equal(outs[k].cpu().numpy(), refs[k]), (rnd, k)
+        # share stream 0's copy of xs[0] with stream 1
+        with torch.cuda.stream(streams[0]):
+            _lib.spmm_run_group(hd, [xs[0].data_ptr()], outs[0].data_ptr(), streams[0].cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(streams[0])
+        torch.cuda.synchronize()
+        streams[1].wait_event(ev)
+        with torch.cuda.stream(streams[1]):
+            _lib.spmm_run_group(hd, [xs[0].data_ptr()], outs[1].data_ptr(), streams[1].cuda_stream, x_unchanged=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(outs[1].cpu().numpy(), refs[0])
+        # rewrite X in place: without the flag the copy is made again
+        xs[0].copy_(xs[3])
+        with torch.cuda.stream(streams[1]):
+            _lib.spmm_run_group(hd, [xs[0].data_ptr()], outs[1].data_ptr(), streams[1].cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(outs[1].cpu().numpy(), refs[3])
+        _lib.group_free(hd)
