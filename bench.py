@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
+L2_PEAK_TBS = 128 * 64 * 2.4e9 / 1e12  # 8 XCDs x 16 L2 channels x 64 B/clk at 2.4 GHz = 19.66 TB/s
 
 
 def nnz_balanced_row_split(rowptr_cpu, nparts):
@@ -559,7 +560,14 @@ def main():
                 "launches_per_product": max(n_panels, 1),
                 "algorithmic_bytes": alg_bytes,
                 "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
-                "fp32_frac": round(synth.flops(my_nnz, my_h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None}
+                "fp32_frac": round(synth.flops(my_nnz, my_h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None,
+                # what actually bounds the sweep (profiles/r01_pmc_summary.txt: TCC_BUSY = 97 % of the launch, 0.5 requests per
+                # cycle and L2 channel): every stored entry pulls one 128-byte line per feature slice out of the L2, whose 128
+                # channels deliver 64 B/clk each
+                "l2": {"gather_bytes": synth.gather_bytes(my_rows, my_nnz, my_h, 4),
+                       "achieved_TBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
+                       "peak_TBs": L2_PEAK_TBS,
+                       "frac": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4) if k_ms else None}}
 
     result = {
         "metric": "SpMM GFLOP/s, Reddit-shaped CSR h=256 fp32", "value": round(gflops, 2), "unit": "GFLOP/s",
