@@ -561,9 +561,9 @@ def main():
                 "algorithmic_bytes": alg_bytes,
                 "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
                 "fp32_frac": round(synth.flops(my_nnz, my_h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None,
-                # what actually bounds the sweep (profiles/r01_pmc_summary.txt: TCC_BUSY = 97 % of the launch, 0.5 requests per
-                # cycle and L2 channel): every stored entry pulls one 128-byte line per feature slice out of the L2, whose 128
-                # channels deliver 64 B/clk each
+                # the level the sweep actually works at (profiles/r02_pmc_summary.txt: TCC_BUSY = 97 % of the launch, one 128-byte
+                # request per L2 channel every two cycles): every stored entry pulls one 128-byte line per feature slice out of
+                # the L2; the reference rate is 128 channels x 64 B/clk
                 "l2": {"gather_bytes": synth.gather_bytes(my_rows, my_nnz, my_h, 4),
                        "achieved_TBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
                        "peak_TBs": L2_PEAK_TBS,
