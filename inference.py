@@ -71,6 +71,8 @@ def get_args():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--nr_dpus", type=int, default=0)
     ap.add_argument("--device", type=str, default="cuda" if torch.cuda.is_available() else "cpu")
+    ap.add_argument("--fuse_post", type=int, default=0, help="1 = GCN: bias + BatchNorm(eval) + ReLU folded into the "
+                    "aggregation's last store (same mathematics, one rounding sequence; not in the reference)")
     args = ap.parse_args()
     print(args, flush=True)
     args.data_type = TORCH_TYPES[args.data_type]
@@ -131,6 +133,7 @@ def main(args):
     Model = {"gcn": gnn.GCN, "gin": gnn.GIN, "sage": gnn.SAGE}[args.model]
     torch.manual_seed(1)
     model = Model(args.in_features, args.hidden_size, args.num_classes, args.num_layers).to(data["x"].device)
+    model.fuse_post = bool(args.fuse_post)
     for i in range(args.repeat):
         if rank == 0:
             print("-------------------- Model={} nrl={} Repeat={}--------------------".format(args.model, args.num_layers, i), flush=True)

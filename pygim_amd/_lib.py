@@ -18,6 +18,7 @@ EXPORTS = [
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
+    "pygim_quant_spmm_run_post",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -69,6 +70,7 @@ def lib():
         L.pygim_group_kernel_events.argtypes = [c_i64, c_int]
         L.pygim_group_plan.argtypes = [c_i64, p_i64]
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
+        L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
         L.pygim_quant_absmax.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
         L.pygim_quantize.argtypes = [c_int, vp, c_i64, c_i64, c_i64, vp, vp, vp, vp]
         L.pygim_dequantize.argtypes = [c_int, vp, c_i64, vp, vp, vp]
@@ -217,6 +219,10 @@ def spmm_run_dequant(handle, xq_ptr, ldx, out_ptr, bits_ptr, stream=0):
                                        ctypes.c_void_p(bits_ptr), ctypes.c_void_p(stream or None)))
 
 
-def quant_spmm_run(handle, x_ptr, ldx, out_ptr, scale_ptr=0, stream=0):
-    check(lib().pygim_quant_spmm_run(int(handle), ctypes.c_void_p(x_ptr), int(ldx), ctypes.c_void_p(out_ptr),
-                                     ctypes.c_void_p(scale_ptr or None), ctypes.c_void_p(stream or None)))
+def quant_spmm_run(handle, x_ptr, ldx, out_ptr, scale_ptr=0, stream=0, col_mul_ptr=0, col_add_ptr=0, relu=False):
+    """quantise -> aggregate -> dequantise; with ``col_mul_ptr`` / ``col_add_ptr`` (device float[h]) the per-column
+    epilogue out = col_mul * out + col_add (then ReLU) runs in the sweep's last store"""
+    check(lib().pygim_quant_spmm_run_post(int(handle), ctypes.c_void_p(x_ptr), int(ldx), ctypes.c_void_p(out_ptr),
+                                          ctypes.c_void_p(scale_ptr or None), ctypes.c_void_p(col_mul_ptr or None),
+                                          ctypes.c_void_p(col_add_ptr or None), 1 if relu else 0,
+                                          ctypes.c_void_p(stream or None)))

@@ -103,15 +103,25 @@ class SparseGroupBase:
         return [c.size(0) for c in self.coo], [c.size(1) for c in self.coo]
 
     # -- quantise -> aggregate -> dequantise in one device call (pygim_amd/quantize.py) ---------------
-    def mul_quantized(self, x: torch.Tensor):
+    def mul_quantized(self, x: torch.Tensor, post=None):
         """``dequantize(self.mul(quantize(x)))`` with models/quantize.py's arithmetic, on device.
-        x: float32 CUDA tensor [ncols, hidden_size].  Returns (out float32 [nrows, hidden_size], scale)."""
+        x: float32 CUDA tensor [ncols, hidden_size].  Returns (out float32 [nrows, hidden_size], scale).
+        ``post = (col_mul, col_add, relu)``: per-column epilogue ``out = col_mul * out + col_add`` (then ReLU) applied in
+        the sweep's last store (a GCN layer's bias + eval-mode BatchNorm + ReLU folded into one affine map)."""
         from .. import _lib
 
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) == self.hidden_size
         x = x.contiguous()
         out = torch.empty((self.raw.size(0), self.hidden_size), dtype=torch.float32, device=x.device)
         scale = torch.empty((), dtype=torch.float32, device=x.device)
+        mul_p = add_p = 0
+        relu = False
+        if post is not None:
+            col_mul, col_add, relu = post
+            col_mul = col_mul.to(x.device, torch.float32).contiguous()
+            col_add = col_add.to(x.device, torch.float32).contiguous()
+            assert col_mul.numel() == self.hidden_size and col_add.numel() == self.hidden_size
+            mul_p, add_p = col_mul.data_ptr(), col_add.data_ptr()
         _lib.quant_spmm_run(self.sp_info_ptr, x.data_ptr(), x.size(1), out.data_ptr(), scale.data_ptr(),
-                            torch.cuda.current_stream(x.device).cuda_stream)
+                            torch.cuda.current_stream(x.device).cuda_stream, mul_p, add_p, relu)
         return out, scale

@@ -634,7 +634,9 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
                                             const T *__restrict__ X, int64_t ldx, int64_t slice_stride,
                                             T *__restrict__ C, int64_t ldc, uint32_t w, uint32_t nslices,
                                             int accumulate, uint32_t col_base, float *__restrict__ Cf, int64_t ldcf,
-                                            const uint32_t *__restrict__ absmax_bits, int log2_range) {
+                                            const uint32_t *__restrict__ absmax_bits, int log2_range,
+                                            const float *__restrict__ post_mul, const float *__restrict__ post_add,
+                                            int post_relu) {
     static_assert(VEC * sizeof(T) == 16, "the sweep gathers 16-byte pieces");
     constexpr bool PACKED = !HAS_VALS && sizeof(T) < 4;
     constexpr int LPR = 8;   // lanes per 128-byte slice of a row
@@ -804,24 +806,36 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     if (lane_on && (!COOP || grp == 0)) {
         if constexpr (DEQ) {
             if (last) {
-                // scale_edge (1.) * scale_x, as k_dequantize
+                // scale_edge (1.) * scale_x, as k_dequantize; then the caller's per-column epilogue, if any:
+                // y = post_mul[f] * y + post_add[f], optionally max(y, 0)  (bias + eval-mode BatchNorm + ReLU of a GCN layer)
                 const float scale = 1.0f * quant_scale(*absmax_bits, log2_range);
                 float *frow = Cf + (int64_t)row * ldcf + f0;
+                float y[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; k++) y[k] = (float)acc.get(k) * scale;
+                if (post_mul) {
+#pragma unroll
+                    for (int k = 0; k < VEC; k++)
+                        if (f0 + k < w) {
+                            y[k] = post_mul[f0 + k] * y[k] + post_add[f0 + k];
+                            if (post_relu) y[k] = fmaxf(y[k], 0.0f);
+                        }
+                }
                 if (f0 + VEC <= w && ((reinterpret_cast<uintptr_t>(frow) & 15u) == 0)) {
 #pragma unroll
                     for (int k = 0; k < VEC; k += 4) {
                         f32x4_t o;
-                        o.x = (float)acc.get(k) * scale;
-                        o.y = (float)acc.get(k + 1) * scale;
-                        o.z = (float)acc.get(k + 2) * scale;
-                        o.w = (float)acc.get(k + 3) * scale;
+                        o.x = y[k];
+                        o.y = y[k + 1];
+                        o.z = y[k + 2];
+                        o.w = y[k + 3];
                         if constexpr (VEC == 4) __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t *>(frow + k));
                         else *reinterpret_cast<f32x4_t *>(frow + k) = o;  // lines completed by several stores: let L2 merge them
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < VEC; k++)
-                        if (f0 + k < w) frow[k] = (float)acc.get(k) * scale;
+                        if (f0 + k < w) frow[k] = y[k];
                 }
                 return;
             }
@@ -850,16 +864,18 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
                                                    int64_t ldx, int64_t slice_stride, T *__restrict__ C,
                                                    int64_t ldc, uint32_t w, uint32_t nslices, int accumulate,
                                                    uint32_t col_base, float *__restrict__ Cf, int64_t ldcf,
-                                                   const uint32_t *__restrict__ absmax_bits, int log2_range) {
+                                                   const uint32_t *__restrict__ absmax_bits, int log2_range,
+                                                   const float *__restrict__ post_mul, const float *__restrict__ post_add,
+                                                   int post_relu) {
     static_assert(LOG_LPR == 3, "lane groups of 8 (one 128-byte line per gathered row slice)");
     if (blockIdx.x < coop_grid)
         panel_sweep<T, VEC, AMODE, HAS_VALS, true, DEQ>(blockIdx.x, coop_row, coop_begin, coop_len, ncoop, colind, vals, X,
                                                         ldx, slice_stride, C, ldc, w, nslices, accumulate, col_base, Cf, ldcf,
-                                                        absmax_bits, log2_range);
+                                                        absmax_bits, log2_range, post_mul, post_add, post_relu);
     else
         panel_sweep<T, VEC, AMODE, HAS_VALS, false, DEQ>(blockIdx.x - coop_grid, item_row, item_begin, item_len, nitems,
                                                          colind, vals, X, ldx, slice_stride, C, ldc, w, nslices, accumulate,
-                                                         col_base, Cf, ldcf, absmax_bits, log2_range);
+                                                         col_base, Cf, ldcf, absmax_bits, log2_range, post_mul, post_add, post_relu);
 }
 
 // Slice-major copy of X for the panel sweep: Xs[s][j][0:F] = X[j][s*F : (s+1)*F] (zero padded past
@@ -1234,6 +1250,16 @@ __global__ void k_quantize(const float *__restrict__ x, int64_t ld, uint64_t row
         if (i >= rows * w) return;
         xq[i] = (T)rintf(x[(i / w) * ld + (i % w)] / scale);
     }
+}
+// the same per-column epilogue as the sweep's fused store, for the unfused path: y = mul[f] * y + add[f], optional ReLU
+__global__ void k_post_affine(float *__restrict__ y, uint64_t rows, uint32_t w, const float *__restrict__ mul,
+                              const float *__restrict__ add, int relu) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    const uint32_t f = (uint32_t)(i % w);
+    float v = mul[f] * y[i] + add[f];
+    if (relu) v = fmaxf(v, 0.0f);
+    y[i] = v;
 }
 template <typename T, bool FLAT>
 __global__ void k_dequantize(const T *__restrict__ q, uint64_t n, const uint32_t *__restrict__ absmax_bits,

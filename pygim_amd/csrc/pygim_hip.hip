@@ -142,6 +142,8 @@ struct Group {
     int64_t deq_ld = 0;
     const uint32_t *deq_amax = nullptr;
     int deq_log2 = 0;
+    const float *post_mul = nullptr, *post_add = nullptr;  // per-column epilogue of the fused store (nullptr = none)
+    int post_relu = 0;
     // pinned pointer tables of the SpMV pack (two slots, each guarded by an event)
     void **h_ptrs = nullptr;
     size_t h_ptrs_n = 0;
@@ -513,7 +515,9 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                        ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid,                           \
                        (AM == 3 ? (const uint32_t *)p.col16 : p.colind), vals, Xs0, ldg,                                  \
                        slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0, q * p.panel_cols,                              \
-                       g->deq_out ? g->deq_out + (size_t)s0 * F : nullptr, g->deq_ld, g->deq_amax, g->deq_log2)
+                       g->deq_out ? g->deq_out + (size_t)s0 * F : nullptr, g->deq_ld, g->deq_amax, g->deq_log2,                  \
+                       g->post_mul ? g->post_mul + (size_t)s0 * F : nullptr, g->post_add ? g->post_add + (size_t)s0 * F : nullptr, \
+                       g->post_relu)
 #define PYGIM_LAUNCH_PANEL(AM, HV) PYGIM_LAUNCH_PANEL_D(AM, HV, false)
                 // addressing mode of the gathers (kernels.hpp gather_raw): 128-byte rows of the slice-major copy
                 // (with 16-bit panel-local column ids when the plan has them), any stride below 4 GiB, or 64-bit
@@ -1216,6 +1220,16 @@ static Part *fusable_part(Group *g) {
     return p;
 }
 
+static int launch_post(Group *g, float *out, hipStream_t st) {
+    if (!g->post_mul) return 0;
+    const uint64_t total = (uint64_t)g->total_rows * (uint64_t)g->h;
+    if (total)
+        hipLaunchKernelGGL(k_post_affine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, (uint64_t)g->total_rows,
+                           (uint32_t)g->h, g->post_mul, g->post_add, g->post_relu);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float *scale_out, int log2_range, hipStream_t st) {
     const uint64_t rows = (uint64_t)g->total_cols, orows = (uint64_t)g->total_rows;
@@ -1271,7 +1285,8 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
         off += g->parts[0].dense_cols[j];
     }
     if (int rc = run_group_common(g, win.data(), lds.data(), false, g->oq, st)) return rc;
-    return launch_dequantize<T>((const T *)g->oq, orows * h, amax, log2_range, out, st);
+    if (int rc = launch_dequantize<T>((const T *)g->oq, orows * h, amax, log2_range, out, st)) return rc;
+    return launch_post(g, out, st);
 }
 
 // A . Xq on ALREADY quantised features with the dequantisation in the sweep's last store (row-sharded multi-GPU
@@ -1552,9 +1567,23 @@ int pygim_group_free(int64_t handle) {
 }
 
 int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, void *stream) {
+    return pygim_quant_spmm_run_post(handle, X, ldx, out, scale_out, nullptr, nullptr, 0, stream);
+}
+
+int pygim_quant_spmm_run_post(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, const float *col_mul,
+                              const float *col_add, int relu, void *stream) {
     if (int rc = need_init()) return rc;
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if ((col_mul == nullptr) != (col_add == nullptr)) return fail(PYGIM_ERR_INVALID, "col_mul and col_add come together");
+    if (col_mul && (!is_device_ptr(col_mul) || !is_device_ptr(col_add))) return fail(PYGIM_ERR_INVALID, "epilogue vectors must be device memory");
+    struct PostGuard {
+        Group *g;
+        ~PostGuard() { g->post_mul = g->post_add = nullptr; g->post_relu = 0; }
+    } guard{g};
+    g->post_mul = col_mul;
+    g->post_add = col_add;
+    g->post_relu = col_mul ? relu : 0;
     if (!X || !out || ldx < g->h) return fail(PYGIM_ERR_INVALID, "bad X / out / ldx");
     if (!is_device_ptr(X) || !is_device_ptr(out) || (scale_out && !is_device_ptr(scale_out)))
         return fail(PYGIM_ERR_INVALID, "pygim_quant_spmm_run needs device pointers");

@@ -253,13 +253,19 @@ class RowSplitAdj:
             return buf.view(self.world * self.max_rows, -1)[: self.nrows]
         return torch.cat([buf[i, : self.split[i + 1] - self.split[i]] for i in range(self.world)], dim=0)
 
-    def mul_quantized(self, x):
+    def mul_quantized(self, x, post=None):
         assert x.is_cuda and x.dtype == torch.float32 and x.size(1) == self.hidden_size
         x = x.contiguous()
         buf = torch.empty((self.world, self.max_rows, self.hidden_size), dtype=torch.float32, device=x.device)
         scale = torch.empty((), dtype=torch.float32, device=x.device)
+        mul_p = add_p = 0
+        relu = False
+        if post is not None:  # per-column epilogue in the sweep's last store (see SparseGroupBase.mul_quantized)
+            col_mul, col_add, relu = post
+            col_mul, col_add = col_mul.to(x.device, torch.float32).contiguous(), col_add.to(x.device, torch.float32).contiguous()
+            mul_p, add_p = col_mul.data_ptr(), col_add.data_ptr()
         self._lib.quant_spmm_run(self.handle, x.data_ptr(), x.size(1), buf[self.rank].data_ptr(), scale.data_ptr(),
-                                 torch.cuda.current_stream(x.device).cuda_stream)
+                                 torch.cuda.current_stream(x.device).cuda_stream, mul_p, add_p, relu)
         return self._gather(buf), scale
 
     def mul(self, x):

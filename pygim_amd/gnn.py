@@ -50,7 +50,17 @@ class GINConv(torch.nn.Module):
         return self.nn(message_and_aggregate(adj_t, x) + (1 + self.eps) * x)
 
 
+def folded_epilogue(conv_bias, bn):
+    """bias + eval-mode BatchNorm as ONE affine map per feature: bn(y + bias) = a * y + b with
+    a = weight / sqrt(running_var + eps), b = (bias - running_mean) * a + bn.bias"""
+    a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    bias = conv_bias if conv_bias is not None else torch.zeros_like(bn.running_mean)
+    return a, (bias - bn.running_mean) * a + bn.bias
+
+
 class _Stack(torch.nn.Module):
+    fuse_post = False  # True: a GCN layer's "+ bias -> BatchNorm (eval) -> ReLU" runs in the aggregation's last store
+
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, make_conv):
         super().__init__()
         self.ln1 = Linear(in_channels, hidden_channels)
@@ -63,6 +73,13 @@ class _Stack(torch.nn.Module):
     def forward(self, x, adj_t, edge_attr=None):
         x = F.dropout(F.relu(self.bn0(self.ln1(x))), p=self.dropout, training=self.training)
         for conv, bn in zip(self.convs, self.bns):
+            if (self.fuse_post and not self.training and isinstance(conv, GCNConv) and x.is_cuda
+                    and hasattr(adj_t, "mul_quantized") and not getattr(adj_t, "row_sharded", False)
+                    and adj_t.dtype in (torch.int8, torch.int16, torch.int32, torch.float32)):
+                # same mathematics as the three torch ops below, one rounding sequence instead of three passes over [N, h]
+                a, b = folded_epilogue(conv.bias, bn)
+                x, _ = adj_t.mul_quantized(conv.lin(x), post=(a, b, True))
+                continue
             x = F.dropout(F.relu(bn(conv(x, adj_t))), p=self.dropout, training=self.training)
         return self.ln2(x)
 

@@ -348,3 +348,44 @@ def test_fused_quantised_aggregation_equals_the_three_steps(rng, tdt, h):
         _lib.set_tunable("panel_bytes", old)
         _lib.set_tunable("panel_mode", force)
         _lib.release()
+
+
+@pytest.mark.parametrize("tdt", [torch.int8, torch.float32])
+def test_gcn_with_the_epilogue_in_the_last_store(rng, tdt):
+    """fuse_post: a GCN layer's + bias -> BatchNorm (eval) -> ReLU as the per-column epilogue of the aggregation's fused
+    store.  Same mathematics as the three torch passes, another rounding sequence: 1e-5 relative on the logits; the
+    epilogue itself (pygim_quant_spmm_run_post) against the plain call + torch arithmetic in the same order: bit for bit."""
+    from pygim_amd.dist import RowSplitAdj
+
+    n, fin, h, ncls = 2500, 32, 96, 7
+    rowptr, col = random_csr(rng, n, n, 14, long_rows=[(3, 1800)], empty_frac=0.05)
+    adj = RowSplitAdj(torch.from_numpy(rowptr), torch.from_numpy(col), n, tdt, h)
+    try:
+        torch.manual_seed(5)
+        model = gnn.GCN(fin, h, ncls, num_layers=3).cuda().eval()
+        for bn in model.bns:  # non-trivial statistics
+            bn.running_mean.uniform_(-0.5, 0.5)
+            bn.running_var.uniform_(0.5, 2.0)
+            bn.weight.data.uniform_(0.5, 1.5)
+            bn.bias.data.uniform_(-0.3, 0.3)
+        for conv in model.convs:
+            conv.bias.data.uniform_(-0.2, 0.2)
+        x = torch.randn(n, fin, device="cuda")
+        with torch.no_grad():
+            ref = model(x, adj, None)
+            model.fuse_post = True
+            out = model(x, adj, None)
+            # (FLT32 quantises to 2^20 levels: a last-bit difference before the next layer's round() moves values by one level,
+            #  2e-6 of max|x|, and three layers of 14-term sums carry that to ~1e-4; INT8's 32 levels never flip here)
+            tol = 1e-5 if tdt == torch.int8 else 1e-3
+            assert torch.allclose(out, ref, rtol=tol, atol=tol), float((out - ref).abs().max())
+            # the epilogue alone, bit for bit
+            y = torch.randn(n, h, device="cuda")
+            a, b = torch.rand(h, device="cuda") + 0.5, torch.randn(h, device="cuda")
+            plain, _ = adj.mul_quantized(y)
+            fused, _ = adj.mul_quantized(y, post=(a, b, True))
+            assert torch.equal(fused, torch.relu(a * plain + b))
+            fused2, _ = adj.mul_quantized(y, post=(a, b, False))
+            assert torch.equal(fused2, a * plain + b)
+    finally:
+        adj._lib.release()
