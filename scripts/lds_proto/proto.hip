@@ -83,14 +83,27 @@ __device__ __forceinline__ void consume_tile(uint32_t tile, uint32_t slice, uint
 // Window variant: the 8 lane groups of a wave no longer share ONE accumulator index.  During phase j a group works on its
 // row j or already on its row j + 1 (bit 15 of the step's id says which), so a group that finishes row j early does not wait
 // for the slowest one; a phase ends when every group has finished row j.  One 16-bit id per group and step.
-// exec-masked adds (the empty asm statements keep the compiler from turning the branch into two sums and eight selects)
-#define ADD_SEL(ID, X)                  \
-    if ((ID) & 0x8000u) {               \
-        asm volatile("" ::: "memory"); \
-        acc[j + 1] += (X);              \
-    } else {                            \
-        asm volatile("" ::: "memory"); \
-        acc[j] += (X);                  \
+// exec-masked adds, hand-written: lanes whose id has bit 15 set (sign bit of the 16-bit load) add to acc[j + 1], the others
+// to acc[j]; one compare, four packed adds, three scalar moves -- no branches, no selects
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define ADD_SEL(ID, X)                                                                                              \
+    {                                                                                                               \
+        f32x2 a0l = {acc[j].x, acc[j].y}, a0h = {acc[j].z, acc[j].w};                                               \
+        f32x2 a1l = {acc[j + 1].x, acc[j + 1].y}, a1h = {acc[j + 1].z, acc[j + 1].w};                               \
+        const f32x2 xl = {(X).x, (X).y}, xh = {(X).z, (X).w};                                                       \
+        asm volatile("v_cmp_gt_i32 vcc, 0, %[id]\n\t"                                                               \
+                     "s_mov_b64 exec, vcc\n\t"                                                                      \
+                     "v_pk_add_f32 %[a1l], %[a1l], %[xl]\n\t"                                                       \
+                     "v_pk_add_f32 %[a1h], %[a1h], %[xh]\n\t"                                                       \
+                     "s_not_b64 exec, exec\n\t"                                                                     \
+                     "v_pk_add_f32 %[a0l], %[a0l], %[xl]\n\t"                                                       \
+                     "v_pk_add_f32 %[a0h], %[a0h], %[xh]\n\t"                                                       \
+                     "s_mov_b64 exec, -1"                                                                           \
+                     : [a0l] "+v"(a0l), [a0h] "+v"(a0h), [a1l] "+v"(a1l), [a1h] "+v"(a1h)                           \
+                     : [id] "v"(ID), [xl] "v"(xl), [xh] "v"(xh)                                                     \
+                     : "vcc", "scc");                                                                                    \
+        acc[j] = f32x4{a0l.x, a0l.y, a0h.x, a0h.y};                                                                 \
+        acc[j + 1] = f32x4{a1l.x, a1l.y, a1h.x, a1h.y};                                                             \
     }
 template <int K, int NWC>
 __device__ __forceinline__ void consume_tile_win(uint32_t tile, uint32_t slice, uint32_t wave, int grp, int li,
@@ -109,9 +122,9 @@ __device__ __forceinline__ void consume_tile_win(uint32_t tile, uint32_t slice, 
         const u32x4 nn = *reinterpret_cast<const u32x4 *>(seg_n + (size_t)wseg * 16);
         uint32_t ia = ids_base + (c & 1) * idb + (boff * 8 + grp) * 2;
         const uint32_t lbase = (c & 1) * xbuf_bytes + li * 16;
-        auto ldid = [&](uint32_t off) { return (uint32_t) * reinterpret_cast<const uint16_t *>(lds + ia + off); };
-        auto rdx = [&](uint32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((id & 0x3ffu) << 7) + lbase); };
-        uint32_t q0 = ldid(0), q1 = ldid(16);
+        auto ldid = [&](uint32_t off) { return (int32_t) * reinterpret_cast<const int16_t *>(lds + ia + off); };
+        auto rdx = [&](int32_t id) { return *reinterpret_cast<const f32x4 *>(lds + ((__builtin_amdgcn_ubfe((uint32_t)id, 0, 10) << 7) + lbase)); };
+        int32_t q0 = ldid(0), q1 = ldid(16);
         ia += 32;
 #pragma unroll
         for (int j = 0; j < K; j++) {
@@ -119,7 +132,7 @@ __device__ __forceinline__ void consume_tile_win(uint32_t tile, uint32_t slice, 
             uint32_t t = 0;
 #pragma nounroll
             for (; t + 2 <= nj; t += 2) {
-                const uint32_t c0 = q0, c1 = q1;
+                const int32_t c0 = q0, c1 = q1;
                 q0 = ldid(0);
                 q1 = ldid(16);
                 ia += 32;
@@ -128,7 +141,7 @@ __device__ __forceinline__ void consume_tile_win(uint32_t tile, uint32_t slice, 
                 ADD_SEL(c1, x1)
             }
             if (t < nj) {
-                const uint32_t c0 = q0;
+                const int32_t c0 = q0;
                 q0 = q1;
                 q1 = ldid(0);
                 ia += 16;
