@@ -7,7 +7,7 @@ mkdir -p $OUT
 i=0
 for set in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 run_proto.py --target 40 --check 0 --iters 2 "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set -d $OUT/p$i -o p$i --output-format csv -- python3 run_proto.py --check 0 --iters 2 "$@" > $OUT/p$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
