@@ -389,3 +389,40 @@ def test_gcn_with_the_epilogue_in_the_last_store(rng, tdt):
             assert torch.equal(fused2, a * plain + b)
     finally:
         adj._lib.release()
+
+
+def test_quantised_entry_points_reject_bad_arguments(rng):
+    """error behaviour of the round-2 entry points: status code + message, nothing launched"""
+    from pygim_amd import _lib
+
+    n, h = 64, 16
+    rowptr, col = random_csr(rng, n, n, 4)
+    rp, cl = torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda()
+    _lib.init_ranks(1)
+    try:
+        hd = _lib.group_create(_lib.CSR, _lib.INT8, [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [cl.numel()], [1], [h], h)
+        x = torch.randn(n, h, device="cuda")
+        out = torch.empty(n, h, device="cuda")
+        a = torch.ones(h, device="cuda")
+        bits = torch.zeros(1, dtype=torch.int32, device="cuda")
+        xq = torch.zeros((n, h), dtype=torch.int8, device="cuda")
+        for call, what in (
+                (lambda: _lib.quant_spmm_run(hd, x.data_ptr(), h, out.data_ptr(), 0, 0, a.data_ptr(), 0, True), "col_mul and col_add come together"),
+                (lambda: _lib.quant_spmm_run(hd, x.data_ptr(), h - 1, out.data_ptr()), "bad X / out / ldx"),
+                (lambda: _lib.quant_spmm_run(hd, x.cpu().data_ptr(), h, out.data_ptr()), "device pointers"),
+                (lambda: _lib.spmm_run_dequant(hd, xq.data_ptr(), h - 1, out.data_ptr(), bits.data_ptr()), "bad Xq"),
+                (lambda: _lib.spmm_run_dequant(hd, xq.cpu().data_ptr(), h, out.data_ptr(), bits.data_ptr()), "device pointers"),
+                (lambda: _lib.spmm_run_dequant(12345, xq.data_ptr(), h, out.data_ptr(), bits.data_ptr()), "unknown group handle"),
+                (lambda: _lib.group_plan(12345), "unknown group handle"),
+                (lambda: _lib.group_kernel_events(12345, True), "unknown group handle")):
+            with pytest.raises(_lib.PygimError) as e:
+                call()
+            assert what in str(e.value), (what, str(e.value))
+        _lib.group_free(hd)
+        hd64 = _lib.group_create(_lib.CSR, _lib.INT64, [rp.data_ptr()], [cl.data_ptr()], None, [n], [n], [cl.numel()], [1], [h], h)
+        with pytest.raises(_lib.PygimError) as e:
+            _lib.spmm_run_dequant(hd64, xq.data_ptr(), h, out.data_ptr(), bits.data_ptr())
+        assert "INT8/INT16/INT32/FLT32" in str(e.value)
+        _lib.group_free(hd64)
+    finally:
+        _lib.release()
