@@ -152,6 +152,19 @@ def _worker(rank, world, port, q):
             if tdt != torch.float32:
                 plain = sh.mul(sh.local_rows(torch.from_numpy(xq_ref)).contiguous())
                 assert np.array_equal(plain.numpy(), oracle.spmm_csr(rowptr, col, None, xq_ref)[sh.r0:sh.r1])
+            # the conv layers' entry point on a row block: the scale is the GLOBAL one whatever `fused` says (round-1
+            # advisor finding: the unfused fallback quantised each rank's block with its own scale)
+            from pygim_amd import quantize as pq
+
+            for fused in (True, False):
+                out = pq.message_and_aggregate(sh, sh.local_rows(torch.from_numpy(xf)).contiguous(), fused=fused)
+                assert np.array_equal(out.numpy(), want[sh.r0:sh.r1]), (tdt, fused)
+        sh64 = pd.RowShardAdj(rp_t, col_t, n, torch.int64, h, engine_factory=OracleShardEngine)
+        try:
+            pq.message_and_aggregate(sh64, sh64.local_rows(torch.from_numpy(xf)).contiguous(), fused=False)
+            raise AssertionError("INT64 row-sharded aggregation must be rejected")
+        except RuntimeError as e:
+            assert "INT8/INT16/INT32/FLT32" in str(e)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
