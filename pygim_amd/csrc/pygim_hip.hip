@@ -182,6 +182,7 @@ struct Context {
         int64_t ld = 0, rows = 0, w = 0;
         size_t es = 0;
         uint64_t stamp = 0;
+        int in_use = 0;  // handed to a call that has not enqueued its kernels yet: not an eviction victim
     };
     static constexpr size_t XS_MAX = 4;
     std::map<std::pair<int, hipStream_t>, XsBuf> xs_bufs;
@@ -201,11 +202,13 @@ int xs_buffer_locked(hipStream_t st, size_t need, Context::XsBuf **out) {
     (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, st);
     if (!g_ctx.xs_bufs.count(key) && g_ctx.xs_bufs.size() >= Context::XS_MAX) {
-        auto victim = g_ctx.xs_bufs.begin();
+        auto victim = g_ctx.xs_bufs.end();
         for (auto it = g_ctx.xs_bufs.begin(); it != g_ctx.xs_bufs.end(); ++it)
-            if (it->second.stamp < victim->second.stamp) victim = it;
-        if (victim->second.ptr) (void)hipFree(victim->second.ptr);  // hipFree waits for the work that uses it
-        g_ctx.xs_bufs.erase(victim);
+            if (it->second.in_use == 0 && (victim == g_ctx.xs_bufs.end() || it->second.stamp < victim->second.stamp)) victim = it;
+        if (victim != g_ctx.xs_bufs.end()) {  // (all busy: grow past the cap rather than pull a buffer from under a caller)
+            if (victim->second.ptr) (void)hipFree(victim->second.ptr);  // hipFree waits for the work that uses it
+            g_ctx.xs_bufs.erase(victim);
+        }
     }
     Context::XsBuf &b = g_ctx.xs_bufs[key];
     if (b.bytes < need) {
@@ -219,9 +222,23 @@ int xs_buffer_locked(hipStream_t st, size_t need, Context::XsBuf **out) {
         b.bytes = need;
     }
     b.stamp = ++g_ctx.xs_clock;
+    b.in_use++;
     *out = &b;
     return 0;
 }
+
+// a slice-major buffer stays pinned (not evictable by other threads' calls) until the kernels that read it are enqueued;
+// after that hipFree's implicit wait protects it
+struct XsPin {
+    void *ptr = nullptr;
+    void hold(void *p) { ptr = p; }
+    ~XsPin() {
+        if (!ptr) return;
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        for (auto &kv : g_ctx.xs_bufs)
+            if (kv.second.ptr == ptr && kv.second.in_use > 0) kv.second.in_use--;
+    }
+};
 
 bool is_device_ptr(const void *p) {
     if (!p) return false;
@@ -428,6 +445,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
             const T *Xg = X;
             int64_t ldg = ldx, slice_stride = F;
             KernelTimer kt(g, st, !p.is_extra);
+            XsPin pin;
             // (rows of one slice that are already contiguous lines need no copy -- as long as no 16-byte piece is
             // partial: X may be a window that ends at the end of an allocation (pygim_block_run on x + f0), so a
             // piece over a ragged tail must never be read from the caller's matrix; those go to the padded copy)
@@ -458,13 +476,16 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                         }
                         if (hit) {
                             hit->stamp = ++g_ctx.xs_clock;
+                            hit->in_use++;
                             xs_use = hit->ptr;
+                            pin.hold(xs_use);
                         }
                     }
                     if (!xs_use) {
                         Context::XsBuf *b = nullptr;
                         if (int rc = xs_buffer_locked(st, std::max<size_t>(need, 256), &b)) return rc;
                         xs_use = b->ptr;
+                        pin.hold(xs_use);
                         b->src = X;
                         b->ld = ldx;
                         b->rows = p.ncols;
@@ -1254,6 +1275,8 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
             b->src = nullptr;  // holds quantised values of a float matrix: never matched by x_unchanged
             xs = b->ptr;
         }
+        XsPin pin;
+        pin.hold(xs);
         const uint64_t threads = (uint64_t)p->ncols * nslices * (1u << LOG_LPR);
         hipLaunchKernelGGL((k_slice_pack_quant<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
                            (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out);
