@@ -974,6 +974,140 @@ __global__ void k_build_panel_ptr(const uint32_t *__restrict__ perm, const uint3
 }
 
 // ---------------------------------------------------------------------------
+// The SpMV end with the dense operand staged in LDS (spmv_sparseP/dpu_kernels/spmv_mul_coo_dpu.c keeps its slice of the
+// vector in the DPU's scratchpad the same way).  For rows of X of at most 16 bytes a gather through the cache hierarchy
+// costs a whole 128-byte L2 request per stored entry (k_csr_vec: 0.68 ms on the Reddit-shaped graph); here a 1024-thread
+// workgroup copies ONE column panel of X (panel_cols rows of W elements, <= 144 KiB) into LDS with coalesced loads and walks
+// a slab of the panel's length-sorted work items: 16 lanes per item stride over its entries (coalesced 16-bit panel-local
+// column ids, one ds_read per entry), a fixed butterfly adds the lanes' partial sums, and the row's running sum continues
+// from C for later panels (FIRST flag) as in the wide sweep.  Integers exact; floats in a fixed order other than the stored
+// one (inside the 1e-5 bound, as k_csr_vec).
+// ---------------------------------------------------------------------------
+extern __shared__ unsigned char pygim_lds_raw[];
+template <typename T, int W, bool HAS_VALS>
+__global__ __launch_bounds__(1024) void k_spmv_lds(const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_begin,
+                                                   const uint32_t *__restrict__ item_len, uint32_t nitems,
+                                                   const unsigned short *__restrict__ col16, const T *__restrict__ vals,
+                                                   const T *__restrict__ X, int64_t ldx, T *__restrict__ C, int64_t ldc,
+                                                   int accumulate, uint32_t col_base, uint32_t pcols, uint32_t items_per_block) {
+    static_assert(W >= 1 && W <= 4, "rows of at most 4 elements");
+    using A = typename AccOf<T>::type;
+    constexpr int LG = 16;  // lanes per work item
+    // stage the panel: rows [col_base, col_base + pcols) of X, W elements each.  Dense X (ldx == W): 16-byte pieces starting at
+    // the 16-byte boundary at or below the panel's first byte (the few leading elements belong to the previous panel and are
+    // simply not addressed); else element by element.
+    const T *xp = X + (int64_t)col_base * ldx;
+    const uint32_t total = pcols * (uint32_t)W;
+    T *xs = reinterpret_cast<T *>(pygim_lds_raw);
+    const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(xp) & 15u) / sizeof(T));
+    if (ldx == (int64_t)W && (reinterpret_cast<uintptr_t>(xp) % sizeof(T)) == 0 && (col_base > 0 || mis == 0)) {
+        constexpr uint32_t PER = 16 / sizeof(T);
+        const uint32_t nvec = (total + mis + PER - 1) / PER;  // (the last piece may reach past the panel: X is padded by the caller? no --
+        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(xp - mis);
+        u32x4_t *dst = reinterpret_cast<u32x4_t *>(xs);
+        const uint32_t full = (total + mis) / PER;            //  whole pieces only; the ragged tail goes element by element)
+        (void)nvec;
+        for (uint32_t i = threadIdx.x; i < full; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
+        for (uint32_t i = full * PER + threadIdx.x; i < total + mis; i += blockDim.x) xs[i] = (xp - mis)[i];
+        xs += mis;
+    } else {
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) xs[i] = xp[(int64_t)(i / W) * ldx + (i % W)];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, li = lane & (LG - 1);
+    const uint32_t grp = threadIdx.x / LG, ngrp = blockDim.x / LG;
+    // the panel's length-sorted items are dealt to the workgroups round-robin (item i -> workgroup i % gridDim.x), so every
+    // workgroup sees the whole length spectrum -- a contiguous slab would hand all the long items to workgroup 0 -- and
+    // inside a workgroup to the lane groups in turn
+    (void)items_per_block;
+    // Software pipeline over a lane group's items: while item t is summed, the ids of item t + 1 (one 8-byte load per lane:
+    // lane li owns entries 4 li .. 4 li + 3 of every 64-entry pass; the id array is padded, so reading past an item's end is
+    // harmless) and the descriptor of item t + 2 are already in flight.
+    // (pipeline depth: the ids of the next D items and the descriptors of the D after those are in flight -- the id array is
+    // streamed once from HBM and a lane group's next item is several microseconds of latency away)
+    constexpr int D = 3;
+    const uint32_t istep = ngrp * gridDim.x;
+    uint32_t i = blockIdx.x + grp * gridDim.x;
+    uint32_t d_row[2 * D], d_s[2 * D], d_lf[2 * D];
+    u16x4_u d_q[D];
+#pragma unroll
+    for (int t = 0; t < 2 * D; t++) {
+        const uint32_t it = i + (uint32_t)t * istep;
+        d_row[t] = d_s[t] = d_lf[t] = 0;
+        if (it < nitems) {
+            d_row[t] = item_row[it];
+            d_s[t] = item_begin[it];
+            d_lf[t] = item_len[it];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < D; t++) {
+        d_q[t] = u16x4_u{0, 0, 0, 0};
+        if (i + (uint32_t)t * istep < nitems)
+            d_q[t] = __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + d_s[t] + 4 * li));
+    }
+    for (; i < nitems; i += istep) {
+        const uint32_t row = d_row[0], s = d_s[0], lf = d_lf[0];
+        const u16x4_u q0 = d_q[0];
+        // advance the pipeline: item t + D gets its ids requested, item t + 2 D its descriptor
+#pragma unroll
+        for (int t = 0; t + 1 < 2 * D; t++) {
+            d_row[t] = d_row[t + 1];
+            d_s[t] = d_s[t + 1];
+            d_lf[t] = d_lf[t + 1];
+        }
+#pragma unroll
+        for (int t = 0; t + 1 < D; t++) d_q[t] = d_q[t + 1];
+        if (i + (uint32_t)D * istep < nitems)
+            d_q[D - 1] = __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + d_s[D - 1] + 4 * li));
+        {
+            const uint32_t it = i + (uint32_t)(2 * D) * istep;
+            if (it < nitems) {
+                d_row[2 * D - 1] = item_row[it];
+                d_s[2 * D - 1] = item_begin[it];
+                d_lf[2 * D - 1] = item_len[it];
+            }
+        }
+        const uint32_t len = lf & 0x3FFFFFFFu;
+        const bool load_c = accumulate || !(lf >> 31);
+        T *crow = C + (int64_t)row * ldc;
+        A acc[W], prev[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) acc[j] = prev[j] = A(0);
+        if (li == 0 && load_c) {  // the row's running sum: requested now, needed only after the entries are summed
+#pragma unroll
+            for (int j = 0; j < W; j++) prev[j] = to_acc<T>(crow[j]);
+        }
+        for (uint32_t k = 4 * li; k < len; k += 4 * LG) {
+            const u16x4_u q = (k == 4 * li) ? q0 : __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + s + k));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k + u < len) {
+                    const T *xr = xs + (uint32_t)q[u] * W;
+                    if constexpr (HAS_VALS) {
+                        const A v = to_acc<T>(__builtin_nontemporal_load(vals + s + k + u));
+#pragma unroll
+                        for (int j = 0; j < W; j++) acc[j] += v * to_acc<T>(xr[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < W; j++) acc[j] += to_acc<T>(xr[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LG >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < W; j++) acc[j] += shfl_xor_t<A>(acc[j], off);
+        }
+        if (li == 0 && !(len == 0 && accumulate)) {
+#pragma unroll
+            for (int j = 0; j < W; j++) crow[j] = from_acc<T>(prev[j] + acc[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // COO, equal-nnz split (rows may straddle waves), "wide" layout.
 // Wave c owns stored entries [c*chunk, (c+1)*chunk).  Row segments closed on
 // both sides are written straight to C (C was zero-filled, or holds the running

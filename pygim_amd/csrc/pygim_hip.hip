@@ -70,6 +70,7 @@ struct Tunables {
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
     int64_t vec_kernel = 1;             // 1 = rows of X of at most 4 elements (SpMV) take the CSR-vector kernel
+    int64_t vec_lds = 1;                // 1 = ... and, when a column panel of X fits, the LDS-staged form of it (k_spmv_lds)
     int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
@@ -599,6 +600,52 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     const uint32_t ww = (uint32_t)w;
     // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
     if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
+        // LDS-staged form: the plan's column panels with 16-bit local ids, a panel of X (panel_cols x w elements) inside the
+        // 144 KiB a workgroup may take; rows cut into segments (segment kernels) keep the plain form
+        constexpr size_t LDS_MAX = 144 * 1024;
+        if (g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 && p.npanels >= 1 &&
+            (size_t)p.panel_cols * ww * sizeof(T) + 32 <= LDS_MAX &&
+            // every panel costs a pass over the item list and a staged copy of its part of X: worth it from about 32 entries per
+            // (row, panel) (Reddit-shaped, 4-byte elements: w = 1 -> 8 panels, 0.43 vs 0.67 ms; w = 2 -> 13 panels, 0.59 vs 0.69 ms;
+            // w = 4 -> 26 panels, 1.03 vs 0.72 ms)
+            (double)p.nnz >= 32.0 * (double)p.nrows * (double)p.npanels) {
+            KernelTimer kt(g, st, !p.is_extra);
+            for (uint32_t q = 0; q < p.npanels; q++) {
+                const size_t o = p.panel_off[q];
+                const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
+                if (cnt == 0) continue;
+                const uint32_t col_base = q * p.panel_cols;
+                const uint32_t pcols = (uint32_t)std::min<int64_t>(p.panel_cols, p.ncols - (int64_t)col_base);
+                // slabs of the item list per workgroup: enough entries to amortise staging the panel, enough workgroups to fill the chip
+                // one workgroup per CU (each stages the panel once), fewer when the panel has few items
+                const uint32_t ipb = 0;
+                const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::max(g_ctx.cu_count, 1), (cnt + 63) / 64));
+                const size_t shmem = ((((size_t)pcols * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + the alignment lead-in
+                const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
+#define PYGIM_SPMV_LDS(W, HV)                                                                                                  \
+    {                                                                                                                          \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_spmv_lds<T, W, HV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                        (int)LDS_MAX));                                                                        \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_spmv_lds<T, W, HV>), dim3(blocks), dim3(1024), shmem, st, ir, ib, il, cnt, p.col16,              \
+                           (const T *)p.vals, x, ldx, c, ldc, accumulate ? 1 : 0, col_base, pcols, ipb);                       \
+    }
+                if (p.vals) {
+                    if (ww == 1) PYGIM_SPMV_LDS(1, true) else if (ww == 2) PYGIM_SPMV_LDS(2, true)
+                    else if (ww == 3) PYGIM_SPMV_LDS(3, true) else PYGIM_SPMV_LDS(4, true)
+                } else {
+                    if (ww == 1) PYGIM_SPMV_LDS(1, false) else if (ww == 2) PYGIM_SPMV_LDS(2, false)
+                    else if (ww == 3) PYGIM_SPMV_LDS(3, false) else PYGIM_SPMV_LDS(4, false)
+                }
+#undef PYGIM_SPMV_LDS
+            }
+            kt.stop();
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         const double avg = (double)p.nnz / (double)p.nrows;
         const int log_g = avg >= 96 ? 6 : avg >= 48 ? 5 : avg >= 24 ? 4 : avg >= 10 ? 3 : 2;
         const uint64_t waves = ((uint64_t)p.nrows + (64u >> log_g) - 1) / (64u >> log_g);
@@ -690,7 +737,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // One-time plans of a part (needs its row pointers on the host): the long-row segment plans and the
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
-int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
+int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
     if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PYGIM_ERR_HIP, "rowptr D2H");
@@ -712,7 +759,11 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
     // L2-blocked plan: columns cut into panels whose 128-byte feature slice fits the L2 budget,
     // per panel the length-sorted list of work items
     if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
-        const int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
+        int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
+        // groups whose rows of X hold at most 4 elements never take the wide sweep: their panels are sized for the LDS-staged
+        // SpMV kernel instead (a panel of X, h elements per column, inside the 144 KiB a workgroup may take)
+        if (h_hint >= 1 && h_hint <= 4 && g_tune.vec_lds && g_tune.vec_kernel)
+            budget_rows = std::max<int64_t>(1, std::min<int64_t>(budget_rows, (int64_t)((144 * 1024 - 64) / ((size_t)h_hint * es))));
         uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
         bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                      (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
@@ -808,7 +859,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st) {
                     return fail(PYGIM_ERR_HIP, "panel plan upload");
                 // 16-bit panel-local column ids (2 bytes per entry more, half the index bytes per sweep)
                 if (g_tune.panel_col16 && p.panel_cols <= 65536 && p.nnz > 0) {
-                    if (hipMalloc((void **)&p.col16, (size_t)p.nnz * 2) != hipSuccess) return fail(PYGIM_ERR_HIP, "col16 alloc");
+                    // (+ 64 bytes: the LDS-staged SpMV kernel fetches ids four at a time and may read past the last entry)
+                    if (hipMalloc((void **)&p.col16, (size_t)p.nnz * 2 + 64) != hipSuccess) return fail(PYGIM_ERR_HIP, "col16 alloc");
                     hipLaunchKernelGGL(k_make_col16, dim3((unsigned)((p.nnz + 255) / 256)), dim3(256), 0, st, p.colind,
                                        (uint64_t)p.nnz, p.panel_cols, p.col16);
                     if (hipStreamSynchronize(st) != hipSuccess) return fail(PYGIM_ERR_HIP, "col16 build");
@@ -978,7 +1030,7 @@ int build_merged_t(Group *g, size_t es, hipStream_t st) {
     cursor = nullptr;
     int rc = 0;
     if (!g->all_ones) rc = split_unit_pattern(*m, g->dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st);
-    if (!rc) rc = build_plans(*m, es, g->d_flags + 4, st);
+    if (!rc) rc = build_plans(*m, es, g->d_flags + 4, st, g->h);
     if (rc) {
         free_part(*m);
         return rc;
@@ -1440,6 +1492,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
     else if (n == "vec_kernel") slot = &g_tune.vec_kernel;
+    else if (n == "vec_lds") slot = &g_tune.vec_lds;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;
@@ -1559,7 +1612,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.own_vals = false;
         }
         if (!g->all_ones && (rc = split_unit_pattern(p, dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st))) return bail(rc);
-        if ((rc = build_plans(p, es, g->d_flags + 4, st))) return bail(rc);
+        if ((rc = build_plans(p, es, g->d_flags + 4, st, g->h))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;
