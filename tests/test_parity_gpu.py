@@ -619,3 +619,65 @@ def test_unsorted_columns_inside_rows(rng):
     finally:
         _lib.set_tunable("panel_mode", old[0])
         _lib.set_tunable("panel_bytes", old[1])
+
+
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_lds_staged_spmv_kernel(rng, dt):
+    """k_spmv_lds (a column panel of X staged in a workgroup's LDS): rows of X of 1..4 elements, several panels with more than
+    32 entries per (row, panel), unit and real weights, CSR and COO, dense and strided X, two unmerged sparse parts (the
+    second accumulates), against the oracle and against the cache-path vector kernel (tunable vec_lds = 0)"""
+    npdt = NP_DTYPES[dt]
+    n = 2600
+    rowptr, col = random_csr(rng, n, n, 160, long_rows=[(7, 3000), (n - 2, 900)], empty_frac=0.03)
+    old = {k: _lib.set_tunable(k, v) for k, v in (("panel_bytes", 128 * 900), ("merge_parts", 0))}
+    try:
+        for w in (1, 2, 3, 4):
+            for weighted in (False, True):
+                x = driver_features(rng, n, w, npdt)
+                vals = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else None
+                ref = oracle.spmm_csr(rowptr, col, vals, x)
+                outs = {}
+                for lds_on in (1, 0):
+                    _lib.set_tunable("vec_lds", lds_on)
+                    out, info = run_group_host("CSR", [rowptr], [col], None if vals is None else [vals], [n], [n], [x], w)
+                    outs[lds_on] = out
+                    if lds_on:
+                        assert info["n_panels"] >= 3, info  # the LDS kernel's rule is met: 160 / 3 entries per (row, panel)
+                if np.issubdtype(npdt, np.integer) or not weighted:
+                    assert np.array_equal(outs[1], ref) and np.array_equal(outs[0], ref), (dt, w, weighted)
+                else:
+                    bound = 1e-5 * abs_scale(rowptr, col, vals, x) + 1e-30
+                    assert np.all(np.abs(outs[1].astype(np.float64) - ref) <= bound), (dt, w)
+        _lib.set_tunable("vec_lds", 1)
+        # COO (coalesced: values > 1), w = 1
+        r, c, v = coalesce(rowptr, col, npdt)
+        x = driver_features(rng, n, 1, npdt)
+        out, _ = run_group_host("COO", [r], [c], [v], [n], [n], [x], 1)
+        assert np.array_equal(out, oracle.spmm_coo(r, c, v, x, n))
+        # the SpMV entry point: 2 right-hand sides packed into [n, 2]
+        xs = [driver_features(rng, n, 1, npdt) for _ in range(2)]
+        out, _ = run_group_host("CSR", [rowptr], [col], None, [n], [n], xs, 2, kind="spmv", n_dense=[2], dense_cols=[1, 1])
+        assert np.array_equal(out, np.concatenate([oracle.spmm_csr(rowptr, col, None, a) for a in xs], axis=1))
+        # strided X and C through pygim_block_run (element-wise staging), then a second part that accumulates
+        hd = None
+        rp_d, cl_d = torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda()
+        tdt = {"INT8": torch.int8, "INT16": torch.int16, "INT32": torch.int32, "INT64": torch.int64, "FLT32": torch.float32,
+               "DBL64": torch.float64}[dt]
+        hd = _lib.group_create(_lib.CSR, CODE_OF_NP[np.dtype(npdt)], [rp_d.data_ptr()], [cl_d.data_ptr()], None, [n], [n],
+                               [len(col)], [1], [2], 2)
+        xw = torch.from_numpy(driver_features(rng, n, 7, npdt)).cuda()
+        cw = torch.zeros((n, 5), dtype=tdt, device="cuda")
+        es = xw.element_size()
+        _lib.block_run(hd, 0, xw.data_ptr() + 3 * es, 7, cw.data_ptr() + 1 * es, 5, 2, False)
+        _lib.block_run(hd, 0, xw.data_ptr() + 3 * es, 7, cw.data_ptr() + 1 * es, 5, 2, True)  # accumulate: twice the product
+        torch.cuda.synchronize()
+        want = oracle.spmm_csr(rowptr, col, None, xw[:, 3:5].cpu().numpy())
+        got = cw.cpu().numpy()
+        assert np.array_equal(got[:, 1:3], (want.astype(np.float64) * 2).astype(npdt) if np.issubdtype(npdt, np.floating)
+                              else (want.astype(np.int64) * 2).astype(npdt))
+        assert not got[:, 0].any() and not got[:, 3:].any()
+        _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("vec_lds", 1)
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
