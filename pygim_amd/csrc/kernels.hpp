@@ -1013,6 +1013,7 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const uint32_t *__restrict__ 
     } else {
         for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) xs[i] = xp[(int64_t)(i / W) * ldx + (i % W)];
     }
+    if (threadIdx.x < (uint32_t)W) xs[pcols * W + threadIdx.x] = T(0);  // the all-zero row (index pcols)
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, li = lane & (LG - 1);
     const uint32_t grp = threadIdx.x / LG, ngrp = blockDim.x / LG;
@@ -1080,18 +1081,29 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const uint32_t *__restrict__ 
         }
         for (uint32_t k = 4 * li; k < len; k += 4 * LG) {
             const u16x4_u q = (k == 4 * li) ? q0 : __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + s + k));
+            if constexpr (HAS_VALS) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (k + u < len) {
-                    const T *xr = xs + (uint32_t)q[u] * W;
-                    if constexpr (HAS_VALS) {
+                for (int u = 0; u < 4; u++) {
+                    if (k + u < len) {
+                        const T *xr = xs + (uint32_t)q[u] * W;
                         const A v = to_acc<T>(__builtin_nontemporal_load(vals + s + k + u));
 #pragma unroll
                         for (int j = 0; j < W; j++) acc[j] += v * to_acc<T>(xr[j]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < W; j++) acc[j] += to_acc<T>(xr[j]);
                     }
+                }
+            } else {
+                // branch-free: entries past the item's end read the all-zero row staged behind the panel
+                T xv[4][W];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t c = (k + u < len) ? (uint32_t)q[u] : pcols;
+#pragma unroll
+                    for (int j = 0; j < W; j++) xv[u][j] = xs[c * W + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int j = 0; j < W; j++) acc[j] += to_acc<T>(xv[u][j]);
                 }
             }
         }

@@ -604,7 +604,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
         // 144 KiB a workgroup may take; rows cut into segments (segment kernels) keep the plain form
         constexpr size_t LDS_MAX = 144 * 1024;
         if (g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 && p.npanels >= 1 &&
-            (size_t)p.panel_cols * ww * sizeof(T) + 32 <= LDS_MAX &&
+            ((size_t)p.panel_cols + 1) * ww * sizeof(T) + 32 <= LDS_MAX &&
             // every panel costs a pass over the item list and a staged copy of its part of X: worth it from about 32 entries per
             // (row, panel) (Reddit-shaped, 4-byte elements: w = 1 -> 8 panels, 0.43 vs 0.67 ms; w = 2 -> 13 panels, 0.59 vs 0.69 ms;
             // w = 4 -> 26 panels, 1.03 vs 0.72 ms)
@@ -620,7 +620,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
                 // one workgroup per CU (each stages the panel once), fewer when the panel has few items
                 const uint32_t ipb = 0;
                 const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::max(g_ctx.cu_count, 1), (cnt + 63) / 64));
-                const size_t shmem = ((((size_t)pcols * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + the alignment lead-in
+                const size_t shmem = (((((size_t)pcols + 1) * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + zero row + alignment lead-in
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_SPMV_LDS(W, HV)                                                                                                  \
     {                                                                                                                          \
