@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined", "pipelined-feature"])
+    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined", "pipelined-feature", "push"])
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
@@ -293,6 +293,92 @@ def main():
             return (f"sp_parts={world} as an nnz-balanced row split, one product per rank; the all-gather (RCCL) of step k "
                     f"overlaps the product of step k+1 (two gather buffers), all gathers complete inside the timed region")
 
+    class PushRows:
+        """sp_parts = world as an nnz-balanced row split whose exchange is a PUSH over xGMI by the copy engines: every rank
+        writes its result block straight into its place in every peer's [N, h] matrix (the peers' buffers are opened through
+        HIP IPC once), world - 1 peer copies on their own streams behind the product, and a 4-byte all-reduce as the arrival
+        barrier.  The pushes of step k overlap the product of step k + 1 (two result matrices); no CU is spent on the
+        exchange and the result needs no re-layout.  xGMI is point-to-point, one link per peer: the copies use all of them."""
+
+        def __init__(self, K):
+            from torch.multiprocessing.reductions import reduce_tensor
+
+            self.K = 1
+            c0, c1 = split[rank], split[rank + 1]
+            self.c0, self.c1 = c0, c1
+            lo, hi = int(rowptr_cpu[c0]), int(rowptr_cpu[c1])
+            rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
+            col_c = col[lo:hi].contiguous()
+            self.keep = [rp_c, col_c]
+            self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None, [c1 - c0], [n],
+                                              [hi - lo], [1], [h], h)]
+            self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.peer = [[None, None] for _ in range(world)]
+            if multi and world > 1:
+                mine = [reduce_tensor(c) for c in self.C]  # (rebuild function, IPC handle + geometry) per buffer
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                for r in range(world):
+                    if r != rank:
+                        self.peer[r] = [fn(*a) for fn, a in everyone[r]]
+            self.copy_streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+            self.sync_stream = torch.cuda.Stream(device=dev)
+            self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.pending = [None, None]
+            self.k = 0
+            self.last = 0
+            self.my_rows, self.my_nnz = c1 - c0, hi - lo
+
+        def step(self, exchange=True):
+            b = self.k & 1
+            self.k += 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()  # everyone's pushes into this buffer (two steps ago) have landed, mine have left
+                self.pending[b] = None
+            mine = self.C[b][self.c0:self.c1]
+            _lib.spmm_run_group(self.handles[0], [x.data_ptr()], mine.data_ptr(), stream)
+            if exchange and multi:
+                done = torch.cuda.Event()
+                done.record(main_stream)
+                for r in range(world):
+                    if r == rank or self.peer[r][b] is None:
+                        continue
+                    s_r = self.copy_streams[r]
+                    s_r.wait_event(done)
+                    with torch.cuda.stream(s_r):
+                        self.peer[r][b][self.c0:self.c1].copy_(mine, non_blocking=True)
+                self.sync_stream.wait_event(done)
+                for r in range(world):
+                    if r != rank:
+                        self.sync_stream.wait_stream(self.copy_streams[r])
+                with torch.cuda.stream(self.sync_stream):
+                    self.pending[b] = dist.all_reduce(self.flags[b], async_op=True)
+            self.last = b
+
+        def drain(self):
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+
+        def free(self):
+            self.drain()
+            torch.cuda.synchronize()
+            self.peer = None  # close the peers' buffers before anyone frees theirs
+            if multi:
+                dist.barrier()
+            for hd in self.handles:
+                _lib.group_free(hd)
+            self.handles = []
+
+        def full_c(self):
+            return self.C[self.last]
+
+        def describe(self):
+            return (f"sp_parts={world} as an nnz-balanced row split, one product per rank; every rank pushes its block into "
+                    f"every peer's result matrix (HIP IPC, {max(world - 1, 0)} peer copies on the copy engines over xGMI) "
+                    f"behind the next step's product, a 4-byte all-reduce as the arrival barrier")
+
     class FeaturePieces:
         """ds_parts = world: rank r owns the feature block X[:, r*h/world : (r+1)*h/world] and computes that
         block of C for ALL rows (A replicated), in K nnz-balanced row pieces on their own streams; each piece
@@ -435,6 +521,8 @@ def main():
         cands.append((PipelinedRows, 1))
     if args.partition == "pipelined-feature" and feat_ok:
         cands.append((PipelinedFeatures, 1))
+    if args.partition == "push":
+        cands.append((PushRows, 1))
     if args.partition == "row":
         cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if not multi else (1, 2, 4)))]
         if multi and args.chunks == 0:
@@ -450,7 +538,7 @@ def main():
             # best of the other are timed on the node (3 candidates instead of 6)
             kk = (args.chunks,) if args.chunks > 0 else (1,)
             row_first = prior.feat_parts == 1 or not feat_ok or world == 1
-            fam_row = [(PipelinedRows, 1), (Pieces, kk[0])]
+            fam_row = [(PipelinedRows, 1), (PushRows, 1)] if args.chunks == 0 else [(Pieces, kk[0])]
             fam_feat = [(PipelinedFeatures, 1), (FeaturePieces, kk[0])] if feat_ok and world > 1 else []
             cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[:1])
     assert cands, "no admissible partition"
@@ -460,7 +548,22 @@ def main():
     else:
         best = None
         for cls, kk in cands:
-            pl = cls(kk)
+            # a candidate that cannot be set up on some rank (e.g. IPC refused) is dropped on ALL ranks, not fatal
+            try:
+                pl = cls(kk)
+                okf = 1
+            except Exception as e:  # noqa: BLE001
+                pl, okf = None, 0
+                print(f"[bench] rank {rank}: candidate {cls.__name__} not available: {str(e)[:200]}", file=sys.stderr)
+            if multi:
+                agree = torch.tensor([okf], dtype=torch.int32, device=dev)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                okf = int(agree.item())
+            if not okf:
+                if pl is not None:
+                    pl.free()
+                timed[f"{cls.__name__}:{kk}"] = None
+                continue
             live[:] = [pl]
             for _ in range(2):
                 pl.step()
@@ -480,6 +583,7 @@ def main():
             else:
                 pl.free()
             del pl
+        assert best is not None, "no candidate could be set up"
         plan = best[1]
     live[:] = [plan]
     K, step = plan.K, plan.step
