@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined", "pipelined-feature", "push"])
+    ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined", "pipelined-feature", "push", "push-feature"])
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
@@ -499,6 +499,96 @@ def main():
             return (f"ds_parts={world} as a feature split (A replicated, {self.hw} features per rank), one product per rank and "
                     f"step; the all-gather (RCCL) of step k overlaps the product of step k+1, then its blocks are laid row-major")
 
+    class PushFeatures:
+        """ds_parts = world with the push exchange: rank r computes C[:, f_r] for all rows straight into its own [N, h]
+        result matrix (column window, row stride h) and pushes that window into every peer's matrix with one strided (2-D)
+        peer copy per peer on its own stream -- the result lands in its final row-major place on every rank, no gather
+        buffer, no re-layout, no CU spent on the exchange; 4-byte all-reduce as the arrival barrier; the pushes of step k
+        overlap the product of step k + 1."""
+
+        def __init__(self, K):
+            import ctypes
+
+            from torch.multiprocessing.reductions import reduce_tensor
+
+            self.K = 1
+            self.hw = h // world
+            self.f0 = rank * self.hw
+            self.hip = ctypes.CDLL("libamdhip64.so")
+            self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz],
+                                              [1], [self.hw], self.hw)]
+            self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.peer = [[None, None] for _ in range(world)]
+            if multi and world > 1:
+                mine = [reduce_tensor(c) for c in self.C]
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                for r in range(world):
+                    if r != rank:
+                        self.peer[r] = [fn(*a) for fn, a in everyone[r]]
+            self.copy_streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
+            self.sync_stream = torch.cuda.Stream(device=dev)
+            self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.pending = [None, None]
+            self.k = 0
+            self.last = 0
+            self.my_rows, self.my_nnz = n, nnz
+
+        def step(self, exchange=True):
+            import ctypes
+
+            b = self.k & 1
+            self.k += 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+            win = self.C[b].data_ptr() + 4 * self.f0
+            _lib.block_run(self.handles[0], 0, x.data_ptr() + 4 * self.f0, h, win, h, self.hw, False, stream)
+            if exchange and multi:
+                done = torch.cuda.Event()
+                done.record(main_stream)
+                for r in range(world):
+                    if r == rank or self.peer[r][b] is None:
+                        continue
+                    s_r = self.copy_streams[r]
+                    s_r.wait_event(done)
+                    rc = self.hip.hipMemcpy2DAsync(ctypes.c_void_p(self.peer[r][b].data_ptr() + 4 * self.f0), ctypes.c_size_t(4 * h),
+                                                   ctypes.c_void_p(win), ctypes.c_size_t(4 * h), ctypes.c_size_t(4 * self.hw),
+                                                   ctypes.c_size_t(n), ctypes.c_int(4), ctypes.c_void_p(s_r.cuda_stream))  # 4 = hipMemcpyDefault
+                    if rc != 0:
+                        raise RuntimeError(f"hipMemcpy2DAsync to rank {r}: error {rc}")
+                self.sync_stream.wait_event(done)
+                for r in range(world):
+                    if r != rank:
+                        self.sync_stream.wait_stream(self.copy_streams[r])
+                with torch.cuda.stream(self.sync_stream):
+                    self.pending[b] = dist.all_reduce(self.flags[b], async_op=True)
+            self.last = b
+
+        def drain(self):
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+
+        def free(self):
+            self.drain()
+            torch.cuda.synchronize()
+            self.peer = None
+            if multi:
+                dist.barrier()
+            for hd in self.handles:
+                _lib.group_free(hd)
+            self.handles = []
+
+        def full_c(self):
+            return self.C[self.last]
+
+        def describe(self):
+            return (f"ds_parts={world} as a feature split (A replicated, {self.hw} features per rank) computed into place; every "
+                    f"rank pushes its column window into every peer's result matrix (HIP IPC, one strided peer copy per peer on "
+                    f"the copy engines over xGMI) behind the next step's product, a 4-byte all-reduce as the arrival barrier")
+
     live = []  # plans whose asynchronous exchanges must be complete at a fence
 
     def fence():
@@ -523,6 +613,8 @@ def main():
         cands.append((PipelinedFeatures, 1))
     if args.partition == "push":
         cands.append((PushRows, 1))
+    if args.partition == "push-feature" and feat_ok:
+        cands.append((PushFeatures, 1))
     if args.partition == "row":
         cands += [(Pieces, k) for k in ((args.chunks,) if args.chunks > 0 else ((1,) if not multi else (1, 2, 4)))]
         if multi and args.chunks == 0:
@@ -539,8 +631,8 @@ def main():
             kk = (args.chunks,) if args.chunks > 0 else (1,)
             row_first = prior.feat_parts == 1 or not feat_ok or world == 1
             fam_row = [(PipelinedRows, 1), (PushRows, 1)] if args.chunks == 0 else [(Pieces, kk[0])]
-            fam_feat = [(PipelinedFeatures, 1), (FeaturePieces, kk[0])] if feat_ok and world > 1 else []
-            cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[:1])
+            fam_feat = [(PushFeatures, 1), (PipelinedFeatures, 1)] if feat_ok and world > 1 else []
+            cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[1:2])
     assert cands, "no admissible partition"
     timed = {}
     if len(cands) == 1:

@@ -93,7 +93,7 @@ def test_inference_driver_under_the_harness_command_line():
     assert res["repeat"] == 2 and res["infer_time(ms)"] > 0
 
 
-@pytest.mark.parametrize("partition", ["auto", "pipelined", "row", "feature", "pipelined-feature", "push"])
+@pytest.mark.parametrize("partition", ["auto", "pipelined", "row", "feature", "pipelined-feature", "push", "push-feature"])
 def test_bench_two_ranks_logic_check(partition):
     """the N > 1 paths of bench.py with 2 ranks over gloo on this one GPU (a logic check, not a measurement): every
     partition assembles the exact C on every rank (column-count checksum) and prints one JSON line from rank 0"""

@@ -38,7 +38,7 @@ def _bench_line(stdout):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("partition", ["pipelined", "row", "feature", "pipelined-feature", "push"])
+@pytest.mark.parametrize("partition", ["pipelined", "row", "feature", "pipelined-feature", "push", "push-feature"])
 def test_bench_one_rank_over_rccl(partition):
     """every exchange scheme of bench.py with its collectives running on RCCL: the gathered C is exact, the JSON line says
     how many ranks RCCL saw and which candidate ran"""
@@ -47,7 +47,7 @@ def test_bench_one_rank_over_rccl(partition):
     assert d["n_gpus"] == 1 and d["config"]["rccl_world"] == 1 and d["config"]["backend"] == "nccl"
     assert d["check"].startswith("column-count checksum"), d.get("check")
     assert d["config"]["ms_per_step_products_only"] > 0
-    assert d["config"]["candidate"].split(":")[0] in ("PipelinedRows", "Pieces", "FeaturePieces", "PipelinedFeatures", "PushRows")
+    assert d["config"]["candidate"].split(":")[0] in ("PipelinedRows", "Pieces", "FeaturePieces", "PipelinedFeatures", "PushRows", "PushFeatures")
 
 
 def test_bench_torchrun_number_equals_plain_number():
