@@ -1348,6 +1348,14 @@ __global__ void k_pack_vectors(const T *const *__restrict__ vecs, uint32_t g, ui
 // ---------------------------------------------------------------------------
 // max |x| as the bit pattern of a non-negative float (orders like an unsigned integer)
 // FLAT = the matrix is one contiguous, 16-byte aligned array whose length is a multiple of 4: float4 accesses
+// zero one word (a kernel node instead of a 4-byte memset node: inside a captured HIP graph the memset of the |max| word was
+// observed to race with the kernels of the previous aggregation that still read it)
+__global__ void k_zero_word(uint32_t *p) { *p = 0u; }
+// C[0:nrows, 0:w] = 0 (row stride ldc), as a kernel node for the same reason
+template <typename T> __global__ void k_zero_rows(T *__restrict__ C, int64_t ldc, uint64_t nrows, uint32_t w) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows * w) C[(int64_t)(i / w) * ldc + (i % w)] = T(0);
+}
 template <bool FLAT>
 __global__ void k_absmax_bits(const float *__restrict__ x, int64_t ld, uint64_t rows, uint32_t w, uint32_t *out) {
     const uint64_t total = rows * w;

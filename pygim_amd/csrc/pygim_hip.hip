@@ -395,7 +395,9 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     const bool coo_native = (g->format == PYGIM_COO) && p.rowind != nullptr && !use_panel && !g_tune.coo_via_rowptr && lanes_needed > 16;
     if (coo_native) {
         // nnz-split kernel + carry fix-up
-        if (!accumulate) HIP_TRY(hipMemset2DAsync(C, (size_t)ldc * sizeof(T), 0, (size_t)w * sizeof(T), nrows, st));
+        if (!accumulate && (uint64_t)nrows * w > 0)
+            hipLaunchKernelGGL((k_zero_rows<T>), dim3((unsigned)(((uint64_t)nrows * w + 255) / 256)), dim3(256), 0, st, C, ldc,
+                               (uint64_t)nrows, w);
         if (p.nnz == 0) return 0;
         const uint32_t chunk = (uint32_t)g_tune.coo_chunk;
         const uint32_t nchunks = (uint32_t)((p.nnz + chunk - 1) / chunk);
@@ -1308,9 +1310,9 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     const uint64_t rows = (uint64_t)g->total_cols, orows = (uint64_t)g->total_rows;
     const uint32_t h = (uint32_t)g->h;
     uint32_t *amax = (uint32_t *)(g->d_flags + 3);
-    HIP_TRY(hipMemsetAsync(amax, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, amax);
     if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
-    if (rows * h == 0 && scale_out) HIP_TRY(hipMemsetAsync(scale_out, 0, sizeof(float), st));
+    if (rows * h == 0 && scale_out) hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, (uint32_t *)scale_out);
     if (Part *p = fusable_part<T>(g)) {
         // FUSED: |max| reduction, then the slice-major copy is written quantised straight from the float features,
         // and every row's last panel item stores float(sum) * scale (no row-major quantised matrix, no integer result,

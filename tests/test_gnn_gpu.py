@@ -426,3 +426,11 @@ def test_quantised_entry_points_reject_bad_arguments(rng):
         _lib.group_free(hd64)
     finally:
         _lib.release()
+
+
+def test_forward_pass_replays_from_a_hip_graph():
+    """inference.py --graph 1: the whole forward pass (torch dense layers + the fused aggregation calls of the C ABI) captured
+    into a HIP graph after two warm-up runs and replayed; same logits checksum as the eager run"""
+    eager, _ = _run_inference(1, ["--data_type=INT8", "--graph=0"])
+    graph, _ = _run_inference(1, ["--data_type=INT8", "--graph=1"])
+    assert eager == graph, (eager, graph)
