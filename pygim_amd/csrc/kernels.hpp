@@ -1000,13 +1000,11 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const uint32_t *__restrict__ 
     const uint32_t total = pcols * (uint32_t)W;
     T *xs = reinterpret_cast<T *>(pygim_lds_raw);
     const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(xp) & 15u) / sizeof(T));
-    if (ldx == (int64_t)W && (reinterpret_cast<uintptr_t>(xp) % sizeof(T)) == 0 && (col_base > 0 || mis == 0)) {
+    if (ldx == (int64_t)W && (reinterpret_cast<uintptr_t>(xp) % sizeof(T)) == 0 && (uint64_t)col_base * W >= mis) {  // (never before X)
         constexpr uint32_t PER = 16 / sizeof(T);
-        const uint32_t nvec = (total + mis + PER - 1) / PER;  // (the last piece may reach past the panel: X is padded by the caller? no --
         const u32x4_t *src = reinterpret_cast<const u32x4_t *>(xp - mis);
         u32x4_t *dst = reinterpret_cast<u32x4_t *>(xs);
-        const uint32_t full = (total + mis) / PER;            //  whole pieces only; the ragged tail goes element by element)
-        (void)nvec;
+        const uint32_t full = (total + mis) / PER;  // whole 16-byte pieces; the ragged tail goes element by element (never past X)
         for (uint32_t i = threadIdx.x; i < full; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
         for (uint32_t i = full * PER + threadIdx.x; i < total + mis; i += blockDim.x) xs[i] = (xp - mis)[i];
         xs += mis;
