@@ -746,9 +746,9 @@ def main():
             traffic = None
     plan_info = _lib.group_plan(handles[0])
     n_panels = int(plan_info["n_panels"])
-    # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
+    # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
     amode = 3 if plan_info["col16"] else 2
-    kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false> x {n_panels} panel launches per product" if n_panels
+    kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false,false> x {n_panels} panel launches per product" if n_panels
              else "k_csr_wide<float,4>")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
