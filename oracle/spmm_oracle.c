@@ -14,6 +14,14 @@
  * cannot be compiled here.  The restatement below follows those loops line by
  * line (citations on every function) and is cross-checked in tests/ against two
  * independent libraries (torch.sparse.mm, scipy.sparse).
+ * The absent dependency, for the record: torch_sparse (rusty1s/pytorch_sparse), whatever wheel
+ * `pip install ... -f https://data.pyg.org/whl/torch-1.13.1+cpu.html` resolved to (Libs/install_libs.sh:13,
+ * no version given; the 0.6.x line for torch 1.13).  Its published algorithm for the call the
+ * driver makes -- torch_sparse.matmul(adj_t, x), reduce = "sum" (spmm_test.py:25) -- is
+ * csrc/cpu/spmm_cpu.cpp: rows in parallel, and per row `for e in rowptr[r] .. rowptr[r+1]:
+ * out[r, k] += value[e] * mat[col[e], k]` in the element type of `mat`: the stored-order row sum
+ * that oracle_spmm_csr_* below computes.  tests/golden/make_golden.py checks the vectors against
+ * the real package whenever it can be imported and records which in `pinned_by`.
  * PINNED: the partition functions (oracle_partition_*) are checked against the
  * reference's own support/partition.c, which compiles from its own sources with
  * plain gcc (oracle/Makefile target `ref` -> oracle/_ref/).
