@@ -22,6 +22,10 @@ SHAPES = {
     "reddit-mini": (4_096, 4_096 * 123, 1_500),
     "products-mini": (20_000, 20_000 * 50, 4_000),
 }
+# (nodes, edges, max degree) of the datasets the reference drivers know by name (spmm_test.py:42-53)
+DATASETS = {"PubMed": (19_717, 88_648, 171), "Reddit": SHAPES["reddit"], "Cora": SHAPES["cora"],
+            "AmazonProducts": (500_000, 84_000_000, 30_000), "ogbn-arxiv": (169_343, 1_166_243, 13_161),
+            "ogbn-proteins": (132_534, 79_122_504, 7_750), "ogbn-products": SHAPES["ogbn-products"]}
 
 
 def _gen(seed, device):

@@ -23,10 +23,7 @@ from pygim_amd.sparse_tensor import SparseTensor, matmul
 
 TORCH_TYPES = {"INT64": torch.int64, "INT32": torch.int32, "INT16": torch.int16, "INT8": torch.int8,
                "FLT32": torch.float32, "DBL64": torch.float64}
-# (nodes, edges, max degree) of the datasets the reference driver knows (spmm_test.py:42-53)
-DATASETS = {"PubMed": (19_717, 88_648, 171), "Reddit": synth.SHAPES["reddit"], "Cora": synth.SHAPES["cora"],
-            "AmazonProducts": (500_000, 84_000_000, 30_000), "ogbn-arxiv": (169_343, 1_166_243, 13_161),
-            "ogbn-proteins": (132_534, 79_122_504, 7_750), "ogbn-products": synth.SHAPES["ogbn-products"]}
+DATASETS = synth.DATASETS  # (nodes, edges, max degree) of the datasets the reference driver knows (spmm_test.py:42-53)
 
 
 def ms_since(t0):

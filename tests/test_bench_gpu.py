@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +92,35 @@ def test_inference_driver_under_the_harness_command_line():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     res = _parse_like_the_harness(r.stdout)
     assert res["repeat"] == 2 and res["infer_time(ms)"] > 0
+
+
+@pytest.mark.parametrize("backend,model", [("spmm_default", None), ("spmm_grande", "gcn"), ("spmv_sparseP", None)])
+def test_experiment_harness_builds_runs_and_parses(backend, model, tmp_path):
+    """pygim_amd/experiment.py end to end on the GPU: Experiment.build links the variant's library where run() looks for
+    it, run() writes the named .out / .err, parse_result reduces them (utils/experiment.py:277-491)"""
+    sys.path.insert(0, ROOT)
+    from pygim_amd.experiment import Experiment
+
+    e = Experiment(dataset="PubMed", sp_part=2 if model is None else 1, ds_part=2, sp_format="COO" if "spmv" in backend else "CSR",
+                   dense_size=64, dtype="INT32", balance="nnz", balance_tsklt="nnz", nr_tasklets=16, cg_lock=False, cache_size=32,
+                   backend=backend, nr_dpus=64 if model is None else None, model=model, num_layers=3 if model else None)
+    build_root, res = str(tmp_path / "build"), str(tmp_path / "results")
+    lib = e.build(ROOT, build_root)
+    assert os.path.isfile(lib)
+    assert e.run(ROOT, "./data", build_root, result_root=res, repeat=2) == 0
+    assert e.status_at(res) == "done"
+    got = e.parse_result(res)
+    assert got["repeat"] == 2
+    with open(e.stdout_path(res)) as f:
+        same = _parse_like_the_harness(f.read())
+    assert set(same) == set(got) and all(np.allclose(same[k], got[k]) for k in got)
+    if model is None:
+        assert got["pim_time_spmm(ms)"] > 0 and got["outputs_equal"] == 1.0
+    else:
+        assert got["infer_time(ms)"] > 0
+    # the library that ran is the one linked into the per-configuration build directory
+    with open(e.stderr_path(res)) as f:
+        assert "Traceback" not in f.read()
 
 
 @pytest.mark.parametrize("partition", ["auto", "pipelined", "row", "feature", "pipelined-feature", "push", "push-feature"])
