@@ -13,8 +13,10 @@ N > 1 : strong scaling of the SAME graph with the full C on every rank at the en
         reference's partition_by_nnz_csr walk, X replicated) in 1 / 2 / 4 pieces with the
         all-gather of each piece behind the products of the others; the same with the
         all-gather of step k behind the product of step k + 1 ("pipelined"); feature split
-        (ds_parts: A replicated, h / N features per rank).  All exchanges are RCCL
-        all-gathers and complete inside the timed region.
+        (ds_parts: A replicated, h / N features per rank); and "push" forms of both, where a
+        rank's block goes into every peer's result matrix by peer copies (HIP IPC, copy engines)
+        with a 4-byte RCCL all-reduce as the arrival barrier (PYGIM_BENCH_NO_PUSH=1 keeps to
+        RCCL all-gathers).  All exchanges complete inside the timed region.
 
 Launch: python bench.py --gpus 1 --steps 20 --warmup 5
         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -22,6 +24,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -632,6 +635,9 @@ def main():
             row_first = prior.feat_parts == 1 or not feat_ok or world == 1
             fam_row = [(PipelinedRows, 1), (PushRows, 1)] if args.chunks == 0 else [(Pieces, kk[0])]
             fam_feat = [(PushFeatures, 1), (PipelinedFeatures, 1)] if feat_ok and world > 1 else []
+            if os.environ.get("PYGIM_BENCH_NO_PUSH", "0") == "1":  # RCCL collectives only (no HIP IPC peer copies)
+                fam_row = [c for c in fam_row if c[0] is not PushRows] + ([(Pieces, 2)] if args.chunks == 0 else [])
+                fam_feat = [c for c in fam_feat if c[0] is not PushFeatures]
             cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[1:2])
     assert cands, "no admissible partition"
     timed = {}
@@ -657,16 +663,30 @@ def main():
                 timed[f"{cls.__name__}:{kk}"] = None
                 continue
             live[:] = [pl]
-            for _ in range(2):
-                pl.step()
-            fence()
-            t_c = time.perf_counter()
-            for _ in range(4):
-                pl.step()
-            fence()
-            tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64, device=dev)
+            # a candidate whose exchange fails at run time on every rank alike (a refused peer copy, say) is dropped as well
+            try:
+                for _ in range(2):
+                    pl.step()
+                fence()
+                t_c = time.perf_counter()
+                for _ in range(4):
+                    pl.step()
+                fence()
+                t_c = time.perf_counter() - t_c
+            except RuntimeError as e:
+                t_c = float("inf")
+                print(f"[bench] rank {rank}: candidate {cls.__name__} failed while running: {str(e)[:200]}", file=sys.stderr)
+            tt = torch.tensor([t_c], dtype=torch.float64, device=dev)
             if multi:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if not math.isfinite(float(tt.item())):
+                live[:] = []
+                try:
+                    pl.free()
+                except RuntimeError:
+                    pass
+                timed[f"{cls.__name__}:{kk}"] = None
+                continue
             timed[f"{cls.__name__}:{kk}"] = round(float(tt.item()) / 4 * 1e3, 4)
             if best is None or float(tt.item()) < best[0]:
                 if best is not None:
