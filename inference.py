@@ -89,6 +89,7 @@ def get_args():
     ap.add_argument("--ds_parts", type=int, default=1)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--nr_dpus", type=int, default=0)
+    ap.add_argument("--group_per_rank", type=int, default=1)  # what the harness passes to the multigroup backend (experiment.py:434); no meaning here
     ap.add_argument("--device", type=str, default="cuda" if torch.cuda.is_available() else "cpu")
     ap.add_argument("--graph", type=int, default=0, help="1 = capture the forward pass into a HIP graph after two warm-up runs and "
                     "replay it (one launch per inference: pays on small graphs, where a forward pass is ~40 short kernels)")

@@ -22,7 +22,7 @@ from typing import Optional
 
 import numpy as np
 
-__all__ = ["Experiment", "run_experiments", "make_argument_parser", "make_logger"]
+__all__ = ["Experiment", "run_experiments", "results_to_csv", "make_argument_parser", "make_logger"]
 
 # backend name -> (driver --version, variant directory under backend_pim/)      (experiment.py:386-395)
 BACKENDS = {
@@ -185,6 +185,8 @@ class Experiment:
             cmd.append(f"--nr_dpus={self.nr_dpus}")
         if whole_model:
             cmd += [f"--model={self.model}", f"--num_layers={self.num_layers}"]
+        if self.backend == "spmm_multigroup" and self.groups_per_rank is not None:
+            cmd.append(f"--group_per_rank={self.groups_per_rank}")   # experiment.py:432-434; accepted and ignored here
         return cmd
 
     def run(self, src_root: str, data_root: str, build_root: str, result_root: Optional[str] = None, repeat: int = 3,
@@ -255,6 +257,49 @@ def parse_stdout(lines):
     out = {k: np.asarray(v).reshape(repeat, -1).mean(axis=0).sum(axis=-1) for k, v in values.items()}
     out["repeat"] = repeat
     return out
+
+
+def results_to_csv(out_dir: str, csv_dir: Optional[str] = None):
+    """backend_pim/spmv_sparseP/parse_results.py:24-76 for a directory of ``.out`` files: per file one CSV with a row per
+    repeat and an ``avg`` row, the derived column ``pim_time_dense(ms) = pim_time_spmm(ms) - load_sparse_time`` when the
+    run logged both (the shims print the per-run timer lines under PYGIM_DATA_LOG=1), and ``average_all.csv`` with one
+    line per file.  Returns {file stem: {key: average}}."""
+    csv_dir = csv_dir or os.path.join(out_dir, "csv_result")
+    os.makedirs(csv_dir, exist_ok=True)
+    averages = {}
+    for name in sorted(os.listdir(out_dir)):
+        if not name.endswith(".out"):
+            continue
+        cols, repeats = collections.OrderedDict(), 0
+        with open(os.path.join(out_dir, name), "r") as reader:
+            for line in reader:
+                if line.startswith("-------------------- Repeat") or line.startswith("-------------------- Model"):
+                    repeats += 1
+                if line.startswith("[DATA]") and ": " in line:
+                    label, value = line[6:].rstrip("\n").split(": ", 1)
+                    cols.setdefault(label, []).append(float(value))
+        if repeats == 0:
+            continue
+        # several lines of one key inside a repeat (one per layer, say) are summed, as parse_result does
+        table = collections.OrderedDict((k, np.asarray(v).reshape(repeats, -1).sum(axis=1)) for k, v in cols.items()
+                                        if len(v) % repeats == 0)
+        if "pim_time_spmm(ms)" in table and "load_sparse_time" in table:
+            table["pim_time_dense(ms)"] = table["pim_time_spmm(ms)"] - table["load_sparse_time"]
+        keys = list(table)
+        with open(os.path.join(csv_dir, name[:-4] + ".csv"), "w") as w:
+            w.write(", ".join(["Repeat"] + keys) + "\n")
+            for rep in range(repeats):
+                w.write(", ".join([str(rep)] + [repr(float(table[k][rep])) for k in keys]) + "\n")
+            w.write(", ".join(["avg"] + [repr(float(table[k].mean())) for k in keys]) + "\n")
+        averages[name[:-4]] = {k: float(table[k].mean()) for k in keys}
+    all_keys = []
+    for avg in averages.values():
+        all_keys += [k for k in avg if k not in all_keys]
+    with open(os.path.join(csv_dir, "average_all.csv"), "w") as w:
+        w.write(", ".join(["run"] + all_keys) + "\n")
+        for stem, avg in averages.items():
+            w.write(", ".join([stem] + [repr(avg[k]) if k in avg else "" for k in all_keys]) + "\n")
+    return averages
 
 
 def run_experiments(args, build_set, experiments, logger: logging.Logger, accept_failures: bool = False, repeat: int = 1):

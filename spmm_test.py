@@ -92,6 +92,7 @@ def get_args():
     ap.add_argument("--ds_parts", type=int, default=1)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--nr_dpus", type=int, default=0)
+    ap.add_argument("--group_per_rank", type=int, default=1)  # what the harness passes to the multigroup backend (experiment.py:434); no meaning here
     ap.add_argument("--device", type=str, default="cpu", choices=["cpu", "cuda"])
     args = ap.parse_args()
     print(args, flush=True)

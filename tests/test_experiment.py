@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from pygim_amd.experiment import Experiment, make_argument_parser, parse_stdout, run_experiments  # noqa: E402
+from pygim_amd.experiment import Experiment, make_argument_parser, parse_stdout, results_to_csv, run_experiments  # noqa: E402
 
 
 def _exp(**kw):
@@ -58,6 +58,8 @@ def test_command_line_is_the_one_the_reference_builds():
     assert "--version=cpu" in c and "--lib_path=None" in c
     with pytest.raises(NotImplementedError):
         _exp(backend=None).command("/s", "/d", "/b")   # the default names are not runnable in the reference either
+    m = _exp(backend="spmm_multigroup", groups_per_rank=2).command("/s", "/d", "/b")
+    assert m[-1] == "--group_per_rank=2" and "--version=spmm" in m    # experiment.py:432-434
 
 
 def test_data_lines_reduce_like_the_reference():
@@ -127,3 +129,22 @@ def test_dry_run_and_build_link(tmp_path):
         _exp(backend="backend_pim_group").build(ROOT, str(tmp_path / "b"))
     ns = make_argument_parser("exp1").parse_args(["run", "--skip_failed"])
     assert ns.action == "run" and ns.result_root == "./results/exp1" and ns.skip_failed and not ns.dry_run
+
+
+def test_out_files_to_csv(tmp_path):
+    """the per-run CSVs of backend_pim/spmv_sparseP/parse_results.py: a row per repeat, the avg row, and the derived
+    pim_time_dense(ms) = pim_time_spmm(ms) - load_sparse_time"""
+    out = tmp_path / "res"
+    out.mkdir()
+    (out / "a.out").write_text("-------------------- Repeat 0\n[DATA]load_sparse_time: 2.0\n[DATA]pim_time_spmm(ms): 10.0\n"
+                               "-------------------- Repeat 1\n[DATA]load_sparse_time: 4.0\n[DATA]pim_time_spmm(ms): 20.0\n")
+    (out / "b.out").write_text("-------------------- Model=gcn Repeat=0\n[DATA]infer_time(ms): 3.0\n")
+    (out / "b.err").write_text("ignored")
+    avg = results_to_csv(str(out))
+    assert avg["a"] == {"load_sparse_time": 3.0, "pim_time_spmm(ms)": 15.0, "pim_time_dense(ms)": 12.0}
+    assert avg["b"] == {"infer_time(ms)": 3.0}
+    rows = (out / "csv_result" / "a.csv").read_text().splitlines()
+    assert rows[0] == "Repeat, load_sparse_time, pim_time_spmm(ms), pim_time_dense(ms)"
+    assert rows[1] == "0, 2.0, 10.0, 8.0" and rows[2] == "1, 4.0, 20.0, 16.0" and rows[3] == "avg, 3.0, 15.0, 12.0"
+    table = (out / "csv_result" / "average_all.csv").read_text().splitlines()
+    assert table[0].startswith("run, load_sparse_time") and table[1].startswith("a, 3.0, 15.0, 12.0") and table[2].startswith("b, ")
