@@ -296,6 +296,13 @@ def main():
             return (f"sp_parts={world} as an nnz-balanced row split, one product per rank; the all-gather (RCCL) of step k "
                     f"overlaps the product of step k+1 (two gather buffers), all gathers complete inside the timed region")
 
+    def check_peer(t):
+        """a peer's buffer opened through HIP IPC must be directly reachable from this rank's device (xGMI / PCIe P2P);
+        otherwise the push candidates are not offered (the exception drops them on every rank)"""
+        other = t.device.index
+        if other != dev.index and not torch.cuda.can_device_access_peer(dev.index, other):
+            raise RuntimeError(f"device {dev.index} has no peer access to device {other}")
+
     class PushRows:
         """sp_parts = world as an nnz-balanced row split whose exchange is a PUSH over xGMI by the copy engines: every rank
         writes its result block straight into its place in every peer's [N, h] matrix (the peers' buffers are opened through
@@ -324,6 +331,7 @@ def main():
                 for r in range(world):
                     if r != rank:
                         self.peer[r] = [fn(*a) for fn, a in everyone[r]]
+                        check_peer(self.peer[r][0])
             self.copy_streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
             self.sync_stream = torch.cuda.Stream(device=dev)
             self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -529,6 +537,7 @@ def main():
                 for r in range(world):
                     if r != rank:
                         self.peer[r] = [fn(*a) for fn, a in everyone[r]]
+                        check_peer(self.peer[r][0])
             self.copy_streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
             self.sync_stream = torch.cuda.Stream(device=dev)
             self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
