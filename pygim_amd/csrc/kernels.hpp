@@ -977,144 +977,268 @@ __global__ void k_build_panel_ptr(const uint32_t *__restrict__ perm, const uint3
 // The SpMV end with the dense operand staged in LDS (spmv_sparseP/dpu_kernels/spmv_mul_coo_dpu.c keeps its slice of the
 // vector in the DPU's scratchpad the same way).  For rows of X of at most 16 bytes a gather through the cache hierarchy
 // costs a whole 128-byte L2 request per stored entry (k_csr_vec: 0.68 ms on the Reddit-shaped graph); here a 1024-thread
-// workgroup copies ONE column panel of X (panel_cols rows of W elements, <= 144 KiB) into LDS with coalesced loads and walks
-// a slab of the panel's length-sorted work items: 16 lanes per item stride over its entries (coalesced 16-bit panel-local
-// column ids, one ds_read per entry), a fixed butterfly adds the lanes' partial sums, and the row's running sum continues
-// from C for later panels (FIRST flag) as in the wide sweep.  Integers exact; floats in a fixed order other than the stored
-// one (inside the 1e-5 bound, as k_csr_vec).
+// workgroup copies ONE column panel of X (panel_cols rows of W elements, <= 128 KiB) into LDS with coalesced loads and every
+// stored entry is one ds_read.  k_spmv_lds: ONE launch for all column panels, no read-modify-write of C, no stores inside
+// the software pipeline (0.14 ms; a first form with a launch per panel and the running sum continued through C: 0.38 ms).
+//   * a workgroup (one per CU) is given one unit = (panel, slot of nslots): it stages the panel of X once and walks the items
+//     slot, slot + nslots, ... of the panel's length-sorted list -- the workgroups of a panel share it like cards dealt in
+//     turn, so each sees the whole length spectrum;
+//   * the sorted list falls into four length classes (at most 64 / 128 / 256 entries, and longer) worked by lane groups of
+//     8 / 16 / 32 / 64 lanes, 8 entries per lane, so that an item is ONE pass: the loop over a lane group's items is then
+//     perfectly regular and runs as a register pipeline -- descriptors 6 items ahead, the 16 bytes of ids (and the weights)
+//     3 items ahead, every load unconditional (indices clamped, never predicated), so the waits are vmcnt(N) for the oldest
+//     load only.  Only the whole-wave class has items of several passes (beyond 512 entries: rare), fetched on demand;
+//   * gfx9 counts stores in vmcnt and lets them retire out of order with loads: ONE pending store turns every later wait
+//     for a load into vmcnt(0) and drains the pipeline (the first form ran 82 % of its wave cycles in such waits).  So a
+//     lane group parks (row, sum) in LDS and flushes F of them at a time;
+//   * results go to part[panel][row] (each written at most once; the buffer is zeroed before), and k_spmv_reduce adds a
+//     row's panels in panel order into C: deterministic, integers exact, floats inside the 1e-5 bound.
 // ---------------------------------------------------------------------------
 extern __shared__ unsigned char pygim_lds_raw[];
+struct SpmvUnit {
+    uint32_t item_off;  // the panel's first item in the part's item arrays
+    uint32_t n_items;   // its items, longest first
+    uint32_t n64, n32, n16;  // the list's leading items by length class: > 256 entries (a wave each, 512 per pass), 129..256 (32 lanes),
+                             // 65..128 (16 lanes); the rest, at most 64 entries, take 8 lanes -- 8 entries per lane in every class
+    uint32_t col_base, pcols;
+    uint32_t slot, nslots;
+    uint32_t panel;
+};
+typedef unsigned short u16x8_u __attribute__((ext_vector_type(8), aligned(2)));
+
+template <int CTRL, typename A> __device__ __forceinline__ A dpp_get(A v) {
+    if constexpr (sizeof(A) == 8) {
+        union { A t; int u[2]; } in, out;
+        in.t = v;
+        out.u[0] = __builtin_amdgcn_update_dpp(0, in.u[0], CTRL, 0xF, 0xF, false);
+        out.u[1] = __builtin_amdgcn_update_dpp(0, in.u[1], CTRL, 0xF, 0xF, false);
+        return out.t;
+    } else {
+        union { A t; int u; } in, out;
+        in.t = v;
+        out.u = __builtin_amdgcn_update_dpp(0, in.u, CTRL, 0xF, 0xF, false);
+        return out.t;
+    }
+}
+// sum over the LG lanes of a lane group, in a fixed order, every lane ends with the total
+template <int LG, typename A> __device__ __forceinline__ A lanes_sum(A v) {
+    static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "half a DPP row, a row, two rows or the whole wave");
+    v += dpp_get<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);  // row_half_mirror
+    if constexpr (LG >= 16) v += dpp_get<0x140>(v);  // row_mirror
+    if constexpr (LG >= 32) v += shfl_xor_t<A>(v, 16);
+    if constexpr (LG == 64) v += shfl_xor_t<A>(v, 32);
+    return v;
+}
+
+template <typename T, int W, bool HAS_VALS, int LG>
+__device__ __forceinline__ void spmv_lds_class(const char *__restrict__ ir, const char *__restrict__ ib,
+                                               const char *__restrict__ il, uint32_t n, uint32_t first, uint32_t stride,
+                                               const char *__restrict__ col16, const T *__restrict__ vals,
+                                               const T *__restrict__ xs, uint32_t pcols,
+                                               typename AccOf<T>::type *__restrict__ out, uint32_t *st_row,
+                                               typename AccOf<T>::type *st_val, uint32_t F, uint32_t li) {
+    using A = typename AccOf<T>::type;
+    constexpr int D = HAS_VALS ? 2 : 3, R = 6;  // (weights cost 8 more loads and up to 16 registers per item in flight)
+    static_assert(R % D == 0 && R >= 2 * D, "descriptor ring: a multiple of the id ring, at least twice as deep");
+    constexpr uint32_t PASS = 8u * LG;  // entries per pass
+    // this lane group's items are first, first + stride, ...; the wave runs as long as its FIRST group has items
+    const uint32_t my_iters = first < n ? (n - first + stride - 1) / stride : 0u;
+    const uint32_t iters = rfl(my_iters);  // lane 0 sits in the wave's first group
+    if (iters == 0) return;
+    uint32_t d_row[R], d_s[R], d_len[R];
+    u16x8_u d_q[D];
+    T d_v[D][8];
+    auto ld_desc = [&](int slot, uint32_t t) {
+        const uint32_t ii = min(first + t * stride, n - 1u) << 2;  // clamped: always a real item, never a predicated load
+        d_row[slot] = *reinterpret_cast<const uint32_t *>(ir + ii);
+        d_s[slot] = *reinterpret_cast<const uint32_t *>(ib + ii);
+        d_len[slot] = *reinterpret_cast<const uint32_t *>(il + ii) & 0x3FFFFFFFu;
+    };
+    auto ld_ids = [&](int qslot, int dslot, uint32_t k0) {  // entries k0 + 8 li .. + 7 of the item in descriptor slot dslot
+        const uint32_t len = d_len[dslot], s = d_s[dslot];
+        const uint32_t e0 = (k0 + 8u * li < len) ? k0 + 8u * li : 0u;  // lanes past the end re-read the item's first ids
+        d_q[qslot] = __builtin_nontemporal_load(reinterpret_cast<const u16x8_u *>(col16 + ((s + e0) << 1)));  // (id array is padded)
+        if constexpr (HAS_VALS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t e = k0 + 8u * li + (uint32_t)u;
+                d_v[qslot][u] = __builtin_nontemporal_load(vals + (e < len ? s + e : 0u));  // element 0 stands in: masked below
+            }
+        }
+    };
+    auto add_pass = [&](A(&acc)[W], const u16x8_u q, const T(&v)[8], uint32_t k0, uint32_t len) {
+        T xv[8][W];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool ok = k0 + 8u * li + (uint32_t)u < len;
+            const uint32_t c = ok ? (uint32_t)q[u] : pcols;  // the all-zero row staged behind the panel
+#pragma unroll
+            for (int j = 0; j < W; j++) xv[u][j] = xs[c * W + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if constexpr (HAS_VALS) {
+                const bool ok = k0 + 8u * li + (uint32_t)u < len;
+                const A w = ok ? to_acc<T>(v[u]) : A(0);
+#pragma unroll
+                for (int j = 0; j < W; j++) acc[j] += w * to_acc<T>(xv[u][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < W; j++) acc[j] += to_acc<T>(xv[u][j]);
+            }
+        }
+    };
+    auto flush = [&](uint32_t staged) {
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t f = li; f < staged; f += LG) {
+            const uint32_t row = st_row[f];
+            if (row != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int j = 0; j < W; j++) out[(size_t)row * W + j] = st_val[f * W + j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int t = 0; t < R; t++) ld_desc(t, (uint32_t)t);
+#pragma unroll
+    for (int t = 0; t < D; t++) ld_ids(t, t, 0u);
+    uint32_t staged = 0;
+    for (uint32_t t0 = 0; t0 < iters; t0 += R) {
+#pragma unroll
+        for (int sx = 0; sx < R; sx++) {
+            const uint32_t t = t0 + (uint32_t)sx;
+            const bool valid = t < my_iters;
+            const uint32_t row = d_row[sx], s = d_s[sx];
+            const uint32_t len = valid ? d_len[sx] : 0u;
+            const u16x8_u q = d_q[sx % D];
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = HAS_VALS ? d_v[sx % D][u] : T(0);
+            // keep the pipeline full first: descriptor of item t + R, ids of item t + D
+            ld_desc(sx, t + (uint32_t)R);
+            ld_ids(sx % D, (sx + D) % R, 0u);
+            A acc[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) acc[j] = A(0);
+            add_pass(acc, q, v, 0u, len);
+            if constexpr (LG == 64) {  // one item per wave: its length is wave-uniform; passes beyond the first on demand
+                const uint32_t ulen = rfl(len);
+                for (uint32_t k0 = PASS; k0 < ulen; k0 += PASS) {
+                    const uint32_t e0 = (k0 + 8u * li < ulen) ? k0 + 8u * li : 0u;
+                    const u16x8_u q2 = __builtin_nontemporal_load(reinterpret_cast<const u16x8_u *>(col16 + ((s + e0) << 1)));
+                    T v2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t e = k0 + 8u * li + (uint32_t)u;
+                        v2[u] = HAS_VALS ? __builtin_nontemporal_load(vals + (e < ulen ? s + e : 0u)) : T(0);
+                    }
+                    add_pass(acc, q2, v2, k0, ulen);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; j++) acc[j] = lanes_sum<LG, A>(acc[j]);
+            if (li == 0) {
+                st_row[staged + sx] = valid ? row : 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < W; j++) st_val[(staged + sx) * W + j] = acc[j];
+            }
+        }
+        staged += R;
+        if (staged + R > F || t0 + R >= iters) {
+            flush(staged);
+            staged = 0;
+        }
+    }
+}
+
 template <typename T, int W, bool HAS_VALS>
-__global__ __launch_bounds__(1024) void k_spmv_lds(const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_begin,
-                                                   const uint32_t *__restrict__ item_len, uint32_t nitems,
+__global__ __launch_bounds__(1024) void k_spmv_lds(const SpmvUnit *__restrict__ units, uint32_t nunits,
+                                                   const uint32_t *__restrict__ item_row,
+                                                   const uint32_t *__restrict__ item_begin,
+                                                   const uint32_t *__restrict__ item_len,
                                                    const unsigned short *__restrict__ col16, const T *__restrict__ vals,
-                                                   const T *__restrict__ X, int64_t ldx, T *__restrict__ C, int64_t ldc,
-                                                   int accumulate, uint32_t col_base, uint32_t pcols, uint32_t items_per_block) {
+                                                   const T *__restrict__ X, int64_t ldx,
+                                                   typename AccOf<T>::type *__restrict__ part, uint32_t nrows,
+                                                   uint32_t stage_off, uint32_t F16) {
     static_assert(W >= 1 && W <= 4, "rows of at most 4 elements");
     using A = typename AccOf<T>::type;
-    constexpr int LG = 16;  // lanes per work item (8: 0.43 ms, 16: 0.38 ms on the Reddit-shaped graph)
-    // stage the panel: rows [col_base, col_base + pcols) of X, W elements each.  Dense X (ldx == W): 16-byte pieces starting at
-    // the 16-byte boundary at or below the panel's first byte (the few leading elements belong to the previous panel and are
-    // simply not addressed); else element by element.
-    const T *xp = X + (int64_t)col_base * ldx;
-    const uint32_t total = pcols * (uint32_t)W;
-    T *xs = reinterpret_cast<T *>(pygim_lds_raw);
-    const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(xp) & 15u) / sizeof(T));
-    if (ldx == (int64_t)W && (reinterpret_cast<uintptr_t>(xp) % sizeof(T)) == 0 && (uint64_t)col_base * W >= mis) {  // (never before X)
-        constexpr uint32_t PER = 16 / sizeof(T);
-        const u32x4_t *src = reinterpret_cast<const u32x4_t *>(xp - mis);
-        u32x4_t *dst = reinterpret_cast<u32x4_t *>(xs);
-        const uint32_t full = (total + mis) / PER;  // whole 16-byte pieces; the ragged tail goes element by element (never past X)
-        for (uint32_t i = threadIdx.x; i < full; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
-        for (uint32_t i = full * PER + threadIdx.x; i < total + mis; i += blockDim.x) xs[i] = (xp - mis)[i];
-        xs += mis;
-    } else {
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) xs[i] = xp[(int64_t)(i / W) * ldx + (i % W)];
-    }
-    if (threadIdx.x < (uint32_t)W) xs[pcols * W + threadIdx.x] = T(0);  // the all-zero row (index pcols)
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, li = lane & (LG - 1);
-    const uint32_t grp = threadIdx.x / LG, ngrp = blockDim.x / LG;
-    // the panel's length-sorted items are dealt to the workgroups round-robin (item i -> workgroup i % gridDim.x), so every
-    // workgroup sees the whole length spectrum -- a contiguous slab would hand all the long items to workgroup 0 -- and
-    // inside a workgroup to the lane groups in turn
-    (void)items_per_block;
-    // Software pipeline over a lane group's items: while item t is summed, the ids of item t + 1 (one 8-byte load per lane:
-    // lane li owns entries 4 li .. 4 li + 3 of every 64-entry pass; the id array is padded, so reading past an item's end is
-    // harmless) and the descriptor of item t + 2 are already in flight.
-    // (pipeline depth: the ids of the next D items and the descriptors of the D after those are in flight -- the id array is
-    // streamed once from HBM and a lane group's next item is several microseconds of latency away)
-    constexpr int D = 3;
-    const uint32_t istep = ngrp * gridDim.x;
-    uint32_t i = blockIdx.x + grp * gridDim.x;
-    uint32_t d_row[2 * D], d_s[2 * D], d_lf[2 * D];
-    u16x4_u d_q[D];
-#pragma unroll
-    for (int t = 0; t < 2 * D; t++) {
-        const uint32_t it = i + (uint32_t)t * istep;
-        d_row[t] = d_s[t] = d_lf[t] = 0;
-        if (it < nitems) {
-            d_row[t] = item_row[it];
-            d_s[t] = item_begin[it];
-            d_lf[t] = item_len[it];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = rfl(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    // staging of (row, sum) pairs: a region per wave of 4 F16 pairs, shared out among the wave's lane groups
+    const uint32_t per_wave = 4u * F16 * (4u + (uint32_t)W * (uint32_t)sizeof(A));
+    unsigned char *stw = pygim_lds_raw + stage_off + wave * per_wave;
+    uint32_t *st_row = reinterpret_cast<uint32_t *>(stw);  // 4 F16 rows, then 4 F16 x W sums
+    A *st_val = reinterpret_cast<A *>(stw + 16u * F16);
+    for (uint32_t un_i = blockIdx.x; un_i < nunits; un_i += gridDim.x) {
+        const SpmvUnit un = units[un_i];
+        if (un_i != blockIdx.x) __syncthreads();  // everyone is done with the previous panel before it is overwritten
+        // stage the panel: rows [col_base, col_base + pcols) of X, W elements each.  Dense X (ldx == W): 16-byte pieces starting
+        // at the 16-byte boundary at or below the panel's first byte (the few leading elements belong to the previous panel and
+        // are simply not addressed); else element by element.
+        const uint32_t pcols = un.pcols;
+        const T *xp = X + (int64_t)un.col_base * ldx;
+        const uint32_t total = pcols * (uint32_t)W;
+        T *xs = reinterpret_cast<T *>(pygim_lds_raw);
+        const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(xp) & 15u) / sizeof(T));
+        if (ldx == (int64_t)W && (reinterpret_cast<uintptr_t>(xp) % sizeof(T)) == 0 && (uint64_t)un.col_base * W >= mis) {  // (never before X)
+            constexpr uint32_t PER = 16 / sizeof(T);
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(xp - mis);
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(xs);
+            const uint32_t full = (total + mis) / PER;  // whole 16-byte pieces; the ragged tail element by element (never past X)
+            for (uint32_t i = threadIdx.x; i < full; i += blockDim.x) dst[i] = __builtin_nontemporal_load(src + i);
+            for (uint32_t i = full * PER + threadIdx.x; i < total + mis; i += blockDim.x) xs[i] = (xp - mis)[i];
+            xs += mis;
+        } else {
+            for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) xs[i] = xp[(int64_t)(i / W) * ldx + (i % W)];
         }
-    }
-#pragma unroll
-    for (int t = 0; t < D; t++) {
-        d_q[t] = u16x4_u{0, 0, 0, 0};
-        if (i + (uint32_t)t * istep < nitems)
-            d_q[t] = __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + d_s[t] + 4 * li));
-    }
-    for (; i < nitems; i += istep) {
-        const uint32_t row = d_row[0], s = d_s[0], lf = d_lf[0];
-        const u16x4_u q0 = d_q[0];
-        // advance the pipeline: item t + D gets its ids requested, item t + 2 D its descriptor
-#pragma unroll
-        for (int t = 0; t + 1 < 2 * D; t++) {
-            d_row[t] = d_row[t + 1];
-            d_s[t] = d_s[t + 1];
-            d_lf[t] = d_lf[t + 1];
-        }
-#pragma unroll
-        for (int t = 0; t + 1 < D; t++) d_q[t] = d_q[t + 1];
-        if (i + (uint32_t)D * istep < nitems)
-            d_q[D - 1] = __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + d_s[D - 1] + 4 * li));
-        {
-            const uint32_t it = i + (uint32_t)(2 * D) * istep;
-            if (it < nitems) {
-                d_row[2 * D - 1] = item_row[it];
-                d_s[2 * D - 1] = item_begin[it];
-                d_lf[2 * D - 1] = item_len[it];
+        if (threadIdx.x < (uint32_t)W) xs[pcols * W + threadIdx.x] = T(0);  // the all-zero row (index pcols)
+        __syncthreads();
+        A *out = part + (size_t)un.panel * nrows * W;
+        const char *ir = reinterpret_cast<const char *>(item_row + un.item_off);
+        const char *ib = reinterpret_cast<const char *>(item_begin + un.item_off);
+        const char *il = reinterpret_cast<const char *>(item_len + un.item_off);
+        const char *c16 = reinterpret_cast<const char *>(col16);
+        // the four length classes in turn: a lane group of LG lanes per item, 64 / LG groups per wave, each with its share of the
+        // wave's staging region
+        uint32_t done = 0;
+        auto run_class = [&](auto lg_tag, uint32_t n) {
+            constexpr int LG = decltype(lg_tag)::value;
+            constexpr uint32_t GW = 64u / LG;
+            if (n > 0) {
+                const uint32_t gw = lane / LG, o = done << 2;
+                const uint32_t f_lg = F16 * LG / 16u;
+                spmv_lds_class<T, W, HAS_VALS, LG>(ir + o, ib + o, il + o, n, un.slot + un.nslots * (wave * GW + gw),
+                                                   un.nslots * nwaves * GW, c16, vals, xs, pcols, out, st_row + gw * f_lg,
+                                                   st_val + gw * f_lg * W, f_lg, lane % LG);
             }
-        }
-        const uint32_t len = lf & 0x3FFFFFFFu;
-        const bool load_c = accumulate || !(lf >> 31);
-        T *crow = C + (int64_t)row * ldc;
-        A acc[W], prev[W];
-#pragma unroll
-        for (int j = 0; j < W; j++) acc[j] = prev[j] = A(0);
-        if (li == 0 && load_c) {  // the row's running sum: requested now, needed only after the entries are summed
-#pragma unroll
-            for (int j = 0; j < W; j++) prev[j] = to_acc<T>(crow[j]);
-        }
-        for (uint32_t k = 4 * li; k < len; k += 4 * LG) {
-            const u16x4_u q = (k == 4 * li) ? q0 : __builtin_nontemporal_load(reinterpret_cast<const u16x4_u *>(col16 + s + k));
-            if constexpr (HAS_VALS) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (k + u < len) {
-                        const T *xr = xs + (uint32_t)q[u] * W;
-                        const A v = to_acc<T>(__builtin_nontemporal_load(vals + s + k + u));
-#pragma unroll
-                        for (int j = 0; j < W; j++) acc[j] += v * to_acc<T>(xr[j]);
-                    }
-                }
-            } else {
-                // branch-free: entries past the item's end read the all-zero row staged behind the panel
-                T xv[4][W];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t c = (k + u < len) ? (uint32_t)q[u] : pcols;
-#pragma unroll
-                    for (int j = 0; j < W; j++) xv[u][j] = xs[c * W + j];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-#pragma unroll
-                    for (int j = 0; j < W; j++) acc[j] += to_acc<T>(xv[u][j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int off = LG >> 1; off > 0; off >>= 1) {
-#pragma unroll
-            for (int j = 0; j < W; j++) acc[j] += shfl_xor_t<A>(acc[j], off);
-        }
-        if (li == 0 && !(len == 0 && accumulate)) {
-#pragma unroll
-            for (int j = 0; j < W; j++) crow[j] = from_acc<T>(prev[j] + acc[j]);
-        }
+            done += n;
+        };
+        run_class(std::integral_constant<int, 64>{}, un.n64);
+        run_class(std::integral_constant<int, 32>{}, un.n32);
+        run_class(std::integral_constant<int, 16>{}, un.n16);
+        run_class(std::integral_constant<int, 8>{}, un.n_items - un.n64 - un.n32 - un.n16);
     }
+}
+
+// C[r][j] (+)= sum over the panels of part[p][r][j], in panel order
+template <typename T, int W>
+__global__ void k_spmv_reduce(const typename AccOf<T>::type *__restrict__ part, uint32_t npanels, uint32_t nrows,
+                              T *__restrict__ C, int64_t ldc, int accumulate) {
+    using A = typename AccOf<T>::type;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nrows * W) return;
+    const size_t stride = (size_t)nrows * W;
+    A acc = part[i];
+    for (uint32_t p = 1; p < npanels; p++) acc += part[i + p * stride];
+    T *c = C + (int64_t)(i / W) * ldc + (i % W);
+    *c = accumulate ? from_acc<T>(to_acc<T>(*c) + acc) : from_acc<T>(acc);
+}
+__global__ void k_zero16(u32x4_t *__restrict__ p, uint64_t n16) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = u32x4_t{0, 0, 0, 0};
 }
 
 // ---------------------------------------------------------------------------

@@ -71,6 +71,7 @@ struct Tunables {
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
     int64_t vec_kernel = 1;             // 1 = rows of X of at most 4 elements (SpMV) take the CSR-vector kernel
     int64_t vec_lds = 1;                // 1 = ... and, when a column panel of X fits, the LDS-staged form of it (k_spmv_lds)
+    int64_t vec_lds_min_seg = 14;       // ... from this many entries per (row, panel) on average
     int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
@@ -103,6 +104,11 @@ struct Part {
     std::vector<uint32_t> panel_coop;       // per panel: leading items long enough for the wave-cooperative mode
     uint32_t npanels = 0, panel_cols = 0;
     unsigned short *col16 = nullptr;        // panel-local 16-bit column ids (panels of <= 65536 columns), same order as colind
+    std::vector<uint32_t> panel_long128;    // per panel: leading items with more than 256 / 128 / 64 entries, 3 counts each (the LDS-staged
+                                            // SpMV kernel's length classes)
+    std::vector<uint64_t> panel_nnz;        // per panel: entries of its items
+    SpmvUnit *d_spmv_units = nullptr;       // the LDS-staged SpMV kernel's (panel, slot) table, built at its first launch
+    uint32_t n_spmv_units = 0;
     std::vector<int64_t> dense_cols;
     // integer weights that are 1 almost everywhere (a coalesced multigraph, backend_pim/spmm.py:40-42): this part keeps
     // the PATTERN only (unit weights: no value array, no multiplies, packed 8/16-bit sums) and `extra` holds the few
@@ -292,6 +298,7 @@ void free_part(Part &p) {
     }
     if (p.d_items) (void)hipFree(p.d_items);
     if (p.col16) (void)hipFree(p.col16);
+    if (p.d_spmv_units) (void)hipFree(p.d_spmv_units);
     if (p.extra) free_part(*p.extra);
 }
 
@@ -602,38 +609,95 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     const uint32_t ww = (uint32_t)w;
     // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
     if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
-        // LDS-staged form: the plan's column panels with 16-bit local ids, a panel of X (panel_cols x w elements) inside the
-        // 144 KiB a workgroup may take; rows cut into segments (segment kernels) keep the plain form
-        constexpr size_t LDS_MAX = 144 * 1024;
-        if (g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 && p.npanels >= 1 &&
-            ((size_t)p.panel_cols + 1) * ww * sizeof(T) + 32 <= LDS_MAX &&
-            // every panel costs a pass over the item list and a staged copy of its part of X: worth it from about 32 entries per
-            // (row, panel) (Reddit-shaped, 4-byte elements: w = 1 -> 8 panels, 0.43 vs 0.67 ms; w = 2 -> 13 panels, 0.59 vs 0.69 ms;
-            // w = 4 -> 26 panels, 1.03 vs 0.72 ms)
-            (double)p.nnz >= 32.0 * (double)p.nrows * (double)p.npanels) {
+        // LDS-staged form: the plan's column panels with 16-bit local ids, a panel of X (panel_cols x w elements) plus the
+        // staging of results inside a workgroup's LDS; rows cut into segments (segment kernels) keep the plain form
+        using A = typename AccOf<T>::type;
+        constexpr size_t LDS_TOTAL = 160 * 1024 - 64;
+        const size_t panel_lds = (((((size_t)p.panel_cols + 1) * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + zero row + alignment lead-in
+        const size_t per_entry = 4 + (size_t)ww * sizeof(A);                                                 // a parked (row, sum)
+        const bool lds_rule = g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 &&
+                              p.npanels >= 1 && p.panel_long128.size() == 3 * (size_t)p.npanels && (uint64_t)p.nnz < (1ull << 31) &&
+                              // every panel costs a pass over the item list: worth it from about 32 entries per (row, panel)
+                              (double)p.nnz >= (double)g_tune.vec_lds_min_seg * (double)p.nrows * (double)p.npanels;
+        if (lds_rule && panel_lds + 64 * 12 * per_entry <= LDS_TOTAL) {
+            // ONE launch over all panels (kernels.hpp, k_spmv_lds): a workgroup per (panel, slot) unit, the panels' sums parked
+            // in part[panel][row] and added in panel order by k_spmv_reduce
+            const size_t stage_budget = std::min<size_t>(32 * 1024, LDS_TOTAL - panel_lds);
+            const uint32_t F16 = (uint32_t)(stage_budget / (64 * per_entry)) / 12 * 12;  // (8-lane groups park F16 / 2, a multiple of 6)
+            const size_t shmem = panel_lds + 64 * (size_t)F16 * per_entry;
+            const uint32_t cu = (uint32_t)std::max(g_ctx.cu_count, 1);
+            if (!p.d_spmv_units) {
+                std::vector<uint32_t> act;
+                double wsum = 0;
+                for (uint32_t q = 0; q < p.npanels; q++)
+                    if (p.panel_off[q + 1] > p.panel_off[q]) {
+                        act.push_back(q);
+                        wsum += (double)std::max<uint64_t>(p.panel_nnz[q], p.panel_off[q + 1] - p.panel_off[q]);
+                    }
+                if (!act.empty()) {
+                    // workgroups per panel in proportion to its entries (at least one); more panels than CUs: one each, taken in turn
+                    std::vector<uint32_t> nb(act.size(), 1);
+                    if (act.size() < cu) {
+                        uint32_t left = cu - (uint32_t)act.size();
+                        std::vector<std::pair<double, size_t>> rem;
+                        uint32_t given = 0;
+                        for (size_t k = 0; k < act.size(); k++) {
+                            const uint32_t q = act[k];
+                            const double share = (double)left * (double)std::max<uint64_t>(p.panel_nnz[q], p.panel_off[q + 1] - p.panel_off[q]) / wsum;
+                            const uint32_t fl = (uint32_t)share;
+                            nb[k] += fl;
+                            given += fl;
+                            rem.emplace_back(share - fl, k);
+                        }
+                        std::sort(rem.begin(), rem.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first > y.first; });
+                        for (size_t k = 0; given < left && k < rem.size(); k++, given++) nb[rem[k].second]++;
+                    }
+                    // slot-major order: consecutive workgroups (dispatched round-robin over the XCDs) take different panels, so with
+                    // 8 panels an XCD's L2 serves one panel of X to all its CUs
+                    std::vector<SpmvUnit> units;
+                    const uint32_t most = *std::max_element(nb.begin(), nb.end());
+                    for (uint32_t slot = 0; slot < most; slot++)
+                        for (size_t k = 0; k < act.size(); k++) {
+                            if (slot >= nb[k]) continue;
+                            const uint32_t q = act[k];
+                            SpmvUnit u;
+                            u.item_off = (uint32_t)p.panel_off[q];
+                            u.n_items = (uint32_t)(p.panel_off[q + 1] - p.panel_off[q]);
+                            u.n64 = p.panel_long128[3 * q];
+                            u.n32 = p.panel_long128[3 * q + 1] - u.n64;
+                            u.n16 = p.panel_long128[3 * q + 2] - u.n64 - u.n32;
+                            u.col_base = q * p.panel_cols;
+                            u.pcols = (uint32_t)std::min<int64_t>(p.panel_cols, p.ncols - (int64_t)u.col_base);
+                            u.slot = slot;
+                            u.nslots = nb[k];
+                            u.panel = q;
+                            units.push_back(u);
+                        }
+                    HIP_TRY(hipMalloc((void **)&p.d_spmv_units, units.size() * sizeof(SpmvUnit)));
+                    HIP_TRY(hipMemcpyAsync(p.d_spmv_units, units.data(), units.size() * sizeof(SpmvUnit), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipStreamSynchronize(st));  // (units is a local; one-time)
+                    p.n_spmv_units = (uint32_t)units.size();
+                }
+            }
+            const size_t part_bytes = ((size_t)p.npanels * (size_t)p.nrows * ww * sizeof(A) + 15) & ~(size_t)15;
+            if (int rc = ensure(&g->scratch, &g->scratch_bytes, part_bytes)) return rc;
+            A *part = (A *)g->scratch;
             KernelTimer kt(g, st, !p.is_extra);
-            for (uint32_t q = 0; q < p.npanels; q++) {
-                const size_t o = p.panel_off[q];
-                const uint32_t cnt = (uint32_t)(p.panel_off[q + 1] - o);
-                if (cnt == 0) continue;
-                const uint32_t col_base = q * p.panel_cols;
-                const uint32_t pcols = (uint32_t)std::min<int64_t>(p.panel_cols, p.ncols - (int64_t)col_base);
-                // slabs of the item list per workgroup: enough entries to amortise staging the panel, enough workgroups to fill the chip
-                // one workgroup per CU (each stages the panel once), fewer when the panel has few items
-                const uint32_t ipb = 0;
-                const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::max(g_ctx.cu_count, 1), (cnt + 63) / 64));
-                const size_t shmem = (((((size_t)pcols + 1) * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + zero row + alignment lead-in
-                const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
+            hipLaunchKernelGGL(k_zero16, dim3((unsigned)((part_bytes / 16 + 255) / 256)), dim3(256), 0, st, (u32x4_t *)part,
+                               (uint64_t)(part_bytes / 16));
+            if (p.n_spmv_units > 0) {
+                const uint32_t *ir = p.d_items, *ib = p.d_items + p.n_items, *il = p.d_items + 2 * p.n_items;
+                const uint32_t blocks = std::min(p.n_spmv_units, cu);
 #define PYGIM_SPMV_LDS(W, HV)                                                                                                  \
     {                                                                                                                          \
         static bool attr_set = false;                                                                                          \
         if (!attr_set) {                                                                                                       \
             HIP_TRY(hipFuncSetAttribute((const void *)k_spmv_lds<T, W, HV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                        (int)LDS_MAX));                                                                        \
+                                        (int)(LDS_TOTAL + 64)));                                                               \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_spmv_lds<T, W, HV>), dim3(blocks), dim3(1024), shmem, st, ir, ib, il, cnt, p.col16,              \
-                           (const T *)p.vals, x, ldx, c, ldc, accumulate ? 1 : 0, col_base, pcols, ipb);                       \
+        hipLaunchKernelGGL((k_spmv_lds<T, W, HV>), dim3(blocks), dim3(1024), shmem, st, p.d_spmv_units, p.n_spmv_units, ir, ib, \
+                           il, p.col16, (const T *)p.vals, x, ldx, part, (uint32_t)p.nrows, (uint32_t)panel_lds, F16);         \
     }
                 if (p.vals) {
                     if (ww == 1) PYGIM_SPMV_LDS(1, true) else if (ww == 2) PYGIM_SPMV_LDS(2, true)
@@ -643,6 +707,14 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
                     else if (ww == 3) PYGIM_SPMV_LDS(3, false) else PYGIM_SPMV_LDS(4, false)
                 }
 #undef PYGIM_SPMV_LDS
+            }
+            {
+                const uint64_t total = (uint64_t)p.nrows * ww;
+                const dim3 rgrid((unsigned)((total + 255) / 256));
+                if (ww == 1) hipLaunchKernelGGL((k_spmv_reduce<T, 1>), rgrid, dim3(256), 0, st, part, p.npanels, (uint32_t)p.nrows, c, ldc, accumulate ? 1 : 0);
+                else if (ww == 2) hipLaunchKernelGGL((k_spmv_reduce<T, 2>), rgrid, dim3(256), 0, st, part, p.npanels, (uint32_t)p.nrows, c, ldc, accumulate ? 1 : 0);
+                else if (ww == 3) hipLaunchKernelGGL((k_spmv_reduce<T, 3>), rgrid, dim3(256), 0, st, part, p.npanels, (uint32_t)p.nrows, c, ldc, accumulate ? 1 : 0);
+                else hipLaunchKernelGGL((k_spmv_reduce<T, 4>), rgrid, dim3(256), 0, st, part, p.npanels, (uint32_t)p.nrows, c, ldc, accumulate ? 1 : 0);
             }
             kt.stop();
             HIP_TRY(hipGetLastError());
@@ -763,9 +835,9 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
     if (g_tune.panel_mode != 2 && p.nrows > 0 && p.nnz > 0) {
         int64_t budget_rows = std::max<int64_t>(1, g_tune.panel_bytes / 128);
         // groups whose rows of X hold at most 4 elements never take the wide sweep: their panels are sized for the LDS-staged
-        // SpMV kernel instead (a panel of X, h elements per column, inside the 144 KiB a workgroup may take)
+        // SpMV kernel instead (a panel of X, h elements per column, inside 128 KiB of a workgroup's LDS; the rest parks results)
         if (h_hint >= 1 && h_hint <= 4 && g_tune.vec_lds && g_tune.vec_kernel)
-            budget_rows = std::max<int64_t>(1, std::min<int64_t>(budget_rows, (int64_t)((144 * 1024 - 64) / ((size_t)h_hint * es))));
+            budget_rows = std::max<int64_t>(1, std::min<int64_t>(budget_rows, (int64_t)((128 * 1024 - 64) / ((size_t)h_hint * es))));
         uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
         bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                      (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
@@ -820,6 +892,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
             std::vector<uint32_t> rows_v, beg_v, len_v, order;
             p.panel_off.assign(1, 0);
             p.panel_coop.clear();
+            p.panel_long128.clear();
+            p.panel_nnz.clear();
             const uint32_t coop_cap = (uint32_t)std::max<int64_t>(64, g_tune.panel_coop);
             for (uint32_t q = 0; q < npan; q++) {
                 const uint32_t *lo = pp.data() + (size_t)q * nr, *hi = lo + nr;
@@ -843,6 +917,19 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
                 uint32_t nco = 0;
                 for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
                 p.panel_coop.push_back(nco);
+                uint32_t n256 = 0, n128 = 0, n64 = 0;
+                uint64_t pn = 0;
+                for (uint32_t r : order) {
+                    const uint32_t l = hi[r] - lo[r];
+                    n256 += l > 256u ? 1u : 0u;  // sorted: prefixes
+                    n128 += l > 128u ? 1u : 0u;
+                    n64 += l > 64u ? 1u : 0u;
+                    pn += l;
+                }
+                p.panel_long128.push_back(n256);
+                p.panel_long128.push_back(n128);
+                p.panel_long128.push_back(n64);
+                p.panel_nnz.push_back(pn);
                 for (uint32_t r : order) {
                     rows_v.push_back(r);
                     beg_v.push_back(lo[r]);
@@ -1495,6 +1582,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
     else if (n == "vec_kernel") slot = &g_tune.vec_kernel;
     else if (n == "vec_lds") slot = &g_tune.vec_lds;
+    else if (n == "vec_lds_min_seg") slot = &g_tune.vec_lds_min_seg;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

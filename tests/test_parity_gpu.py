@@ -681,3 +681,31 @@ def test_lds_staged_spmv_kernel(rng, dt):
         _lib.set_tunable("vec_lds", 1)
         for k, v in old.items():
             _lib.set_tunable(k, v)
+
+
+@pytest.mark.parametrize("dt", ["INT32", "FLT32", "INT8"])
+def test_lds_staged_spmv_more_panels_than_workgroups(rng, dt):
+    """k_spmv_lds when the (panel, slot) units outnumber the CUs: a workgroup then takes several units in turn, re-staging
+    its LDS panel between them (panels of 8 columns -> 400 panels; the entries-per-panel rule is switched off), with all four
+    length classes present (items of 0..600 entries inside one panel are impossible at 8 columns, so a second, wide-panel run
+    covers the long classes)"""
+    npdt = NP_DTYPES[dt]
+    n = 3200
+    rowptr, col = random_csr(rng, n, n, 40, long_rows=[(5, 2500), (n - 1, 700)], empty_frac=0.05)
+    for panel_bytes, want_panels in ((128 * 8, 300), (128 * 1600, 2)):
+        old = {k: _lib.set_tunable(k, v) for k, v in (("panel_bytes", panel_bytes), ("vec_lds_min_seg", 0), ("merge_parts", 0),
+                                                       ("panel_mode", 1))}
+        try:
+            for w, weighted in ((1, False), (2, True), (4, False)):
+                x = driver_features(rng, n, w, npdt)
+                vals = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else None
+                ref = oracle.spmm_csr(rowptr, col, vals, x)
+                out, info = run_group_host("CSR", [rowptr], [col], None if vals is None else [vals], [n], [n], [x], w)
+                assert info["n_panels"] >= want_panels, info
+                if np.issubdtype(npdt, np.integer) or not weighted:
+                    assert np.array_equal(out, ref), (dt, w, weighted, panel_bytes)
+                else:
+                    assert np.all(np.abs(out.astype(np.float64) - ref) <= 1e-5 * abs_scale(rowptr, col, vals, x) + 1e-30)
+        finally:
+            for k, v in old.items():
+                _lib.set_tunable(k, v)
