@@ -20,6 +20,7 @@ class SparseTensorCOO(SparseGroupBase):
     def __init__(self, coo, dtype=torch.int32, groups=32):
         super().__init__(coo.int(), dtype=dtype, format="")
         self.groups = groups
+        self._wide = None  # (width, handle): a second group planned for the whole [N, h] product, see _mul_device
 
     def build_coo(self):
         quantum = 64 // torch.iinfo(self.dtype).bits
@@ -68,7 +69,18 @@ class SparseTensorCOO(SparseGroupBase):
 
         Bp = self._pad_rows(B).contiguous()
         out = torch.empty((self.coo[0].size(0), Bp.size(1)), dtype=self.dtype, device=B.device)
-        _lib.block_run(self.sp_info_ptr, 0, Bp.data_ptr(), Bp.size(1), out.data_ptr(), Bp.size(1), Bp.size(1), False,
+        handle = self.sp_info_ptr
+        if 2 <= self.dense_parts <= 4 and Bp.size(1) > 4:
+            # groups of 2..4 vectors are planned for the LDS-staged SpMV kernel (narrow column panels); the whole-matrix
+            # product wants the sweep's panels: a second group over the same arrays, made once (10.1 -> 6.9 ms, Reddit-shaped)
+            if self._wide is None or self._wide[0] != Bp.size(1):
+                if self._wide is not None:
+                    torch.ops.pim_ops.spmm_free_group(self._wide[1])
+                nrows, ncols = [c.size(0) for c in self.coo], [c.size(1) for c in self.coo]
+                self._wide = (Bp.size(1), torch.ops.pim_ops.spmv_coo_to_device_group(
+                    self.row_indices, self.col_indices, self.values, nrows, ncols, [1] * Bp.size(1), Bp.size(1), 1))
+            handle = self._wide[1]
+        _lib.block_run(handle, 0, Bp.data_ptr(), Bp.size(1), out.data_ptr(), Bp.size(1), Bp.size(1), False,
                        torch.cuda.current_stream(B.device).cuda_stream)
         return out[:self.raw.size(0), ...]
 

@@ -75,12 +75,13 @@ def test_spmv_wrapper_gpu(rng):
     torch.ops.pim_ops.dpu_init_ranks(8)
     try:
         for tdt in (torch.int8, torch.int16, torch.int32, torch.int64):
-            for groups in (1, 8):
+            for groups in (1, 2, 4, 8):  # (2..4: the device path plans a second group for the whole-matrix product)
                 A = spmv_mod.prepare_pim_spmv(adj, ns(data_type=tdt, sp_format="COO", sp_parts=1, ds_parts=groups))
                 x = torch.randint(-8, 4, (597, 16)).to(tdt)
                 ref = oracle.spmm_csr(rowptr, col, None, x.numpy())
                 assert np.array_equal(spmv_mod.pim_spmv(x, A).numpy(), ref), (tdt, groups)
                 assert np.array_equal(A.mul(x.cuda()).cpu().numpy(), ref)
+                assert np.array_equal(A.mul(x.cuda()).cpu().numpy(), ref)  # (second call: the cached wide group)
     finally:
         torch.ops.pim_ops.dpu_release()
 
