@@ -57,8 +57,11 @@ class SparseTensorCOO(SparseGroupBase):
         return res[:self.raw.size(0), ...]
 
     def mul(self, B: torch.Tensor):
-        if B.is_cuda and B.dtype == self.dtype and len(self.coo) == 1:
-            return self._mul_device(B)
+        if B.dtype == self.dtype and len(self.coo) == 1 and B.dim() == 2 and B.size(1) % self.groups == 0:
+            if B.is_cuda:
+                return self._mul_device(B)
+            # CPU tensors: one upload, one product, one download instead of h / groups staged backend calls (same sums)
+            return self._mul_device(B.cuda()).cpu()
         panels = dense_split(B, B.size(1) // self.groups)
         return torch.cat([self.mul_single(panel) for panel in panels], dim=1)
 

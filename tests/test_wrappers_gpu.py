@@ -80,6 +80,9 @@ def test_spmv_wrapper_gpu(rng):
                 x = torch.randint(-8, 4, (597, 16)).to(tdt)
                 ref = oracle.spmm_csr(rowptr, col, None, x.numpy())
                 assert np.array_equal(spmv_mod.pim_spmv(x, A).numpy(), ref), (tdt, groups)
+                # the reference's own loop: h / groups backend calls of `groups` SpMVs each (spmv.py:95-102)
+                looped = torch.cat([A.mul_single(panel) for panel in spmv_mod.dense_split(x, 16 // groups)], dim=1)
+                assert np.array_equal(looped.numpy(), ref), (tdt, groups, "mul_single loop")
                 assert np.array_equal(A.mul(x.cuda()).cpu().numpy(), ref)
                 assert np.array_equal(A.mul(x.cuda()).cpu().numpy(), ref)  # (second call: the cached wide group)
     finally:
