@@ -356,3 +356,30 @@ def test_random_quantised_aggregations(seed):
     finally:
         for k, v in old.items():
             _lib.set_tunable(k, v)
+
+
+@pytest.mark.parametrize("seed", range(max(24, _EXTRA)))
+def test_random_lds_spmv(seed):
+    """k_spmv_lds on random shapes: rows of X of 1..4 elements, every element type, unit and real weights, panels from a handful
+    of columns (more units than CUs) to the whole matrix, all four length classes, empty rows, accumulate through a second call"""
+    rng = np.random.default_rng(12000 + seed)
+    dt = ALL_DTYPES[seed % 6]
+    npdt = NP_DTYPES[dt]
+    nrows = int(rng.integers(1, 1500))
+    ncols = int(rng.integers(1, 4000))
+    w = int(rng.integers(1, 5))
+    rowptr, col = skewed_csr(rng, nrows, ncols, float(rng.choice([2, 30, 150, 500])), float(rng.choice([0.3, 1.0, 1.6])),
+                             bool(rng.random() < 0.3))
+    weighted = bool(rng.random() < 0.4)
+    knobs = {"panel_mode": 1, "vec_lds_min_seg": 0, "panel_bytes": int(rng.choice([128 * 4, 128 * 64, 128 * 700, 4 << 20])),
+             "merge_parts": 0, "split_unit_pattern": int(rng.choice([0, 1]))}
+    old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
+    try:
+        x = driver_features(rng, ncols, w, npdt)
+        vals = rng.integers(-3, 4, size=len(col)).astype(npdt) if weighted else None
+        ref = oracle.spmm_csr(rowptr, col, vals, x)
+        out, info = run_group_host("CSR", [rowptr], [col], None if vals is None else [vals], [nrows], [ncols], [x], w)
+        assert np.array_equal(out, ref), (seed, dt, nrows, ncols, w, weighted, knobs, info)
+    finally:
+        for k, v in old.items():
+            _lib.set_tunable(k, v)
