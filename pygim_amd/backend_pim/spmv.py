@@ -60,8 +60,9 @@ class SparseTensorCOO(SparseGroupBase):
         if B.dtype == self.dtype and len(self.coo) == 1 and B.dim() == 2 and B.size(1) % self.groups == 0:
             if B.is_cuda:
                 return self._mul_device(B)
-            # CPU tensors: one upload, one product, one download instead of h / groups staged backend calls (same sums)
-            return self._mul_device(B.cuda()).cpu()
+            if torch.cuda.is_available():
+                # CPU tensors: one upload, one product, one download instead of h / groups staged backend calls (same sums)
+                return self._mul_device(B.cuda()).cpu()
         panels = dense_split(B, B.size(1) // self.groups)
         return torch.cat([self.mul_single(panel) for panel in panels], dim=1)
 
