@@ -86,3 +86,29 @@ def autotune(nrows, ncols, nnz, hidden_size, elem_bytes=4, n_gpus=8):
     (utils/autotuner.py:333-343).  sp_parts here are ROW parts, balanced by nnz."""
     best, _ = choose(nrows, ncols, nnz, hidden_size, elem_bytes, n_gpus)
     return [best.row_parts, best.feat_parts, "nnz", "nnz", None]
+
+
+def autotune_dataset(datadir, dataset, hidden_size, split_set, blnc_set=(0, 2), elem_bytes=4):
+    """The reference's call shape (utils/autotuner.py:263: ``autotune(datadir, dataset, hidden_size, split_set, blnc_set)``):
+    price every ``(sp_parts, ds_parts)`` of ``split_set`` for the named dataset -- read from ``datadir`` when its raw files are
+    there, else the dataset's node / edge counts -- as a (row parts x feature parts) grid and return the cheapest as
+    ``[sp_parts, ds_parts, balance, balance_tasklet, None]`` (autotuner.py:333-343).  ``blnc_set`` selected UPMEM balance
+    schemes; every split here is nnz-balanced, so it only has to be non-empty."""
+    from . import datasets, synth
+
+    assert len(split_set) > 0 and len(blnc_set) > 0
+    got = datasets.load_adjacency(datadir, dataset)
+    if got is not None:
+        nrows, nnz = int(got[2]), int(len(got[1]))
+    else:
+        nrows, nnz, _ = synth.DATASETS[dataset]
+    best = None
+    for sp, ds in split_set:
+        if sp < 1 or ds < 1 or ds > hidden_size:
+            continue
+        c = price(nrows, nrows, nnz, hidden_size, elem_bytes, sp, ds)
+        if best is None or c.seconds < best.seconds:
+            best = c
+    if best is None:
+        return [None, None, None, None, None]
+    return [best.row_parts, best.feat_parts, "nnz", "nnz", None]

@@ -223,20 +223,17 @@ class Experiment:
         return rc
 
     def _apply_tuned_partition(self, data_root):
-        """experiment.py:402-405 asks the autotuner for (sp_part, ds_part, balance, balance_tsklt, groups_per_rank);
-        here the chooser of pygim_amd/autotune.py prices the splits of this graph over the visible GPUs."""
-        from . import autotune, datasets, synth
+        """experiment.py:402-405 asks the autotuner for (sp_part, ds_part, balance, balance_tsklt, groups_per_rank) among
+        sp_ds_set = [(1, 32), (2, 16)]; here the candidates are the (row parts x feature parts) grids over the GPUs of this
+        job (WORLD_SIZE, one when not under torch.distributed.run), priced by pygim_amd/autotune.py."""
+        from . import autotune
 
         name = "ogbn-proteins" if self.dataset == "ogbnproteins" else self.dataset
-        got = datasets.load_adjacency(data_root, name)
-        if got is not None:
-            nrows, nnz = int(got[2]), int(len(got[1]))
-        else:
-            nrows, nnz, _ = synth.DATASETS[name]
         es = {"INT64": 8, "INT32": 4, "INT16": 2, "INT8": 1, "FLT32": 4, "DBL64": 8}[self.dtype]
-        n_gpus = int(os.environ.get("WORLD_SIZE", "1"))
+        n_gpus = max(int(os.environ.get("WORLD_SIZE", "1")), 1)
+        grids = [(r, n_gpus // r) for r in range(1, n_gpus + 1) if n_gpus % r == 0]
         self.sp_part, self.ds_part, self.balance, self.balance_tsklt, self.groups_per_rank = \
-            autotune.autotune(nrows, nrows, nnz, self.dense_size, es, n_gpus)
+            autotune.autotune_dataset(data_root, name, self.dense_size, grids, elem_bytes=es)
 
     # -- results -------------------------------------------------------------------------------------------
     def parse_result(self, result_root: str):

@@ -148,3 +148,20 @@ def test_out_files_to_csv(tmp_path):
     assert rows[1] == "0, 2.0, 10.0, 8.0" and rows[2] == "1, 4.0, 20.0, 16.0" and rows[3] == "avg, 3.0, 15.0, 12.0"
     table = (out / "csv_result" / "average_all.csv").read_text().splitlines()
     assert table[0].startswith("run, load_sparse_time") and table[1].startswith("a, 3.0, 15.0, 12.0") and table[2].startswith("b, ")
+
+
+def test_tuned_partition_and_reference_shaped_autotune(monkeypatch):
+    """utils/autotuner.py:263's call shape over the chooser, and Experiment(tune=...) taking its answer (experiment.py:402-405)"""
+    from pygim_amd import autotune
+
+    got = autotune.autotune_dataset("./data", "Reddit", 256, [(1, 8), (2, 4), (4, 2), (8, 1)])
+    assert got[2:] == ["nnz", "nnz", None] and got[0] * got[1] == 8
+    table = {(c.row_parts, c.feat_parts): c.seconds for c in autotune.choose(232965, 232965, 114615892, 256, 4, 8)[1]}
+    assert table[(got[0], got[1])] == min(table.values())
+    assert autotune.autotune_dataset("./data", "PubMed", 64, [(1, 128)]) == [None, None, None, None, None]  # more parts than columns
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    e = _exp(dataset="Reddit", dense_size=256, tune=True, backend="spmm_default")
+    e._apply_tuned_partition("./data")
+    assert (e.sp_part, e.ds_part) == (got[0], got[1]) and e.balance == "nnz"
+    off = _exp(tune="FALSE")
+    assert off.command(ROOT, "./data", "/b")[7:9] == ["--sp_part=2", "--ds_part=4"]   # 'FALSE' leaves the split alone
