@@ -15,8 +15,9 @@ N > 1 : strong scaling of the SAME graph with the full C on every rank at the en
         all-gather of step k behind the product of step k + 1 ("pipelined"); feature split
         (ds_parts: A replicated, h / N features per rank); and "push" forms of both, where a
         rank's block goes into every peer's result matrix by peer copies (HIP IPC, copy engines)
-        with a 4-byte RCCL all-reduce as the arrival barrier (PYGIM_BENCH_NO_PUSH=1 keeps to
-        RCCL all-gathers).  All exchanges complete inside the timed region.
+        with a 4-byte RCCL all-reduce as the arrival barrier (--partition push / push-feature, or
+        PYGIM_BENCH_PUSH=1 to let auto time them too; the default auto keeps to RCCL all-gathers).
+        All exchanges complete inside the timed region.
 
 Launch: python bench.py --gpus 1 --steps 20 --warmup 5
         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -644,10 +645,15 @@ def main():
             row_first = prior.feat_parts == 1 or not feat_ok or world == 1
             fam_row = [(PipelinedRows, 1), (PushRows, 1)] if args.chunks == 0 else [(Pieces, kk[0])]
             fam_feat = [(PushFeatures, 1), (PipelinedFeatures, 1)] if feat_ok and world > 1 else []
-            if os.environ.get("PYGIM_BENCH_NO_PUSH", "0") == "1":  # RCCL collectives only (no HIP IPC peer copies)
-                fam_row = [c for c in fam_row if c[0] is not PushRows] + ([(Pieces, 2)] if args.chunks == 0 else [])
-                fam_feat = [c for c in fam_feat if c[0] is not PushFeatures]
-            cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[1:2])
+            if os.environ.get("PYGIM_BENCH_PUSH", "0") != "1":
+                # default: RCCL collectives only.  The push exchange (HIP IPC peer copies) has run between processes on ONE GPU
+                # only -- no multi-GPU box in the build -- so it is offered by --partition push / push-feature or PYGIM_BENCH_PUSH=1,
+                # not timed blind inside the driver's scaling run
+                fam_row = [(PipelinedRows, 1), (Pieces, 2)] if args.chunks == 0 else fam_row
+                fam_feat = [(PipelinedFeatures, 1), (FeaturePieces, 2)] if fam_feat else []
+                cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[:1])
+            else:
+                cands = (fam_row + fam_feat[:1]) if row_first else (fam_feat + fam_row[1:2])
     assert cands, "no admissible partition"
     timed = {}
     if len(cands) == 1:
