@@ -210,3 +210,32 @@ def test_papers100m_per_gpu_slices_f32():
         finally:
             _lib.group_free(hd)
         del x
+
+
+@pytest.mark.parametrize("w,tdt,code,weighted", [(1, torch.int32, "INT32", False), (2, torch.float32, "FLT32", False),
+                                                 (4, torch.int32, "INT32", True)])
+def test_reddit_spmv_end_full_size(w, tdt, code, weighted):
+    """the SpMV end of the path (spmv_sparseP: rows of X of 1..4 elements) on the Reddit-shaped graph at full size: the LDS-staged
+    kernel's plan (several panels, all four length classes), column-count checksum, determinism, sampled rows against the oracle"""
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["reddit"]
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    x = synth.features(n, w, tdt, seed=3, device=dev)
+    vals = torch.randint(-3, 4, (nnz,), device=dev, dtype=tdt) if weighted else None
+    hd = _lib.group_create(_lib.CSR, getattr(_lib, code), [rowptr.data_ptr()], [col.data_ptr()], None if vals is None else [vals.data_ptr()],
+                           [n], [n], [nnz], [1], [w], w)
+    try:
+        plan = _lib.group_plan(hd)
+        assert plan["n_panels"] >= 8 and plan["col16"] == 1, plan   # panels sized for a workgroup's LDS
+        c1 = run(hd, x, n, w)
+        if vals is None:
+            colw = torch.bincount(col.long(), minlength=n).double()
+        else:
+            colw = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, col.long(), vals.double())
+        assert torch.equal(c1.double().sum(0), colw @ x.double())
+        assert torch.equal(run(hd, x, n, w), c1)
+        sample_rows_vs_oracle(rowptr, col, vals, x, c1, [(0, 64), (n // 2, n // 2 + 64), (n - 64, n)])
+        longest = int((rowptr[1:] - rowptr[:-1]).argmax())
+        sample_rows_vs_oracle(rowptr, col, vals, x, c1, [(longest, longest + 1)])
+    finally:
+        _lib.group_free(hd)
