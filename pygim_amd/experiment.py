@@ -232,8 +232,9 @@ class Experiment:
         es = {"INT64": 8, "INT32": 4, "INT16": 2, "INT8": 1, "FLT32": 4, "DBL64": 8}[self.dtype]
         n_gpus = max(int(os.environ.get("WORLD_SIZE", "1")), 1)
         grids = [(r, n_gpus // r) for r in range(1, n_gpus + 1) if n_gpus % r == 0]
-        self.sp_part, self.ds_part, self.balance, self.balance_tsklt, self.groups_per_rank = \
-            autotune.autotune_dataset(data_root, name, self.dense_size, grids, elem_bytes=es)
+        tuned = autotune.autotune_dataset(data_root, name, self.dense_size, grids, elem_bytes=es)
+        if tuned[0] is not None:  # (no admissible grid, e.g. more feature parts than columns: keep the split as given)
+            self.sp_part, self.ds_part, self.balance, self.balance_tsklt, self.groups_per_rank = tuned
 
     # -- results -------------------------------------------------------------------------------------------
     def parse_result(self, result_root: str):
