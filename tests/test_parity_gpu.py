@@ -709,3 +709,25 @@ def test_lds_staged_spmv_more_panels_than_workgroups(rng, dt):
         finally:
             for k, v in old.items():
                 _lib.set_tunable(k, v)
+
+
+@pytest.mark.parametrize("dt", ["INT32", "FLT32", "INT8"])
+def test_degenerate_shapes(dt):
+    """no stored entries at all (CSR and COO), a 1 x 1 matrix, one row / one column, widths 1 and 5: the result is what the
+    oracle's loops give (zeros where nothing is stored), for the sweep as for the SpMV end"""
+    npdt = NP_DTYPES[dt]
+    for nrows, ncols, entries in ((7, 5, []), (1, 1, [(0, 0)]), (1, 9, [(0, 3), (0, 3), (0, 8)]), (6, 1, [(2, 0), (5, 0)])):
+        rows = np.array([e[0] for e in entries], dtype=np.int32)
+        cols = np.array([e[1] for e in entries], dtype=np.int32)
+        rowptr = np.zeros(nrows + 1, dtype=np.int32)
+        np.add.at(rowptr, rows + 1, 1)
+        rowptr = np.cumsum(rowptr).astype(np.int32)
+        for h in (1, 5):
+            x = (np.arange(ncols * h).reshape(ncols, h) % 7 - 3).astype(npdt)
+            ref = oracle.spmm_csr(rowptr, cols, None, x)
+            out, _ = run_group_host("CSR", [rowptr], [cols], None, [nrows], [ncols], [x], h)
+            assert out.shape == (nrows, h) and np.array_equal(out, ref), (dt, nrows, ncols, h, "csr")
+            if len(entries) == len(set(entries)):   # COO input is coalesced
+                vals = np.ones(len(entries), dtype=npdt)
+                out, _ = run_group_host("COO", [rows], [cols], [vals], [nrows], [ncols], [x], h)
+                assert np.array_equal(out, oracle.spmm_coo(rows, cols, vals, x, nrows)), (dt, nrows, ncols, h, "coo")
