@@ -617,7 +617,8 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
         const size_t per_entry = 4 + (size_t)ww * sizeof(A);                                                 // a parked (row, sum)
         const bool lds_rule = g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 &&
                               p.npanels >= 1 && p.panel_long128.size() == 3 * (size_t)p.npanels && (uint64_t)p.nnz < (1ull << 31) &&
-                              // every panel costs a pass over the item list: worth it from about 32 entries per (row, panel)
+                              // every (row, panel) item costs one pipeline step whatever its length: against k_csr_vec it pays from about
+                              // 14 entries per item (Reddit-shaped: w = 4, 17 entries per item, 0.46 against 0.73 ms)
                               (double)p.nnz >= (double)g_tune.vec_lds_min_seg * (double)p.nrows * (double)p.npanels;
         if (lds_rule && panel_lds + 64 * 12 * per_entry <= LDS_TOTAL) {
             // ONE launch over all panels (kernels.hpp, k_spmv_lds): a workgroup per (panel, slot) unit, the panels' sums parked
