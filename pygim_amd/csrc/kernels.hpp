@@ -983,8 +983,8 @@ __global__ void k_build_panel_ptr(const uint32_t *__restrict__ perm, const uint3
 //   * a workgroup (one per CU) is given one unit = (panel, slot of nslots): it stages the panel of X once and walks the items
 //     slot, slot + nslots, ... of the panel's length-sorted list -- the workgroups of a panel share it like cards dealt in
 //     turn, so each sees the whole length spectrum;
-//   * the sorted list falls into four length classes (at most 64 / 128 / 256 entries, and longer) worked by lane groups of
-//     8 / 16 / 32 / 64 lanes, 8 entries per lane, so that an item is ONE pass: the loop over a lane group's items is then
+//   * the sorted list falls into five length classes (at most 32 / 64 / 128 / 256 entries, and longer) worked by lane groups of
+//     4 / 8 / 16 / 32 / 64 lanes, 8 entries per lane, so that an item is ONE pass: the loop over a lane group's items is then
 //     perfectly regular and runs as a register pipeline -- descriptors 6 items ahead, the 16 bytes of ids (and the weights)
 //     3 items ahead, every load unconditional (indices clamped, never predicated), so the waits are vmcnt(N) for the oldest
 //     load only.  Only the whole-wave class has items of several passes (beyond 512 entries: rare), fetched on demand;
@@ -998,8 +998,9 @@ extern __shared__ unsigned char pygim_lds_raw[];
 struct SpmvUnit {
     uint32_t item_off;  // the panel's first item in the part's item arrays
     uint32_t n_items;   // its items, longest first
-    uint32_t n64, n32, n16;  // the list's leading items by length class: > 256 entries (a wave each, 512 per pass), 129..256 (32 lanes),
-                             // 65..128 (16 lanes); the rest, at most 64 entries, take 8 lanes -- 8 entries per lane in every class
+    uint32_t n64, n32, n16, n8;  // the list's leading items by length class: > 256 entries (a wave each, 512 per pass), 129..256
+                                 // (32 lanes), 65..128 (16 lanes), 33..64 (8 lanes); the rest, at most 32 entries, take 4 lanes --
+                                 // 8 entries per lane in every class
     uint32_t col_base, pcols;
     uint32_t slot, nslots;
     uint32_t panel;
@@ -1022,10 +1023,10 @@ template <int CTRL, typename A> __device__ __forceinline__ A dpp_get(A v) {
 }
 // sum over the LG lanes of a lane group, in a fixed order, every lane ends with the total
 template <int LG, typename A> __device__ __forceinline__ A lanes_sum(A v) {
-    static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "half a DPP row, a row, two rows or the whole wave");
+    static_assert(LG == 4 || LG == 8 || LG == 16 || LG == 32 || LG == 64, "a quad, half a DPP row, a row, two rows or the whole wave");
     v += dpp_get<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_get<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_get<0x141>(v);  // row_half_mirror
+    if constexpr (LG >= 8) v += dpp_get<0x141>(v);  // row_half_mirror
     if constexpr (LG >= 16) v += dpp_get<0x140>(v);  // row_mirror
     if constexpr (LG >= 32) v += shfl_xor_t<A>(v, 16);
     if constexpr (LG == 64) v += shfl_xor_t<A>(v, 32);
@@ -1162,7 +1163,7 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const SpmvUnit *__restrict__ 
                                                    const unsigned short *__restrict__ col16, const T *__restrict__ vals,
                                                    const T *__restrict__ X, int64_t ldx,
                                                    typename AccOf<T>::type *__restrict__ part, uint32_t nrows,
-                                                   uint32_t stage_off, uint32_t F16) {
+                                                   uint32_t stage_off, uint32_t F16, int merge4) {
     static_assert(W >= 1 && W <= 4, "rows of at most 4 elements");
     using A = typename AccOf<T>::type;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const SpmvUnit *__restrict__ 
         const char *ib = reinterpret_cast<const char *>(item_begin + un.item_off);
         const char *il = reinterpret_cast<const char *>(item_len + un.item_off);
         const char *c16 = reinterpret_cast<const char *>(col16);
-        // the four length classes in turn: a lane group of LG lanes per item, 64 / LG groups per wave, each with its share of the
+        // the five length classes in turn: a lane group of LG lanes per item, 64 / LG groups per wave, each with its share of the
         // wave's staging region
         uint32_t done = 0;
         auto run_class = [&](auto lg_tag, uint32_t n) {
@@ -1219,7 +1220,11 @@ __global__ __launch_bounds__(1024) void k_spmv_lds(const SpmvUnit *__restrict__ 
         run_class(std::integral_constant<int, 64>{}, un.n64);
         run_class(std::integral_constant<int, 32>{}, un.n32);
         run_class(std::integral_constant<int, 16>{}, un.n16);
-        run_class(std::integral_constant<int, 8>{}, un.n_items - un.n64 - un.n32 - un.n16);
+        // (merge4: the staging region is too small to give 4-lane groups their own slots -- wide sums -- so the shortest class
+        //  rides with the 8-lane one)
+        const uint32_t rest = un.n_items - un.n64 - un.n32 - un.n16;
+        run_class(std::integral_constant<int, 8>{}, merge4 ? rest : un.n8);
+        run_class(std::integral_constant<int, 4>{}, merge4 ? 0u : rest - un.n8);
     }
 }
 

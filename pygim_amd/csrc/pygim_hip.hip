@@ -104,8 +104,8 @@ struct Part {
     std::vector<uint32_t> panel_coop;       // per panel: leading items long enough for the wave-cooperative mode
     uint32_t npanels = 0, panel_cols = 0;
     unsigned short *col16 = nullptr;        // panel-local 16-bit column ids (panels of <= 65536 columns), same order as colind
-    std::vector<uint32_t> panel_long128;    // per panel: leading items with more than 256 / 128 / 64 entries, 3 counts each (the LDS-staged
-                                            // SpMV kernel's length classes)
+    std::vector<uint32_t> panel_long128;    // per panel: leading items with more than 256 / 128 / 64 / 32 entries, 4 counts each (the
+                                            // LDS-staged SpMV kernel's length classes)
     std::vector<uint64_t> panel_nnz;        // per panel: entries of its items
     SpmvUnit *d_spmv_units = nullptr;       // the LDS-staged SpMV kernel's (panel, slot) table, built at its first launch
     uint32_t n_spmv_units = 0;
@@ -616,7 +616,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
         const size_t panel_lds = (((((size_t)p.panel_cols + 1) * ww * sizeof(T)) + 15) & ~(size_t)15) + 16;  // + zero row + alignment lead-in
         const size_t per_entry = 4 + (size_t)ww * sizeof(A);                                                 // a parked (row, sum)
         const bool lds_rule = g_tune.vec_lds && g_tune.panel_mode != 2 && p.d_items && p.col16 && p.lp_panel.n_tasks == 0 &&
-                              p.npanels >= 1 && p.panel_long128.size() == 3 * (size_t)p.npanels && (uint64_t)p.nnz < (1ull << 31) &&
+                              p.npanels >= 1 && p.panel_long128.size() == 4 * (size_t)p.npanels && (uint64_t)p.nnz < (1ull << 31) &&
                               // every (row, panel) item costs one pipeline step whatever its length: against k_csr_vec it pays from about
                               // 14 entries per item (Reddit-shaped: w = 4, 17 entries per item, 0.46 against 0.73 ms)
                               (double)p.nnz >= (double)g_tune.vec_lds_min_seg * (double)p.nrows * (double)p.npanels;
@@ -624,7 +624,11 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
             // ONE launch over all panels (kernels.hpp, k_spmv_lds): a workgroup per (panel, slot) unit, the panels' sums parked
             // in part[panel][row] and added in panel order by k_spmv_reduce
             const size_t stage_budget = std::min<size_t>(32 * 1024, LDS_TOTAL - panel_lds);
-            const uint32_t F16 = (uint32_t)(stage_budget / (64 * per_entry)) / 12 * 12;  // (8-lane groups park F16 / 2, a multiple of 6)
+            // parked pairs per 16-lane group: a multiple of 24 so that 4-lane groups get F16 / 4 (a multiple of the pipeline's 6), or
+            // -- wide sums, little room -- a multiple of 12 and no 4-lane class
+            uint32_t F16 = (uint32_t)(stage_budget / (64 * per_entry)) / 24 * 24;
+            const int merge4 = F16 == 0 ? 1 : 0;
+            if (merge4) F16 = (uint32_t)(stage_budget / (64 * per_entry)) / 12 * 12;
             const size_t shmem = panel_lds + 64 * (size_t)F16 * per_entry;
             const uint32_t cu = (uint32_t)std::max(g_ctx.cu_count, 1);
             if (!p.d_spmv_units) {
@@ -664,9 +668,10 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
                             SpmvUnit u;
                             u.item_off = (uint32_t)p.panel_off[q];
                             u.n_items = (uint32_t)(p.panel_off[q + 1] - p.panel_off[q]);
-                            u.n64 = p.panel_long128[3 * q];
-                            u.n32 = p.panel_long128[3 * q + 1] - u.n64;
-                            u.n16 = p.panel_long128[3 * q + 2] - u.n64 - u.n32;
+                            u.n64 = p.panel_long128[4 * q];
+                            u.n32 = p.panel_long128[4 * q + 1] - u.n64;
+                            u.n16 = p.panel_long128[4 * q + 2] - u.n64 - u.n32;
+                            u.n8 = p.panel_long128[4 * q + 3] - u.n64 - u.n32 - u.n16;
                             u.col_base = q * p.panel_cols;
                             u.pcols = (uint32_t)std::min<int64_t>(p.panel_cols, p.ncols - (int64_t)u.col_base);
                             u.slot = slot;
@@ -698,7 +703,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spmv_lds<T, W, HV>), dim3(blocks), dim3(1024), shmem, st, p.d_spmv_units, p.n_spmv_units, ir, ib, \
-                           il, p.col16, (const T *)p.vals, x, ldx, part, (uint32_t)p.nrows, (uint32_t)panel_lds, F16);         \
+                           il, p.col16, (const T *)p.vals, x, ldx, part, (uint32_t)p.nrows, (uint32_t)panel_lds, F16, merge4); \
     }
                 if (p.vals) {
                     if (ww == 1) PYGIM_SPMV_LDS(1, true) else if (ww == 2) PYGIM_SPMV_LDS(2, true)
@@ -918,18 +923,20 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
                 uint32_t nco = 0;
                 for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
                 p.panel_coop.push_back(nco);
-                uint32_t n256 = 0, n128 = 0, n64 = 0;
+                uint32_t n256 = 0, n128 = 0, n64 = 0, n32 = 0;
                 uint64_t pn = 0;
                 for (uint32_t r : order) {
                     const uint32_t l = hi[r] - lo[r];
                     n256 += l > 256u ? 1u : 0u;  // sorted: prefixes
                     n128 += l > 128u ? 1u : 0u;
                     n64 += l > 64u ? 1u : 0u;
+                    n32 += l > 32u ? 1u : 0u;
                     pn += l;
                 }
                 p.panel_long128.push_back(n256);
                 p.panel_long128.push_back(n128);
                 p.panel_long128.push_back(n64);
+                p.panel_long128.push_back(n32);
                 p.panel_nnz.push_back(pn);
                 for (uint32_t r : order) {
                     rows_v.push_back(r);
