@@ -198,7 +198,7 @@ int pygim_group_kernel_events(int64_t handle, int on);
 int pygim_group_plan(int64_t handle, int64_t out[8]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
- * "panel_coop", "panel_block", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
+ * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
  * "split_unit_pattern", "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events"};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, merge_parts at creation) are read when a group is created; the others per product.  */

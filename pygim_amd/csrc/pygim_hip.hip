@@ -66,6 +66,7 @@ struct Tunables {
     int64_t panel_bytes = 4 << 20;      // L2 budget of one (column panel x 128-byte feature slice)
     int64_t panel_min_seg = 8;          // auto: least average entries per (row, panel) worth a panel sweep
     int64_t panel_block = 256;          // threads per block of the sweep kernel (64, 128 or 256)
+    int64_t panel_lds_pad = 0;          // (experiment) unused dynamic LDS per sweep block: fewer resident blocks per CU
     int64_t panel_coop = 512;           // items longer than this are walked by a whole wave (8 lane groups)
     int64_t panel_pack = 1;             // 1 = gather from a slice-major copy of X (made per product)
     int64_t slice_group_bytes = 640ll << 20;  // sweep at most this many bytes of slice-major X per launch (0 = all slices at once)
@@ -542,7 +543,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 const uint32_t norm_grid = nnorm ? 8u * ns * ((row_blocks + 7) / 8) : 0u;
                 const uint32_t *ir = p.d_items + o, *ib = p.d_items + p.n_items + o, *il = p.d_items + 2 * p.n_items + o;
 #define PYGIM_LAUNCH_PANEL_D(AM, HV, DQ)                                                                    \
-    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV, DQ>), dim3(coop_grid + norm_grid), dim3(bthreads), 0, st,   \
+    hipLaunchKernelGGL((k_csr_panel<T, VEC, LOG_LPR, AM, HV, DQ>), dim3(coop_grid + norm_grid), dim3(bthreads), (size_t)g_tune.panel_lds_pad, st,   \
                        ir + ncoop, ib + ncoop, il + ncoop, nnorm, ir, ib, il, ncoop, coop_grid,                           \
                        (AM == 3 ? (const uint32_t *)p.col16 : p.colind), vals, Xs0, ldg,                                  \
                        slice_stride, Cs0, ldc, ws, ns, accumulate ? 1 : 0, q * p.panel_cols,                              \
@@ -1590,6 +1591,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
     else if (n == "vec_kernel") slot = &g_tune.vec_kernel;
     else if (n == "vec_lds") slot = &g_tune.vec_lds;
+    else if (n == "panel_lds_pad") slot = &g_tune.panel_lds_pad;
     else if (n == "vec_lds_min_seg") slot = &g_tune.vec_lds_min_seg;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
