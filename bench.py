@@ -19,7 +19,7 @@ N > 1 : strong scaling of the SAME graph with the full C on every rank at the en
         PYGIM_BENCH_PUSH=1 to let auto time them too; the default auto keeps to RCCL all-gathers).
         All exchanges complete inside the timed region.
 
-Launch: python bench.py --gpus 1 --steps 20 --warmup 5
+Launch: python bench.py --gpus N --steps 20 --warmup 5          (N > 1 without WORLD_SIZE: starts its own N ranks as children)
         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Rank 0 prints ONE JSON line.
 """
@@ -111,6 +111,24 @@ def cpu_baseline(rowptr, col, x, args):
                       f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` as a plain command: start the N ranks as CHILD processes (torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1), relay their output and return their exit code.  Nothing in this process has touched the
+    GPU yet, and nothing is exec'ed: a failing rank makes the launcher (max-restarts 0) and this process exit non-zero."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "--max-restarts", "0", os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +144,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     from pygim_amd import _lib, synth
 

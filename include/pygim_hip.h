@@ -72,6 +72,9 @@ typedef enum { PYGIM_CSR = 0, PYGIM_COO = 1 } pygim_format;
 int pygim_init_ranks(int64_t nr_ranks, int64_t *units_per_rank);
 int pygim_init_units(int64_t nr_units, int64_t *units_per_rank, int64_t *nr_ranks_out);
 int pygim_release(void);
+/* number of pygim_release calls so far: a handle made under an earlier generation is dead (every group was freed),
+ * even when the allocator hands the same address out again -- wrappers that cache a handle compare this. */
+int64_t pygim_generation(void);
 int pygim_is_initialized(void);
 const char *pygim_last_error(void);
 /* name / CU count / bytes of HBM of the device in use */
@@ -196,10 +199,16 @@ int pygim_group_kernel_events(int64_t handle, int on);
  * column panels (0 = no panel plan), columns per panel, work items, 16-bit panel-local column ids built (0/1),
  * wave-cooperative (long) items, segment-kernel tasks, merged (0/1), has a non-unit-weight correction part (0/1) */
 int pygim_group_plan(int64_t handle, int64_t out[8]);
+/* schedule of the LDS-staged product (k_lds_spmm; the reference's scratchpad loop spmm_default/dpu_kernels/
+ * spmm_mul_csr_dpu.c:108-126 with X chunks in LDS and the running sums of a tile of rows in registers) of the same matrix:
+ * row tiles (0 = no such plan), 64 KiB chunk fills per 64-feature slice and product, tokens incl. padding, stored entries */
+int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
- * "split_unit_pattern", "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events"};
+ * "split_unit_pattern", "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
+ * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
+ * "lds_min_width", "lds_threads"};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, merge_parts at creation) are read when a group is created; the others per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

@@ -18,7 +18,7 @@ EXPORTS = [
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
-    "pygim_quant_spmm_run_post",
+    "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -69,6 +69,8 @@ def lib():
         L.pygim_group_kernel_ms.argtypes = [c_i64, ctypes.POINTER(ctypes.c_double), p_i64, c_int]
         L.pygim_group_kernel_events.argtypes = [c_i64, c_int]
         L.pygim_group_plan.argtypes = [c_i64, p_i64]
+        L.pygim_group_lds_plan.argtypes = [c_i64, p_i64]
+        L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
         L.pygim_quant_absmax.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
@@ -176,6 +178,17 @@ def group_plan(handle):
     check(lib().pygim_group_plan(int(handle), out))
     keys = ["n_panels", "panel_cols", "n_items", "col16", "n_coop_items", "n_segment_tasks", "merged", "has_extra"]
     return dict(zip(keys, [int(v) for v in out]))
+
+
+def group_lds_plan(handle):
+    out = (ctypes.c_int64 * 4)()
+    check(lib().pygim_group_lds_plan(int(handle), out))
+    return dict(zip(["tiles", "chunk_fills", "tokens", "nnz"], [int(v) for v in out]))
+
+
+def generation():
+    """count of pygim_release calls: handles of an earlier generation are dead"""
+    return int(lib().pygim_generation())
 
 
 def group_info(handle):

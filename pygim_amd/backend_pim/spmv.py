@@ -20,7 +20,22 @@ class SparseTensorCOO(SparseGroupBase):
     def __init__(self, coo, dtype=torch.int32, groups=32):
         super().__init__(coo.int(), dtype=dtype, format="")
         self.groups = groups
-        self._wide = None  # (width, handle): a second group planned for the whole [N, h] product, see _mul_device
+        self._wide = None  # (width, handle, generation): a second group planned for the whole [N, h] product, see _mul_device
+
+    def _drop_wide(self):
+        """free the cached second group if it is still alive (dpu_release frees every group and bumps the generation:
+        a handle of an earlier generation must neither be used nor freed -- its address may belong to someone else)"""
+        from .. import _lib
+
+        wide, self._wide = self._wide, None
+        if wide is not None and _lib.is_initialized() and wide[2] == _lib.generation():
+            torch.ops.pim_ops.spmm_free_group(wide[1])
+
+    def __del__(self):
+        try:
+            self._drop_wide()
+        except Exception:  # interpreter shutdown: the library may be gone already
+            pass
 
     def build_coo(self):
         quantum = 64 // torch.iinfo(self.dtype).bits
@@ -31,6 +46,7 @@ class SparseTensorCOO(SparseGroupBase):
 
     def to_pim_group_coo(self, hidden_size, rank_pre_spmv=1):
         B_parts = hidden_size
+        self._drop_wide()
         self.format = "COO"
         self.hidden_size = hidden_size
         self.dense_parts = B_parts
@@ -77,12 +93,12 @@ class SparseTensorCOO(SparseGroupBase):
         if 2 <= self.dense_parts <= 4 and Bp.size(1) > 4:
             # groups of 2..4 vectors are planned for the LDS-staged SpMV kernel (narrow column panels); the whole-matrix
             # product wants the sweep's panels: a second group over the same arrays, made once (10.1 -> 6.9 ms, Reddit-shaped)
-            if self._wide is None or self._wide[0] != Bp.size(1):
-                if self._wide is not None:
-                    torch.ops.pim_ops.spmm_free_group(self._wide[1])
+            if self._wide is None or self._wide[0] != Bp.size(1) or self._wide[2] != _lib.generation():
+                self._drop_wide()
                 nrows, ncols = [c.size(0) for c in self.coo], [c.size(1) for c in self.coo]
                 self._wide = (Bp.size(1), torch.ops.pim_ops.spmv_coo_to_device_group(
-                    self.row_indices, self.col_indices, self.values, nrows, ncols, [1] * Bp.size(1), Bp.size(1), 1))
+                    self.row_indices, self.col_indices, self.values, nrows, ncols, [1] * Bp.size(1), Bp.size(1), 1),
+                    _lib.generation())
             handle = self._wide[1]
         _lib.block_run(handle, 0, Bp.data_ptr(), Bp.size(1), out.data_ptr(), Bp.size(1), Bp.size(1), False,
                        torch.cuda.current_stream(B.device).cuda_stream)

@@ -1,0 +1,214 @@
+// lds_plan.hpp -- host-side schedule of the LDS-staged product (k_lds_spmm, lds_kernel_gen.hpp).
+//
+// What the schedule describes (the reference keeps a DPU's slice of the dense operand in its
+// scratchpad and walks the stored entries of its rows against it,
+// spmm_default/dpu_kernels/spmm_mul_csr_dpu.c:108-126; the host cuts rows into per-DPU ranges,
+// spmm_mul_csr.c:118-259 -- here the "DPU" is a compute unit, its scratchpad the 160 KiB LDS and
+// its row range a TILE whose running sums live in the CU's vector registers):
+//
+//   * rows are cut into tiles of R = NW * KA consecutive rows (NW waves of a 512-thread workgroup,
+//     KA accumulator registers per wave: one register holds a row's 64-feature slice, one feature
+//     per lane).  Inside a tile the rows are dealt to the waves longest first, serpentine, so that
+//     every wave carries the same number of stored entries.
+//   * columns are cut into chunks of KC = 256 columns; a chunk of one 64-feature slice of X is
+//     64 KiB of LDS.  A tile lists the chunks in which it has entries (uniform graphs: all of them;
+//     community-structured graphs: a few) -- the workgroup streams exactly those through a
+//     double-buffered LDS ring.
+//   * per (tile, wave) a token stream: chunk after chunk, inside a chunk row after row (the order
+//     of the wave's accumulator index), inside a row in stored order.  A token is
+//     (column inside the chunk) << 8 | accumulator index, so that one stored entry costs the wave
+//     one ds_read_b32 and one indexed v_add.  Every row is summed by one wave in stored order:
+//     float results are bit-identical to the sequential CPU loop.
+//   * every (slot, wave) list is padded to whole batches of BATCH tokens with tokens that add a
+//     row of the chunk into a dummy accumulator.
+//
+// Pure C++ (no HIP): built here for the device, and by the CPU tests against an emulator.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace pygim {
+
+struct LdsTile {           // 64 bytes, read by the kernel with scalar loads
+    uint32_t nch;          // chunks (slots) this tile streams
+    uint32_t chunk_off;    // first entry of its chunk-id list (nch + 2 entries, the last id repeated)
+    uint32_t nb_off;       // first entry of its batch counts, [nch + 1][NW] (a closing row of zeros)
+    uint32_t row0;         // first row of the tile
+    uint32_t tokstart[8];  // per wave: first batch of its token stream (units of BATCH tokens)
+    uint32_t nnz;          // stored entries of the tile
+    uint32_t pad[3];
+};
+
+struct LdsGeometry {
+    uint32_t NW = 8;      // consumer waves per workgroup
+    uint32_t KA = 208;    // accumulators (rows) per wave; accumulator KA is the dummy
+    uint32_t KC = 256;    // columns per chunk
+    uint32_t BATCH = 16;  // tokens per batch (one scalar load)
+};
+
+struct LdsPlanHost {
+    LdsGeometry geo;
+    uint32_t ntiles = 0, nchunks = 0;
+    uint64_t ntokens = 0;            // incl. padding
+    uint64_t slots = 0;              // sum over tiles of nch: 64 KiB chunk fills per 64-feature slice
+    std::vector<uint32_t> tok;       // ntokens + BATCH of slack (the kernel prefetches one batch ahead)
+    std::vector<uint32_t> nb, chunks, rowmap;
+    std::vector<LdsTile> tiles;      // heaviest tile first (workgroups are dispatched in index order)
+};
+
+// rowptr / col: CSR with sorted column ids inside every row (checked by the caller).
+// threads = 0: std::thread::hardware_concurrency().
+inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
+                           LdsPlanHost &out, unsigned threads = 0) {
+    const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, B = geo.BATCH;
+    const uint32_t R = NW * KA;
+    const uint32_t ntiles = (nrows + R - 1) / R;
+    const uint32_t nchunks = (ncols + KC - 1) / KC;
+    out.geo = geo;
+    out.ntiles = ntiles;
+    out.nchunks = nchunks;
+    out.tiles.assign(ntiles, LdsTile());
+    out.rowmap.assign((size_t)ntiles * R, 0xFFFFFFFFu);
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = std::min<unsigned>(threads, std::max(1u, ntiles));
+
+    // per tile: the (wave, k) of every row, the chunk list, per (slot, wave) token counts
+    struct TileTmp {
+        std::vector<uint32_t> chunk_ids;   // ascending
+        std::vector<uint32_t> cnt;         // [nch][NW] tokens (unpadded)
+        std::vector<uint8_t> wave_of;      // per row of the tile
+        std::vector<uint16_t> k_of;
+        uint64_t batches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    std::vector<TileTmp> tmp(ntiles);
+    auto run = [&](auto &&fn) {
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> pool;
+        auto body = [&]() {
+            for (;;) {
+                const uint32_t t = next.fetch_add(1);
+                if (t >= ntiles) return;
+                fn(t);
+            }
+        };
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
+        body();
+        for (auto &th : pool) th.join();
+    };
+    run([&](uint32_t t) {
+        TileTmp &tt = tmp[t];
+        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0;
+        // longest rows first (stable), dealt serpentine over the waves
+        std::vector<uint32_t> order(nr);
+        for (uint32_t i = 0; i < nr; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
+        });
+        tt.wave_of.resize(nr);
+        tt.k_of.resize(nr);
+        for (uint32_t i = 0; i < nr; i++) {
+            const uint32_t round = i / NW, pos = i % NW;
+            const uint32_t w = (round & 1) ? NW - 1 - pos : pos;
+            tt.wave_of[order[i]] = (uint8_t)w;
+            tt.k_of[order[i]] = (uint16_t)round;
+            out.rowmap[((size_t)t * NW + w) * KA + round] = r0 + order[i];
+        }
+        // token counts per (chunk, wave)
+        std::vector<uint32_t> cnt((size_t)nchunks * NW, 0);
+        for (uint32_t i = 0; i < nr; i++) {
+            const uint32_t w = tt.wave_of[i];
+            for (uint32_t e = rowptr[r0 + i]; e < rowptr[r0 + i + 1]; e++) cnt[(size_t)(col[e] / KC) * NW + w]++;
+        }
+        for (uint32_t c = 0; c < nchunks; c++) {
+            uint32_t any = 0;
+            for (uint32_t w = 0; w < NW; w++) any |= cnt[(size_t)c * NW + w];
+            if (!any) continue;
+            tt.chunk_ids.push_back(c);
+            for (uint32_t w = 0; w < NW; w++) {
+                const uint32_t n = cnt[(size_t)c * NW + w];
+                tt.cnt.push_back(n);
+                tt.batches[w] += (n + B - 1) / B;
+            }
+        }
+        out.tiles[t].nch = (uint32_t)tt.chunk_ids.size();
+        out.tiles[t].row0 = r0;
+        out.tiles[t].nnz = rowptr[r1] - rowptr[r0];
+    });
+    // offsets
+    uint64_t tokb = 0, nbo = 0, cho = 0, slots = 0;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        LdsTile &d = out.tiles[t];
+        d.chunk_off = (uint32_t)cho;
+        d.nb_off = (uint32_t)nbo;
+        cho += d.nch + 2;
+        nbo += (uint64_t)(d.nch + 1) * NW;
+        slots += d.nch;
+        for (uint32_t w = 0; w < NW; w++) {
+            d.tokstart[w] = (uint32_t)tokb;
+            tokb += tmp[t].batches[w];
+        }
+    }
+    out.slots = slots;
+    out.ntokens = tokb * B;
+    out.tok.assign((size_t)out.ntokens + B, KA);  // everything starts as padding (column 0 -> the dummy accumulator)
+    out.nb.assign((size_t)nbo, 0);
+    out.chunks.assign((size_t)cho, 0);
+    run([&](uint32_t t) {
+        TileTmp &tt = tmp[t];
+        const LdsTile &d = out.tiles[t];
+        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0, nch = d.nch;
+        for (uint32_t j = 0; j < nch + 2; j++) out.chunks[(size_t)d.chunk_off + j] = nch ? tt.chunk_ids[std::min(j, nch - 1)] : 0;
+        // where each (slot, wave) list starts inside the wave's stream
+        std::vector<uint32_t> slot_of(nchunks, 0xFFFFFFFFu);
+        for (uint32_t j = 0; j < nch; j++) slot_of[tt.chunk_ids[j]] = j;
+        std::vector<uint64_t> cursor((size_t)nch * NW);
+        for (uint32_t w = 0; w < NW; w++) {
+            uint64_t at = (uint64_t)d.tokstart[w] * B;
+            for (uint32_t j = 0; j < nch; j++) {
+                cursor[(size_t)j * NW + w] = at;
+                const uint32_t nbat = (tt.cnt[(size_t)j * NW + w] + B - 1) / B;
+                out.nb[(size_t)d.nb_off + (size_t)j * NW + w] = nbat;
+                at += (uint64_t)nbat * B;
+            }
+        }
+        // rows in accumulator order per wave == any order that visits a wave's rows k = 0, 1, ...: walk k-major
+        for (uint32_t k = 0; k < KA; k++)
+            for (uint32_t w = 0; w < NW; w++) {
+                const uint32_t row = out.rowmap[((size_t)t * NW + w) * KA + k];
+                if (row == 0xFFFFFFFFu) continue;
+                for (uint32_t e = rowptr[row]; e < rowptr[row + 1]; e++) {
+                    const uint32_t c = col[e];
+                    const uint32_t j = slot_of[c / KC];
+                    out.tok[cursor[(size_t)j * NW + w]++] = ((c % KC) << 8) | k;
+                }
+            }
+        (void)nr;
+    });
+    // heaviest tile first
+    std::vector<uint32_t> ord(ntiles);
+    for (uint32_t t = 0; t < ntiles; t++) ord[t] = t;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tiles[a].nnz > out.tiles[b].nnz; });
+    std::vector<LdsTile> tiles2(ntiles);
+    std::vector<uint32_t> rowmap2(out.rowmap.size());
+    for (uint32_t i = 0; i < ntiles; i++) {
+        tiles2[i] = out.tiles[ord[i]];
+        std::copy(out.rowmap.begin() + (size_t)ord[i] * R, out.rowmap.begin() + (size_t)(ord[i] + 1) * R, rowmap2.begin() + (size_t)i * R);
+    }
+    out.tiles.swap(tiles2);
+    out.rowmap.swap(rowmap2);
+}
+
+// Cheap pre-check from the row pointers alone: stored entries per staged column if every tile streamed every chunk
+// (the uniform-graph bound; community-structured graphs stream fewer chunks and do better).
+inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo) {
+    const uint64_t R = (uint64_t)geo.NW * geo.KA;
+    const uint64_t ntiles = (nrows + R - 1) / R;
+    if (!ntiles || !ncols) return 0;
+    return (double)nnz / ((double)ntiles * (double)ncols);
+}
+
+}  // namespace pygim

@@ -13,6 +13,7 @@
 // point fails with PYGIM_ERR_NO_DEVICE.
 #include "../../include/pygim_hip.h"
 #include "kernels.hpp"
+#include "lds_kernel_gen.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -78,6 +79,10 @@ struct Tunables {
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
+    int64_t lds_mode = 2;               // LDS-staged product (k_lds_spmm): 0 = auto (reuse rule), 1 = whenever a part has the plan, 2 = never
+    int64_t lds_min_reuse_x100 = 150;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product
+    int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
+    int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
 } g_tune;
 
 struct LongPlan {
@@ -115,6 +120,11 @@ struct Part {
     // the PATTERN only (unit weights: no value array, no multiplies, packed 8/16-bit sums) and `extra` holds the few
     // entries with weight v != 1 as (v - 1); A.X = pattern.X + extra.X exactly in modular arithmetic
     std::unique_ptr<Part> extra;
+    // LDS-staged product (lds_plan.hpp): token streams and tile table on the device; lds_tiles == nullptr: no such plan
+    uint32_t *lds_tok = nullptr, *lds_nb = nullptr, *lds_chunks = nullptr, *lds_rowmap = nullptr;
+    LdsTile *lds_tiles = nullptr;
+    uint32_t lds_ntiles = 0;
+    uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
 
@@ -189,12 +199,14 @@ struct Context {
         const void *src = nullptr;  // what the buffer holds: X pointer, stride, rows, width, element size
         int64_t ld = 0, rows = 0, w = 0;
         size_t es = 0;
+        int kind = 0;  // 0 = 128-byte slices (sweep), 1 = 256-byte slices, rows padded to whole chunks (LDS-staged product)
         uint64_t stamp = 0;
         int in_use = 0;  // handed to a call that has not enqueued its kernels yet: not an eviction victim
     };
     static constexpr size_t XS_MAX = 4;
     std::map<std::pair<int, hipStream_t>, XsBuf> xs_bufs;
     uint64_t xs_clock = 0;
+    int64_t generation = 0;  // bumped by pygim_release: handles made before it are dead even if an address comes back
 } g_ctx;
 
 void free_xs_buffers_locked() {
@@ -300,6 +312,10 @@ void free_part(Part &p) {
     if (p.d_items) (void)hipFree(p.d_items);
     if (p.col16) (void)hipFree(p.col16);
     if (p.d_spmv_units) (void)hipFree(p.d_spmv_units);
+    for (void *q : {(void *)p.lds_tok, (void *)p.lds_nb, (void *)p.lds_chunks, (void *)p.lds_rowmap, (void *)p.lds_tiles})
+        if (q) (void)hipFree(q);
+    p.lds_tok = p.lds_nb = p.lds_chunks = p.lds_rowmap = nullptr;
+    p.lds_tiles = nullptr;
     if (p.extra) free_part(*p.extra);
 }
 
@@ -482,7 +498,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                         for (auto &kv : g_ctx.xs_bufs) {
                             Context::XsBuf &b = kv.second;
                             if (kv.first.first == dev && b.ptr && b.src == (const void *)X && b.ld == ldx && b.rows == p.ncols &&
-                                b.w == (int64_t)w && b.es == sizeof(T) && (!hit || b.stamp > hit->stamp))
+                                b.w == (int64_t)w && b.es == sizeof(T) && b.kind == 0 && (!hit || b.stamp > hit->stamp))
                                 hit = &b;
                         }
                         if (hit) {
@@ -502,10 +518,11 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                         b->rows = p.ncols;
                         b->w = (int64_t)w;
                         b->es = sizeof(T);
+                        b->kind = 0;
                         const uint64_t threads = (uint64_t)p.ncols * nslices * (1u << LOG_LPR);
                         if (threads > 0)
                             hipLaunchKernelGGL((k_slice_pack<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)),
-                                               dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)xs_use);
+                                               dim3(256), 0, st, X, ldx, (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)p.ncols);
                     }
                 }
                 g->packed_src = X;
@@ -602,12 +619,107 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
     return join();
 }
 
+// LDS-staged product (lds_kernel_gen.hpp / lds_plan.hpp): X is copied slice-major in 256-byte slices (64 features, rows padded to
+// whole 256-column chunks), then ONE launch: a 512-thread workgroup per (tile of rows, slice) streams the tile's chunks of X
+// through a double-buffered 128 KiB LDS ring and keeps the tile's running sums in registers; C is written once.
+template <typename T>
+int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate, hipStream_t st) {
+    static_assert(sizeof(T) == 4, "4-byte elements");
+    const uint32_t nslices = (w + 63) / 64;
+    const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
+    const size_t need = (size_t)rows_pad * nslices * 256;
+    KernelTimer kt(g, st, !p.is_extra);
+    XsPin pin;
+    void *xs_use = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        if (g->x_unchanged) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            Context::XsBuf *hit = nullptr;
+            for (auto &kv : g_ctx.xs_bufs) {
+                Context::XsBuf &b = kv.second;
+                if (kv.first.first == dev && b.ptr && b.src == (const void *)X && b.ld == ldx && b.rows == p.ncols && b.w == (int64_t)w &&
+                    b.es == sizeof(T) && b.kind == 1 && (!hit || b.stamp > hit->stamp))
+                    hit = &b;
+            }
+            if (hit) {
+                hit->stamp = ++g_ctx.xs_clock;
+                hit->in_use++;
+                xs_use = hit->ptr;
+                pin.hold(xs_use);
+            }
+        }
+        if (!xs_use) {
+            Context::XsBuf *b = nullptr;
+            if (int rc = xs_buffer_locked(st, std::max<size_t>(need, 256), &b)) return rc;
+            xs_use = b->ptr;
+            pin.hold(xs_use);
+            b->src = X;
+            b->ld = ldx;
+            b->rows = p.ncols;
+            b->w = (int64_t)w;
+            b->es = sizeof(T);
+            b->kind = 1;
+            const uint64_t threads = (uint64_t)p.ncols * nslices * 16;
+            if (threads > 0)
+                hipLaunchKernelGGL((k_slice_pack<T, 4, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
+                                   (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)rows_pad);
+        }
+    }
+    LdsArgs a;
+    a.tok = p.lds_tok;
+    a.nb = p.lds_nb;
+    a.chunks = p.lds_chunks;
+    a.tiles = p.lds_tiles;
+    a.rowmap = p.lds_rowmap;
+    a.xs = (const char *)xs_use;
+    a.c = (char *)C;
+    a.slice_stride = rows_pad * 256;
+    a.ldc_bytes = (uint32_t)((size_t)ldc * sizeof(T));
+    a.w = w;
+    a.nslices = nslices;
+    a.ntiles = p.lds_ntiles;
+    a.accumulate = accumulate ? 1 : 0;
+    a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
+    const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
+    if constexpr (std::is_same<T, float>::value) {
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lds_spmm_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_lds_spmm_f32, dim3(grid), dim3(512), LDS_BYTES, st, a);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_lds_spmm_i32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_lds_spmm_i32, dim3(grid), dim3(512), LDS_BYTES, st, a);
+    }
+    kt.stop();
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc) {
+    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return false;
+    if (!p.lds_tiles || g_tune.lds_mode == 2 || p.vals || g->deq_out || g->pre_xs) return false;
+    if ((int64_t)w < g_tune.lds_min_width) return false;
+    if ((uint64_t)ldc * sizeof(T) >= (1ull << 32)) return false;
+    return true;
+}
+
 template <typename T>
 int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t ldc, int64_t w, bool accumulate,
                  hipStream_t st) {
     const T *x = (const T *)X;
     T *c = (T *)C;
     const uint32_t ww = (uint32_t)w;
+    if constexpr (sizeof(T) == 4) {
+        if (want_lds<T>(g, p, ww, ldc)) return launch_lds<T>(g, p, x, ldx, c, ldc, ww, accumulate, st);
+    }
     // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
     if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
         // LDS-staged form: the plan's column panels with 16-bit local ids, a panel of X (panel_cols x w elements) plus the
@@ -818,6 +930,8 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // One-time plans of a part (needs its row pointers on the host): the long-row segment plans and the
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
+int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr);
+
 int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
     if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
@@ -966,6 +1080,45 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
             }
         }
     }
+    return build_lds_plan(p, es, d_flag_sorted, st, h_rowptr);
+}
+
+// One-time: the schedule of the LDS-staged product (lds_plan.hpp) for parts it pays for.  Built on the host from
+// the row pointers and column ids (the reference balances its DPU row ranges on the host too, spmm_mul_csr.c:118-259).
+int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr) {
+    if (g_tune.lds_mode == 2 || es != 4 || p.vals || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
+    if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
+    LdsGeometry geo;
+    geo.NW = LDS_NW;
+    geo.KA = LDS_KA;
+    geo.KC = LDS_KC;
+    geo.BATCH = LDS_BATCH;
+    if (g_tune.lds_mode == 0 &&
+        lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
+        return 0;
+    int unsorted = 0;
+    if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
+    hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr, p.colind,
+                       (uint32_t)p.nrows, d_flag_sorted);
+    if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "sortedness check");
+    if (unsorted) return 0;  // stored order inside a row must be column order for the chunk walk
+    std::vector<uint32_t> h_col((size_t)p.nnz);
+    if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
+    LdsPlanHost plan;
+    lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+    std::vector<uint32_t>().swap(h_col);
+    auto up = [&](auto **dst, const auto &v) {
+        using E = typename std::remove_reference<decltype(v[0])>::type;
+        const size_t bytes = std::max<size_t>(v.size() * sizeof(E), 64);
+        if (hipMalloc((void **)dst, bytes) != hipSuccess) return false;
+        return v.empty() || hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_nb, plan.nb) || !up(&p.lds_chunks, plan.chunks) || !up(&p.lds_rowmap, plan.rowmap) ||
+        !up(&p.lds_tiles, plan.tiles))
+        return fail(PYGIM_ERR_HIP, "LDS plan upload");
+    p.lds_ntiles = plan.ntiles;
+    p.lds_slots = plan.slots;
+    p.lds_tokens = plan.ntokens;
     return 0;
 }
 
@@ -1548,8 +1701,11 @@ int pygim_release(void) {
         free_xs_buffers_locked();
     }
     g_ctx.inited = false;
+    g_ctx.generation++;
     return 0;
 }
+
+int64_t pygim_generation(void) { return g_ctx.generation; }
 
 int pygim_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
     int dev = 0;
@@ -1593,6 +1749,10 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "vec_lds") slot = &g_tune.vec_lds;
     else if (n == "panel_lds_pad") slot = &g_tune.panel_lds_pad;
     else if (n == "vec_lds_min_seg") slot = &g_tune.vec_lds_min_seg;
+    else if (n == "lds_mode") slot = &g_tune.lds_mode;
+    else if (n == "lds_min_reuse_x100") slot = &g_tune.lds_min_reuse_x100;
+    else if (n == "lds_min_width") slot = &g_tune.lds_min_width;
+    else if (n == "lds_threads") slot = &g_tune.lds_threads;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;
@@ -1888,6 +2048,17 @@ int pygim_group_plan(int64_t handle, int64_t out[8]) {
     out[5] = p.lp_panel.n_tasks;
     out[6] = (g->merged && g->parts.size() > 1) ? 1 : 0;
     out[7] = p.extra ? 1 : 0;
+    return 0;
+}
+
+int pygim_group_lds_plan(int64_t handle, int64_t out[4]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    out[0] = p.lds_tiles ? (int64_t)p.lds_ntiles : 0;
+    out[1] = (int64_t)p.lds_slots;
+    out[2] = (int64_t)p.lds_tokens;
+    out[3] = p.nnz;
     return 0;
 }
 

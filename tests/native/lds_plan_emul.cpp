@@ -1,0 +1,78 @@
+// Test infrastructure: a CPU emulator of k_lds_spmm's token walk over the schedule lds_plan.hpp builds.
+// It reads the plan exactly as the kernel does (tile table, chunk lists, batch counts, token streams, row map)
+// so that tests/test_lds_plan.py can compare "what the schedule says" with the oracle on the CPU.
+#include "../../pygim_amd/csrc/lds_plan.hpp"
+
+#include <cstring>
+
+using namespace pygim;
+
+template <typename T>
+static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
+                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
+    LdsGeometry geo;
+    geo.KA = KA;
+    geo.BATCH = batch;
+    LdsPlanHost plan;
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads);
+    const uint32_t NW = geo.NW, KC = geo.KC;
+    const uint32_t nslices = (h + 63) / 64;
+    if (stats) {
+        stats[0] = plan.ntiles;
+        stats[1] = plan.slots;
+        stats[2] = plan.ntokens;
+        stats[3] = plan.tok.size();
+    }
+    std::vector<char> written((size_t)nrows, 0);
+    for (uint32_t ti = 0; ti < plan.ntiles; ti++) {
+        const LdsTile &t = plan.tiles[ti];
+        for (uint32_t s = 0; s < nslices; s++) {
+            const uint32_t wvalid = std::min(64u, h - s * 64);
+            for (uint32_t w = 0; w < NW; w++) {
+                std::vector<T> acc((size_t)(KA + 1) * 64, T(0));
+                uint64_t at = (uint64_t)t.tokstart[w] * batch;
+                for (uint32_t j = 0; j < t.nch; j++) {
+                    const uint32_t chunk = plan.chunks[t.chunk_off + j];
+                    const uint32_t nb = plan.nb[t.nb_off + (size_t)j * NW + w];
+                    for (uint32_t b = 0; b < nb * batch; b++, at++) {
+                        if (at >= plan.tok.size()) return 2;
+                        const uint32_t tk = plan.tok[at];
+                        const uint32_t k = tk & 0xFF, c = (tk >> 8) & 0xFF;
+                        if (tk >> 16) return 3;
+                        if (k > KA) return 4;
+                        const uint64_t xr = (uint64_t)chunk * KC + c;
+                        if (k < KA && xr >= ncols) return 5;
+                        for (uint32_t l = 0; l < wvalid; l++) {
+                            const T x = xr < ncols ? X[xr * h + s * 64 + l] : T(0);
+                            T &a = acc[(size_t)k * 64 + l];
+                            if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)x);
+                            else a = a + x;
+                        }
+                    }
+                }
+                if (plan.nb[t.nb_off + (size_t)t.nch * NW + w] != 0) return 6;  // closing row of zeros
+                for (uint32_t k = 0; k < KA; k++) {
+                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * KA + k];
+                    if (row == 0xFFFFFFFFu) continue;
+                    if (row >= nrows) return 7;
+                    if (s == 0) written[row]++;
+                    for (uint32_t l = 0; l < wvalid; l++) C[(size_t)row * h + s * 64 + l] = acc[(size_t)k * 64 + l];
+                }
+            }
+        }
+    }
+    for (uint32_t r = 0; r < nrows; r++)
+        if (written[r] != 1) return 8;
+    return 0;
+}
+
+extern "C" {
+int lds_emul_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
+    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats);
+}
+int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
+    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats);
+}
+}

@@ -1,0 +1,97 @@
+"""CPU: the schedule of the LDS-staged product (pygim_amd/csrc/lds_plan.hpp) says what the oracle computes.
+
+tests/native/lds_plan_emul.cpp walks the plan exactly as k_lds_spmm does (tile table, chunk lists, batch counts,
+token streams, row map), on the host.  The walk must reproduce the oracle's CSR loop (spmm_grande/spmm_mul_csr.c:119-136
+restated in oracle/spmm_oracle.c) BIT-exactly for floats too: every row is summed by one wave in stored order.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, random_csr
+
+_SRC = os.path.join(ROOT, "tests", "native", "lds_plan_emul.cpp")
+_SO = os.path.join(ROOT, "tests", "native", "liblds_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    deps = [_SRC, os.path.join(ROOT, "pygim_amd", "csrc", "lds_plan.hpp")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", _SRC, "-o", _SO])
+    return ctypes.CDLL(_SO)
+
+
+def _run(emul, rowptr, col, ncols, x, ka=208, batch=16, threads=4):
+    nrows = len(rowptr) - 1
+    h = x.shape[1]
+    out = np.full((nrows, h), 77, dtype=x.dtype)
+    stats = (ctypes.c_uint64 * 4)()
+    fn = emul.lds_emul_f32 if x.dtype == np.float32 else emul.lds_emul_i32
+    rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
+    xx = np.ascontiguousarray(x)
+    rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols,
+            xx.ctypes.data_as(ctypes.c_void_p), h, out.ctypes.data_as(ctypes.c_void_p), ka, batch, threads, stats)
+    assert rc == 0, f"emulator rejected the plan (code {rc})"
+    return out, list(stats)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+@pytest.mark.parametrize("shape", [(1, 1, 3), (300, 700, 64), (3000, 2500, 100), (1700, 5000, 256), (5000, 300, 65)])
+def test_plan_walk_equals_oracle(emul, dtype, shape):
+    nrows, ncols, h = shape
+    rng = np.random.default_rng(nrows * 7 + h)
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=12, long_rows=[(0, min(3000, 4 * ncols))] if nrows > 100 else ())
+    if dtype == np.float32:
+        x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    else:
+        x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)  # sums wrap
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    got, stats = _run(emul, rowptr, col, ncols, x)
+    assert got.tobytes() == want.tobytes()           # bit-exact, floats included (stored-order sums)
+    assert stats[2] % 16 == 0 and stats[3] == stats[2] + 16
+
+
+def test_small_geometry_many_tiles_and_ragged_tail(emul):
+    # KA = 5 -> tiles of 40 rows: many tiles, a ragged last tile, rows of every length incl. empty ones
+    rng = np.random.default_rng(5)
+    nrows, ncols, h = 333, 1000, 70
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=30, empty_frac=0.3, long_rows=[(17, 2000), (332, 999)])
+    x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    for batch in (8, 16):
+        got, stats = _run(emul, rowptr, col, ncols, x, ka=5, batch=batch)
+        assert got.tobytes() == want.tobytes()
+        assert stats[0] == (nrows + 39) // 40
+
+
+def test_clustered_columns_stream_few_chunks(emul):
+    # community-like columns: a tile streams only the chunks its rows touch (lds_plan.hpp: chunk list per tile)
+    rng = np.random.default_rng(11)
+    nrows = ncols = 20000
+    deg = rng.integers(5, 40, size=nrows)
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    rows = np.repeat(np.arange(nrows), deg)
+    col = np.clip(rows + np.rint(rng.normal(0, 200, size=rows.size)).astype(np.int64), 0, ncols - 1)
+    key = np.sort(rows * ncols + col)
+    col = (key % ncols).astype(np.int64)
+    x = rng.integers(-8, 4, size=(ncols, 64)).astype(np.float32)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    got, stats = _run(emul, rowptr, col, ncols, x)
+    assert got.tobytes() == want.tobytes()
+    ntiles, slots = stats[0], stats[1]
+    nchunks = (ncols + 255) // 256
+    assert slots < ntiles * nchunks / 3       # far fewer chunk fills than "every tile streams all of X"
+
+
+def test_empty_matrix_and_empty_rows(emul):
+    rowptr = np.zeros(11, dtype=np.int64)
+    col = np.zeros(0, dtype=np.int64)
+    x = np.ones((7, 64), dtype=np.float32)
+    got, stats = _run(emul, rowptr, col, 7, x)
+    assert not got.any() and stats[1] == 0
