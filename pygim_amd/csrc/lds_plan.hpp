@@ -33,15 +33,17 @@
 
 namespace pygim {
 
-struct LdsTile {           // 64 bytes, read by the kernel with scalar loads
-    uint32_t nch;          // chunks (slots) this tile streams
-    uint32_t chunk_off;    // first entry of its chunk-id list (nch + 2 entries, the last id repeated)
-    uint32_t nb_off;       // first entry of its batch counts, [nch + 1][NW] (a closing row of zeros)
-    uint32_t row0;         // first row of the tile
-    uint32_t tokstart[8];  // per wave: first batch of its token stream (units of BATCH tokens)
-    uint32_t nnz;          // stored entries of the tile
+struct LdsTile {            // 96 bytes, read by the kernel with scalar loads
+    uint32_t nch;           // chunks (slots) this tile streams
+    uint32_t chunk_off;     // first entry of its chunk-id list (nch + 2 entries, the last id repeated)
+    uint32_t nb_off;        // first entry of its batch counts, [nch + 2][NW] (two closing rows of zeros)
+    uint32_t row0;          // first row of the tile
+    uint32_t nnz;           // stored entries of the tile
     uint32_t pad[3];
+    uint32_t tokstart[16];  // per wave: first batch of its token stream (units of BATCH tokens)
 };
+
+constexpr uint32_t LDS_TOK_SLACK = 4096 + 64;  // tokens readable past the last one (next batch; touched lines)
 
 struct LdsGeometry {
     uint32_t NW = 8;      // consumer waves per workgroup
@@ -55,7 +57,7 @@ struct LdsPlanHost {
     uint32_t ntiles = 0, nchunks = 0;
     uint64_t ntokens = 0;            // incl. padding
     uint64_t slots = 0;              // sum over tiles of nch: 64 KiB chunk fills per 64-feature slice
-    std::vector<uint32_t> tok;       // ntokens + BATCH of slack (the kernel prefetches one batch ahead)
+    std::vector<uint32_t> tok;       // ntokens + LDS_TOK_SLACK (the kernel loads one batch ahead and touches lines 4 KiB ahead)
     std::vector<uint32_t> nb, chunks, rowmap;
     std::vector<LdsTile> tiles;      // heaviest tile first (workgroups are dispatched in index order)
 };
@@ -82,7 +84,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         std::vector<uint32_t> cnt;         // [nch][NW] tokens (unpadded)
         std::vector<uint8_t> wave_of;      // per row of the tile
         std::vector<uint16_t> k_of;
-        uint64_t batches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t batches[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     };
     std::vector<TileTmp> tmp(ntiles);
     auto run = [&](auto &&fn) {
@@ -145,7 +147,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         d.chunk_off = (uint32_t)cho;
         d.nb_off = (uint32_t)nbo;
         cho += d.nch + 2;
-        nbo += (uint64_t)(d.nch + 1) * NW;
+        nbo += (uint64_t)(d.nch + 2) * NW;
         slots += d.nch;
         for (uint32_t w = 0; w < NW; w++) {
             d.tokstart[w] = (uint32_t)tokb;
@@ -154,9 +156,9 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     }
     out.slots = slots;
     out.ntokens = tokb * B;
-    out.tok.assign((size_t)out.ntokens + B, KA);  // everything starts as padding (column 0 -> the dummy accumulator)
-    out.nb.assign((size_t)nbo, 0);
-    out.chunks.assign((size_t)cho, 0);
+    out.tok.assign((size_t)out.ntokens + LDS_TOK_SLACK, KA);  // everything starts as padding (column 0 -> the dummy accumulator)
+    out.nb.assign((size_t)nbo + 256, 0);      // (+ slack: the kernel touches lines a few slots ahead)
+    out.chunks.assign((size_t)cho + 128, 0);
     run([&](uint32_t t) {
         TileTmp &tt = tmp[t];
         const LdsTile &d = out.tiles[t];

@@ -83,6 +83,8 @@ struct Tunables {
     int64_t lds_min_reuse_x100 = 150;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product
     int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
+    int64_t lds_waves = 8;              // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
+    int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
 
 struct LongPlan {
@@ -123,7 +125,7 @@ struct Part {
     // LDS-staged product (lds_plan.hpp): token streams and tile table on the device; lds_tiles == nullptr: no such plan
     uint32_t *lds_tok = nullptr, *lds_nb = nullptr, *lds_chunks = nullptr, *lds_rowmap = nullptr;
     LdsTile *lds_tiles = nullptr;
-    uint32_t lds_ntiles = 0;
+    uint32_t lds_ntiles = 0, lds_nw = 8;
     uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
@@ -683,21 +685,26 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.accumulate = accumulate ? 1 : 0;
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
+    using KernelFn = void (*)(LdsArgs);
+    KernelFn fn = nullptr;
     if constexpr (std::is_same<T, float>::value) {
-        static bool attr = false;
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lds_spmm_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-            attr = true;
-        }
-        hipLaunchKernelGGL(k_lds_spmm_f32, dim3(grid), dim3(512), LDS_BYTES, st, a);
+        fn = p.lds_nw == 16 ? k_lds_spmm_f32_w16 : k_lds_spmm_f32_w8;
+        if (p.lds_nw == 8 && g_tune.lds_ablate == 1) fn = k_lds_spmm_f32_w8_ab1;
+        if (p.lds_nw == 8 && g_tune.lds_ablate == 2) fn = k_lds_spmm_f32_w8_ab2;
+        if (p.lds_nw == 8 && g_tune.lds_ablate == 3) fn = k_lds_spmm_f32_w8_ab3;
+        if (p.lds_nw == 8 && g_tune.lds_ablate == 4) fn = k_lds_spmm_f32_w8_ab4;
     } else {
-        static bool attr = false;
-        if (!attr) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_lds_spmm_i32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-            attr = true;
-        }
-        hipLaunchKernelGGL(k_lds_spmm_i32, dim3(grid), dim3(512), LDS_BYTES, st, a);
+        fn = p.lds_nw == 16 ? k_lds_spmm_i32_w16 : k_lds_spmm_i32_w8;
     }
+    {
+        static std::set<KernelFn> attr_done;
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        if (!attr_done.count(fn)) {
+            HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            attr_done.insert(fn);
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(p.lds_nw * 64), LDS_BYTES, st, a);
     kt.stop();
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1089,10 +1096,10 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     if (g_tune.lds_mode == 2 || es != 4 || p.vals || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
     if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
     LdsGeometry geo;
-    geo.NW = LDS_NW;
-    geo.KA = LDS_KA;
+    geo.NW = g_tune.lds_waves == 16 ? 16 : 8;
+    geo.KA = lds_ka(geo.NW);
     geo.KC = LDS_KC;
-    geo.BATCH = LDS_BATCH;
+    geo.BATCH = lds_batch(geo.NW);
     if (g_tune.lds_mode == 0 &&
         lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
         return 0;
@@ -1117,6 +1124,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         !up(&p.lds_tiles, plan.tiles))
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
     p.lds_ntiles = plan.ntiles;
+    p.lds_nw = geo.NW;
     p.lds_slots = plan.slots;
     p.lds_tokens = plan.ntokens;
     return 0;
@@ -1753,6 +1761,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_min_reuse_x100") slot = &g_tune.lds_min_reuse_x100;
     else if (n == "lds_min_width") slot = &g_tune.lds_min_width;
     else if (n == "lds_threads") slot = &g_tune.lds_threads;
+    else if (n == "lds_waves") slot = &g_tune.lds_waves;
+    else if (n == "lds_ablate") slot = &g_tune.lds_ablate;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

@@ -6,171 +6,268 @@ arguments into wave-uniform pointers).  Why assembly: a wave keeps KA rows' runn
 registers (one 64-feature slice per register, one feature per lane) and picks the register of each stored entry
 with the wave-uniform VGPR index (s_set_gpr_idx_*), which HIP C++ cannot express for 200 registers.
 
-Per stored entry the wave issues
+Per stored entry (token) the wave issues
     v_bfi_b32   addr = (token & 0xff00) | (lane * 4 + buffer)      -- row of the X chunk in LDS
     ds_read_b32 x    = LDS[addr]                                   -- 64 lanes x 4 B, conflict-free
     s_set_gpr_idx_idx token                                        -- M0[7:0] = accumulator index
     v_add       acc[idx] += x
 which is the reference's scratchpad loop (spmm_default/dpu_kernels/spmm_mul_csr_dpu.c:108-126) with the
-accumulators of ~1 700 rows resident per compute unit.  Schedule format: lds_plan.hpp.
+accumulators of ~1 500 rows resident per compute unit.  Schedule format: lds_plan.hpp.
 
-Register map (everything from v16 / s40 up is named in the clobber list, the compiler keeps below):
-    v16..v31   x / address registers of a batch          s40..s55  token set A      s56..s71  token set B
-    v32        lane*4 + current LDS buffer                 s72 batches left in the slot, s73 slot, s74 next chunk id
-    v33        0xff00                                      s75 tmp, s76:77 DMA source, s78 DMA LDS base, s79 buffer select
-    v34        lane*16 (DMA lane offset)                   s80:81 token pointer, s82:83 batch-count pointer,
-    v36        lane*4 (store offset), v37/v38 tmp          s84:85 chunk-id pointer, s86 nch, s87 next slot's batches,
-    v40..      accumulators, v[40+KA] = dummy              s88 chunk id after next, s89 k, s90..s97 row ids, s98:99 store address
+Structure of a workgroup (NW waves, one per (tile of rows, 64-feature slice)):
+    for every chunk (slot) of the tile:       -- 64 KiB of one slice of X, double-buffered in LDS
+        touch the NEXT slot's token lines (vector load, result unused -> the scalar token loads hit L2)
+        LDS-DMA this wave's share of the NEXT chunk (global_load_lds_dwordx4)
+        batches of BATCH tokens, software-pipelined: the LDS reads of batch i + 1 are issued before the
+            adds of batch i, the scalar load of batch i + 2 before both (three token sets in SGPRs, two x sets in VGPRs)
+        s_waitcnt vmcnt(0); s_barrier
+    store the accumulators to their rows of C
+
+What was measured on the way (profiles/r03_lds_kernel.md): the first form loaded tokens one batch ahead with s_load and
+waited lgkmcnt(0) per batch -- 10.1 ms, 62 % of the wave cycles in s_waitcnt: the token stream is read once, so every scalar
+load paid the HBM latency, and SMEM results cannot be waited for one by one.  Touching the lines ahead through the vector
+memory path (L2) brought 7.8 ms; moving the touches in front of the chunk DMA (so that the slot's closing vmcnt(0) never
+waits for a young touch) and pipelining the batch loop brought the rest.
 """
 import os
 import sys
 
-KA = 208
-BATCH = 16
-NW = 8
-ACC0 = 40
-X0 = 16
-TOKA, TOKB = 40, 56
+
+class Geo:
+    """register geometry of one kernel variant: NW waves per workgroup, KA accumulators per wave, BATCH tokens per scalar load.
+    VGPRs: temporaries v[T0..T0+7], two x / address sets of BATCH registers from X0, accumulators v[ACC0..ACC0+KA] (the last
+    one is the dummy that padding tokens add into).  SGPRs: three token sets from TOK0, control registers from CTL0."""
+
+    def __init__(self, NW, KA, BATCH, T0):
+        self.NW, self.KA, self.BATCH, self.T0 = NW, KA, BATCH, T0
+        self.X0 = T0 + 8
+        self.ACC0 = self.X0 + 2 * BATCH
+        self.vmax = 512 // (NW // 4)          # VGPRs per lane at NW / 4 waves per SIMD
+        assert self.ACC0 + KA + 1 <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
+        self.pieces = 64 // NW                # 1 KiB DMA pieces of a 64 KiB chunk per wave
+        self.threads = NW * 64
+        self.CTL0 = 84                        # control registers s84..s101; token sets below them (s32 is reserved: start at s36)
+        self.TOK0 = self.CTL0 - 3 * BATCH
+        assert self.TOK0 % 4 == 0 and self.TOK0 >= 36
 
 
-def body(op_add, weighted=False):
+GEOS = {8: Geo(8, 192, 16, 16), 16: Geo(16, 96, 8, 4)}
+
+
+def body(op_add, g, ablate=0):
+    """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
+    3 = no address computation and no LDS reads, 4 = no accumulation"""
+    KA, BATCH, NW, ACC0 = g.KA, g.BATCH, g.NW, g.ACC0
+    VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = (f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
+    XS = [g.X0, g.X0 + BATCH]
+    TOK = [g.TOK0 + i * BATCH for i in range(3)]
+    c = g.CTL0
+    # control SGPRs
+    NBL, NLEFT, CIDN, TMP = (f"s{c + i}" for i in range(4))              # batches left, slots left, next chunk id, temporary
+    PA_LO, PA_HI, PA = f"s{c + 4}", f"s{c + 5}", f"s[{c + 4}:{c + 5}]"   # 64-bit temporary (touch / DMA source address); even
+    DLDS, BUF = f"s{c + 6}", f"s{c + 7}"                                   # DMA LDS base (also a temporary), buffer select (0 / 0x10000)
+    TMP2 = DLDS
+    TP_LO, TP_HI, TP = f"s{c + 8}", f"s{c + 9}", f"s[{c + 8}:{c + 9}]"      # token pointer (address of the newest loaded batch)
+    NP_LO, NP_HI, NP = f"s{c + 10}", f"s{c + 11}", f"s[{c + 10}:{c + 11}]"  # batch-count pointer (this slot's entry)
+    CP_LO, CP_HI, CP = f"s{c + 12}", f"s{c + 13}", f"s[{c + 12}:{c + 13}]"  # chunk-id pointer (this slot's entry)
+    NBN, NBN2, CIDN2, ROT = (f"s{c + 14 + i}" for i in range(4))           # batches of slot+1 / +2, chunk id of slot+2, token-set rotation
+    assert c + 17 <= 101 and c % 2 == 0
+    # result stage (aliases of loop registers)
+    KREG, ROWID, EX_LO = NBL, NLEFT, c + 2
+    EX = f"s[{EX_LO}:{EX_LO + 1}]"
+    tokload = f"s_load_dwordx{BATCH}"
     L = []
     a = L.append
     # ---- set-up
-    a("v_lshlrev_b32 v36, 2, %[lane]")
-    a("v_lshlrev_b32 v34, 4, %[lane]")
-    a("v_mov_b32 v33, 0xff00")
+    a(f"v_lshlrev_b32 {VL4}, 2, %[lane]")
+    a(f"v_lshlrev_b32 {VL16}, 4, %[lane]")
+    a(f"v_lshlrev_b32 {VL128}, 7, %[lane]")
+    a(f"v_mov_b32 {VM}, 0xff00")
+    a(f"v_mov_b32 {VZ}, 0")
     for i in range(KA + 1):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
-    a("s_mov_b64 s[80:81], %[tok]")
-    a("s_mov_b64 s[82:83], %[nb]")
-    a("s_mov_b64 s[84:85], %[chunks]")
-    a("s_mov_b32 s86, %[nch]")
-    a("s_mov_b32 s73, 0")
-    a("s_mov_b32 s79, 0")
-    a("s_cmp_eq_u32 s86, 0")
+    a(f"s_mov_b64 {TP}, %[tok]")
+    a(f"s_mov_b64 {NP}, %[nb]")
+    a(f"s_mov_b64 {CP}, %[chunks]")
+    a(f"s_mov_b32 {NLEFT}, %[nch]")
+    a(f"s_mov_b32 {BUF}, 0")
+    a(f"s_mov_b32 {ROT}, 0")
+    a(f"s_cmp_eq_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_out_%=")
-    a("s_load_dword s74, s[84:85], 0x0")        # chunk id of slot 0
-    a("s_load_dword s88, s[84:85], 0x4")        # chunk id of slot 1
-    a("s_load_dword s72, s[82:83], 0x0")        # batches of slot 0
-    a(f"s_load_dwordx16 s[{TOKA}:{TOKA + 15}], s[80:81], 0x0")
+    a(f"s_load_dword {CIDN}, {CP}, 0x0")                 # chunk id of slot 0
+    a(f"s_load_dword {CIDN2}, {CP}, 0x4")                # chunk id of slot 1
+    a(f"s_load_dword {NBL}, {NP}, 0x0")                  # batches of slot 0
+    a(f"s_load_dword {NBN}, {NP}, {hex(NW * 4)}")        # batches of slot 1
+    a(f"{tokload} s[{TOK[0]}:{TOK[0] + BATCH - 1}], {TP}, 0x0")
     a("s_waitcnt lgkmcnt(0)")
 
-    def dma(cid, bufsel_expr_reg):
-        # 8 pieces of 1 KiB: this wave's eighth of the 64 KiB chunk `cid` -> LDS buffer `bufsel`
-        a(f"s_lshl_b32 s75, {cid}, 16")
-        a("s_add_u32 s76, %[xs_lo], s75")
-        a("s_addc_u32 s77, %[xs_hi], 0")
-        a(f"s_add_u32 s78, {bufsel_expr_reg}, %[ldsw]")
-        for i in range(8):
-            a("s_mov_b32 m0, s78")
+    def dma(cid, bufsel_reg):
+        # this wave's 1 KiB pieces of the 64 KiB chunk `cid` -> LDS buffer `bufsel`
+        a(f"s_lshl_b32 {TMP}, {cid}, 16")
+        a(f"s_add_u32 {PA_LO}, %[xs_lo], {TMP}")
+        a(f"s_addc_u32 {PA_HI}, %[xs_hi], 0")
+        a(f"s_add_u32 {DLDS}, {bufsel_reg}, %[ldsw]")
+        for i in range(g.pieces):
+            a(f"s_mov_b32 m0, {DLDS}")
             a("s_nop 0")
-            a("global_load_lds_dwordx4 v34, s[76:77]")
-            if i < 7:
-                a("s_add_u32 s76, s76, 0x400")
-                a("s_addc_u32 s77, s77, 0")
-                a("s_add_u32 s78, s78, 0x400")
+            a(f"global_load_lds_dwordx4 {VL16}, {PA}")
+            if i < g.pieces - 1:
+                a(f"s_add_u32 {PA_LO}, {PA_LO}, 0x400")
+                a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
+                a(f"s_add_u32 {DLDS}, {DLDS}, 0x400")
 
-    dma("s74", "s79")
+    dma(CIDN, BUF)
     a("s_waitcnt vmcnt(0)")
     a("s_barrier")
-    a("s_mov_b32 s74, s88")                      # s74 = chunk id of the NEXT slot from here on
-    a("s_mov_b32 s91, 0")                        # s91 = parity: which token set holds the current batch (0 = A)
+    a(f"s_mov_b32 {CIDN}, {CIDN2}")               # CIDN = chunk id of the NEXT slot from here on
     # ---- slot loop
     a("L_slot_%=:")
-    a("s_add_u32 s75, s73, 1")
-    a("s_cmp_lt_u32 s75, s86")
+    # Touch (one vector load, result unused) the lines of the NEXT slot's tokens so that the scalar loads of the batch loop hit the
+    # XCD's L2.  Lane l touches line l of the range; 63 lines per load, as many loads as the range needs.  Issued BEFORE the chunk
+    # DMA, so the slot's closing vmcnt(0) never waits for a young touch.  TP = this slot's first batch.
+    a(f"s_mul_i32 {TMP}, {NBL}, {BATCH * 4}")
+    a(f"s_add_u32 {PA_LO}, {TP_LO}, {TMP}")
+    a(f"s_addc_u32 {PA_HI}, {TP_HI}, 0")
+    a(f"s_mul_i32 {TMP}, {NBN}, {BATCH * 4}")
+    a(f"s_add_u32 {TMP}, {TMP}, 0xff")
+    a(f"s_lshr_b32 {TMP}, {TMP}, 7")              # lines of the next slot's tokens, + 1
+    a("L_touch_%=:")
+    a(f"s_min_u32 {TMP2}, {TMP}, 63")
+    a(f"s_bfm_b64 exec, {TMP2}, 0")
+    a(f"global_load_dword {VT1}, {VL128}, {PA}")
+    a(f"s_add_u32 {PA_LO}, {PA_LO}, 0x1f80")
+    a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
+    a(f"s_sub_u32 {TMP}, {TMP}, {TMP2}")
+    a(f"s_cmp_gt_u32 {TMP}, 0")
+    a("s_cbranch_scc1 L_touch_%=")
+    a("s_mov_b64 exec, -1")
+    # ... and the lines of the batch counts / chunk ids a few slots on (all lanes one address = one request each)
+    a(f"global_load_dword {VT1}, {VZ}, {NP} offset:{NW * 4 * 8}")
+    a(f"global_load_dword {VT1}, {VZ}, {CP} offset:256")
+    a(f"s_cmp_gt_u32 {NLEFT}, 1")
     a("s_cbranch_scc0 L_nodma_%=")
-    a("s_xor_b32 s90, s79, 0x10000")
-    dma("s74", "s90")
+    a(f"s_xor_b32 {TMP2}, {BUF}, 0x10000")
+    dma(CIDN, TMP2)
     a("L_nodma_%=:")
-    a("s_load_dword s88, s[84:85], 0x8")        # chunk id of slot j + 2 (the list is padded by two)
-    a("s_load_dword s87, s[82:83], 0x20")       # batches of slot j + 1 (closing row of zeros)
-    a("v_add_u32 v32, s79, v36")
-    a("s_cmp_eq_u32 s72, 0")
+    a(f"s_load_dword {CIDN2}, {CP}, 0x8")                # chunk id of slot j + 2 (the list is padded by two)
+    a(f"s_load_dword {NBN2}, {NP}, {hex(NW * 8)}")       # batches of slot j + 2 (two closing rows of zeros)
+    a(f"v_add_u32 {VB}, {BUF}, {VL4}")
+    a(f"s_cmp_eq_u32 {NBL}, 0")
     a("s_cbranch_scc1 L_slotend_%=")
-    a("s_cmp_eq_u32 s91, 0")
-    a("s_cbranch_scc0 L_batchB_%=")
+    a(f"s_cmp_eq_u32 {ROT}, 0")
+    a("s_cbranch_scc1 L_E0_%=")
+    a(f"s_cmp_eq_u32 {ROT}, 1")
+    a("s_cbranch_scc1 L_E1_%=")
+    a("s_branch L_E2_%=")
 
-    def batch(P, Q, me, other):
-        a(f"L_batch{me}_%=:")
-        a("s_add_u32 s80, s80, 0x40")
-        a("s_addc_u32 s81, s81, 0")
-        a(f"s_load_dwordx16 s[{Q}:{Q + 15}], s[80:81], 0x0")   # the next batch (this slot's or the next one's)
-        for i in range(BATCH):
-            a(f"v_bfi_b32 v{X0 + i}, v33, s{P + i}, v32")
-        for i in range(BATCH):
-            a(f"ds_read_b32 v{X0 + i}, v{X0 + i}")
-        a("s_waitcnt lgkmcnt(0)")
-        a(f"s_set_gpr_idx_on s{P}, gpr_idx(SRC1,DST)")
-        a(f"{op_add} v{ACC0}, v{X0}, v{ACC0}")
+    def load_next(r):
+        a(f"s_add_u32 {TP_LO}, {TP_LO}, {hex(BATCH * 4)}")
+        a(f"s_addc_u32 {TP_HI}, {TP_HI}, 0")
+        a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, 0x0")
+
+    def reads(r, x):
+        if ablate != 3:
+            for i in range(BATCH):
+                a(f"v_bfi_b32 v{XS[x] + i}, {VM}, s{TOK[r] + i}, {VB}")
+        if ablate not in (2, 3):
+            for i in range(BATCH):
+                a(f"ds_read_b32 v{XS[x] + i}, v{XS[x] + i}")
+
+    def adds(r, x):
+        if ablate == 4:
+            return
+        a(f"s_set_gpr_idx_on s{TOK[r]}, gpr_idx(SRC1,DST)")
+        a(f"{op_add} v{ACC0}, v{XS[x]}, v{ACC0}")
         for i in range(1, BATCH):
-            a(f"s_set_gpr_idx_idx s{P + i}")
-            a(f"{op_add} v{ACC0}, v{X0 + i}, v{ACC0}")
+            if ablate != 1:
+                a(f"s_set_gpr_idx_idx s{TOK[r] + i}")
+            a(f"{op_add} v{ACC0}, v{XS[x] + i}, v{ACC0}")
         a("s_set_gpr_idx_off")
-        a("s_sub_u32 s72, s72, 1")
-        a("s_cmp_eq_u32 s72, 0")
-        a(f"s_cbranch_scc1 L_done{me}_%=")
 
-    batch(TOKA, TOKB, "A", "B")
-    batch(TOKB, TOKA, "B", "A")
-    a("s_branch L_batchA_%=")
-    a("L_doneA_%=:")
-    a("s_mov_b32 s91, 1")                        # the prefetched batch sits in set B
-    a("s_branch L_slotend_%=")
-    a("L_doneB_%=:")
-    a("s_mov_b32 s91, 0")
+    def count_and_exit(r_next, x_next):
+        a(f"s_sub_u32 {NBL}, {NBL}, 1")
+        a(f"s_cmp_eq_u32 {NBL}, 0")
+        a(f"s_cbranch_scc1 L_D{r_next}{x_next}_%=")
+
+    # entries: tokens of the slot's first batch sit in set r
+    for r in (1, 2, 0):
+        a(f"L_E{r}_%=:")
+        load_next((r + 1) % 3)
+        reads(r, 0)
+        count_and_exit(r, 0)
+        if r != 0:
+            a(f"s_branch L_B{r}0_%=")
+    # (E0 falls through into B00) steady-state bodies in cycle order: (0,A) (1,B) (2,A) (0,B) (1,A) (2,B)
+    rr, xx = 0, 0
+    for _ in range(6):
+        a(f"L_B{rr}{xx}_%=:")
+        a("s_waitcnt lgkmcnt(0)")            # batch i's reads (issued a phase ago) and batch i + 1's tokens are in
+        load_next((rr + 2) % 3)
+        reads((rr + 1) % 3, 1 - xx)
+        adds(rr, xx)
+        rr, xx = (rr + 1) % 3, 1 - xx
+        count_and_exit(rr, xx)
+    a("s_branch L_B00_%=")
+    # drains: the last batch of the slot (tokens in set r, reads in flight in x-set x)
+    for r in range(3):
+        for x in range(2):
+            a(f"L_D{r}{x}_%=:")
+            a("s_waitcnt lgkmcnt(0)")
+            adds(r, x)
+            a(f"s_mov_b32 {ROT}, {(r + 1) % 3}")
+            a("s_branch L_slotend_%=")
     a("L_slotend_%=:")
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # my pieces of the next chunk have landed; s87 / s88 are in
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # my pieces of the next chunk have landed; NBN2 / CIDN2 are in
     a("s_barrier")                               # ... and everybody is done reading the current one
-    a("s_xor_b32 s79, s79, 0x10000")
-    a("s_mov_b32 s72, s87")
-    a("s_mov_b32 s74, s88")
-    a("s_add_u32 s84, s84, 4")
-    a("s_addc_u32 s85, s85, 0")
-    a("s_add_u32 s82, s82, 0x20")
-    a("s_addc_u32 s83, s83, 0")
-    a("s_add_u32 s73, s73, 1")
-    a("s_cmp_lt_u32 s73, s86")
+    a(f"s_xor_b32 {BUF}, {BUF}, 0x10000")
+    a(f"s_mov_b32 {NBL}, {NBN}")
+    a(f"s_mov_b32 {NBN}, {NBN2}")
+    a(f"s_mov_b32 {CIDN}, {CIDN2}")
+    a(f"s_add_u32 {CP_LO}, {CP_LO}, 4")
+    a(f"s_addc_u32 {CP_HI}, {CP_HI}, 0")
+    a(f"s_add_u32 {NP_LO}, {NP_LO}, {hex(NW * 4)}")
+    a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
+    a(f"s_sub_u32 {NLEFT}, {NLEFT}, 1")
+    a(f"s_cmp_gt_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_slot_%=")
     # ---- results: acc[k] -> C[rowmap[k]] (lanes beyond the slice's width masked off)
     a("L_out_%=:")
-    a("s_mov_b64 s[92:93], exec")
+    a(f"s_mov_b64 {EX}, exec")
     a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
     a("s_and_b64 exec, exec, vcc")
-    a("s_mov_b64 s[82:83], %[rowmap]")
-    a("s_mov_b32 s89, 0")
+    a(f"s_mov_b64 {NP}, %[rowmap]")
+    a(f"s_mov_b32 {KREG}, 0")
     a("L_orow_%=:")
-    a("s_load_dword s90, s[82:83], 0x0")
+    a(f"s_load_dword {ROWID}, {NP}, 0x0")
     a("s_waitcnt lgkmcnt(0)")
-    a("s_cmp_eq_u32 s90, -1")
+    a(f"s_cmp_eq_u32 {ROWID}, -1")
     a("s_cbranch_scc1 L_oskip_%=")
-    a("s_mul_i32 s98, s90, %[ldc]")
-    a("s_mul_hi_u32 s99, s90, %[ldc]")
-    a("s_add_u32 s98, s98, %[c_lo]")
-    a("s_addc_u32 s99, s99, %[c_hi]")
-    a("s_set_gpr_idx_on s89, gpr_idx(SRC0)")
-    a(f"v_mov_b32 v37, v{ACC0}")
+    a(f"s_mul_i32 {PA_LO}, {ROWID}, %[ldc]")
+    a(f"s_mul_hi_u32 {PA_HI}, {ROWID}, %[ldc]")
+    a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
+    a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
+    a(f"s_set_gpr_idx_on {KREG}, gpr_idx(SRC0)")
+    a(f"v_mov_b32 {VT0}, v{ACC0}")
     a("s_set_gpr_idx_off")
     a("s_cmp_eq_u32 %[accum], 0")
     a("s_cbranch_scc1 L_ost_%=")
-    a("global_load_dword v38, v36, s[98:99]")
+    a(f"global_load_dword {VT1}, {VL4}, {PA}")
     a("s_waitcnt vmcnt(0)")
-    a(f"{op_add} v37, v38, v37")
+    a(f"{op_add} {VT0}, {VT1}, {VT0}")
     a("L_ost_%=:")
-    a("global_store_dword v36, v37, s[98:99]")
+    a(f"global_store_dword {VL4}, {VT0}, {PA}")
     a("L_oskip_%=:")
-    a("s_add_u32 s82, s82, 4")
-    a("s_addc_u32 s83, s83, 0")
-    a("s_add_u32 s89, s89, 1")
-    a(f"s_cmp_lt_u32 s89, {KA}")
+    a(f"s_add_u32 {NP_LO}, {NP_LO}, 4")
+    a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
+    a(f"s_add_u32 {KREG}, {KREG}, 1")
+    a(f"s_cmp_lt_u32 {KREG}, {KA}")
     a("s_cbranch_scc1 L_orow_%=")
-    a("s_mov_b64 exec, s[92:93]")
+    a(f"s_mov_b64 exec, {EX}")
     a("s_waitcnt vmcnt(0)")
     return L
 
 
-HEADER = '''// GENERATED by scripts/gen_lds_kernel.py -- do not edit; edit the generator and re-run it.
+HEADER = """// GENERATED by scripts/gen_lds_kernel.py -- do not edit; edit the generator and re-run it.
 // LDS-staged product kernels for gfx950: schedule format in lds_plan.hpp, design notes in the generator.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -179,7 +276,10 @@ HEADER = '''// GENERATED by scripts/gen_lds_kernel.py -- do not edit; edit the g
 
 namespace pygim {
 
-constexpr uint32_t LDS_KA = %(KA)d, LDS_NW = %(NW)d, LDS_BATCH = %(BATCH)d, LDS_KC = 256, LDS_BYTES = 131072;
+constexpr uint32_t LDS_KC = 256, LDS_BYTES = 131072;
+// kernel variants: waves per workgroup -> accumulators per wave, tokens per batch
+constexpr uint32_t lds_ka(uint32_t nw) { return nw == 16 ? %(KA16)du : %(KA8)du; }
+constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du; }
 
 struct LdsArgs {
     const uint32_t *tok;      // token streams
@@ -192,12 +292,13 @@ struct LdsArgs {
     uint64_t slice_stride;    // bytes between two slices of xs
     uint32_t ldc_bytes, w, nslices, ntiles, accumulate, xcd_group;
 };
-'''
+"""
 
-KERNEL = '''
+KERNEL = """
 // %(doc)s
-__global__ __launch_bounds__(512) void %(name)s(LdsArgs a) {
+__global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     extern __shared__ char lds_dyn[];
+    constexpr uint32_t NW = %(NW)d, KA = %(KA)d, BATCH = %(BATCH)d, PIECE = %(piece)du;
     const uint32_t b = blockIdx.x;
     uint32_t slice, ti;
     if (a.xcd_group) {  // blocks b and b + 8 share an XCD: an XCD (or a group of them) streams ONE slice of X through its L2
@@ -213,14 +314,14 @@ __global__ __launch_bounds__(512) void %(name)s(LdsArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const LdsTile *t = a.tiles + ti;
     const uint32_t nch = __builtin_amdgcn_readfirstlane(t->nch);
-    const uint64_t tok = (uint64_t)(a.tok + (uint64_t)t->tokstart[wave] * LDS_BATCH);
+    const uint64_t tok = (uint64_t)(a.tok + (uint64_t)t->tokstart[wave] * BATCH);
     const uint64_t nb = (uint64_t)(a.nb + t->nb_off + wave);
     const uint64_t chunks = (uint64_t)(a.chunks + t->chunk_off);
-    const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * 8192u);
-    const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * LDS_NW + wave) * LDS_KA);
+    const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * PIECE);
+    const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * KA);
     const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
-    const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * 8192u);
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * PIECE);
 #define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
     const uint32_t tok_lo = PYGIM_SU(tok), tok_hi = PYGIM_SU(tok >> 32), nb_lo = PYGIM_SU(nb), nb_hi = PYGIM_SU(nb >> 32);
     const uint32_t ch_lo = PYGIM_SU(chunks), ch_hi = PYGIM_SU(chunks >> 32), xs_lo = PYGIM_SU(xs), xs_hi = PYGIM_SU(xs >> 32);
@@ -236,17 +337,24 @@ __global__ __launch_bounds__(512) void %(name)s(LdsArgs a) {
           [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw)
         : %(clobbers)s, "vcc", "scc", "memory");
 }
-'''
+"""
 
 
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pygim_amd", "csrc", "lds_kernel_gen.hpp")
-    clob = ", ".join([f'"v{i}"' for i in range(16, 256)] + [f'"s{i}"' for i in range(40, 100)])
-    text = HEADER % dict(KA=KA, NW=NW, BATCH=BATCH)
-    for name, op, doc in (("k_lds_spmm_f32", "v_add_f32", "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"),
-                          ("k_lds_spmm_i32", "v_add_u32", "INT32, unit weights: two's-complement modular sums")):
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op))
-        text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob)
+    text = HEADER % dict(KA8=GEOS[8].KA, KA16=GEOS[16].KA, B8=GEOS[8].BATCH, B16=GEOS[16].BATCH)
+    variants = []
+    for nw in (8, 16):
+        variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
+        variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
+    for ab in (1, 2, 3, 4):
+        variants.append((f"k_lds_spmm_f32_w8_ab{ab}", "v_add_f32", 8, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
+    for name, op, nw, ab, doc in variants:
+        g = GEOS[nw]
+        clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab))
+        text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,
+                              piece=g.pieces * 1024)
     text += "\n}  // namespace pygim\n"
     with open(out, "w") as f:
         f.write(text)

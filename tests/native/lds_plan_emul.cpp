@@ -9,8 +9,9 @@ using namespace pygim;
 
 template <typename T>
 static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
+                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
     LdsGeometry geo;
+    geo.NW = nw;
     geo.KA = KA;
     geo.BATCH = batch;
     LdsPlanHost plan;
@@ -68,11 +69,11 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
 
 extern "C" {
 int lds_emul_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
-    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
+    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw);
 }
 int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats) {
-    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
+    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw);
 }
 }
