@@ -39,7 +39,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3
-L2_PEAK_TBS = 128 * 64 * 2.4e9 / 1e12  # 8 XCDs x 16 L2 channels x 64 B/clk at 2.4 GHz = 19.66 TB/s
+L2_PEAK_TBS = 34.5  # MI355X_MICROARCH.md, L2 section (its measured rate for L2-resident ROW GATHERS is 16.8-18.8 TB/s)
+LDS_READ_B32_TBS = 256 * 128 * 2.4e9 / 1e12  # ds_read_b32: 128 B/clk per CU (MI355X_MICROARCH.md, LDS table) x 256 CUs at 2.4 GHz = 78.6
 
 
 def nnz_balanced_row_split(rowptr_cpu, nparts):
@@ -140,6 +141,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole graph, about 6 s on 128 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the clustered-columns measurement beside the headline")
     ap.add_argument("--partition", default="auto", choices=["auto", "row", "feature", "pipelined", "pipelined-feature", "push", "push-feature"])
     ap.add_argument("--chunks", type=int, default=0, help="row pieces per rank (0 = 1 on one GPU; on N > 1 the fastest of 1 / 2 / 4, measured before the warm-up)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
@@ -796,30 +798,50 @@ def main():
         try:
             tj = json.load(open(args.traffic_json))
             traffic = tj.get("hbm_bytes_per_product")
+            lds_now = _lib.group_lds_plan(handles[0])["tiles"] > 0
+            if lds_now != ("k_lds_spmm" in str(tj.get("kernel"))):
+                traffic = None  # the committed counter run is of the other kernel family: nothing to replay
             traffic_source = {"replayed_from": os.path.relpath(args.traffic_json, ROOT), "collected": tj.get("collected"),
                               "box": tj.get("box"), "command": tj.get("command"), "kernel_ms_then": tj.get("kernel_ms")}
         except Exception:
             traffic = None
     plan_info = _lib.group_plan(handles[0])
+    lds_info = _lib.group_lds_plan(handles[0])
     n_panels = int(plan_info["n_panels"])
-    # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
-    amode = 3 if plan_info["col16"] else 2
-    kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false,false> x {n_panels} panel launches per product" if n_panels
-             else "k_csr_wide<float,4>")
+    gather = synth.gather_bytes(my_rows, my_nnz, my_h, 4)
+    if lds_info["tiles"] > 0 and my_h >= 33:
+        # LDS-staged product (pygim_amd/csrc/lds_kernel_gen.hpp): one launch; every stored entry reads its 256-byte row slice
+        # of X from LDS (ds_read_b32), the chunks of X are staged L2 -> LDS once per (tile, slice)
+        nsl = (my_h + 63) // 64
+        kname = f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16 (ONE launch per product: {lds_info['tiles']} row tiles x {nsl} slices)"
+        launches = 1
+        staged = lds_info["chunk_fills"] * 65536 * nsl
+        on_chip = {"level": "LDS (ds_read_b32, one 256-byte row slice per stored entry and slice)", "gather_bytes": gather,
+                   "achieved_TBs": round(gather / (k_ms * 1e-3) / 1e12, 2) if k_ms else None, "peak_TBs": round(LDS_READ_B32_TBS, 1),
+                   "frac": round(gather / (k_ms * 1e-3) / 1e12 / LDS_READ_B32_TBS, 4) if k_ms else None,
+                   "staged_L2_to_LDS_bytes": staged,
+                   "staged_TBs": round(staged / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
+                   "tokens_incl_padding": lds_info["tokens"]}
+    else:
+        # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
+        amode = 3 if plan_info["col16"] else 2
+        kname = (f"k_slice_pack + k_csr_panel<float,4,3,{amode},false,false> x {n_panels} panel launches per product" if n_panels
+                 else "k_csr_wide<float,4>")
+        launches = max(n_panels, 1)
+        # the sweep pulls one 128-byte line per (stored entry, slice) out of the L2: a RANDOM-LINE GATHER rate, to be read against
+        # the guide's measured 16.8-18.8 TB/s for L2-resident row gathers, not against the L2's streaming peak
+        on_chip = {"level": "L2 -> L1 random-line gathers", "gather_bytes": gather,
+                   "achieved_TBs": round(gather / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
+                   "peak_TBs": L2_PEAK_TBS, "frac": round(gather / (k_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4) if k_ms else None,
+                   "measured_gather_ceiling_TBs": "16.8-18.8 (MI355X_MICROARCH.md, indexed rows from the XCD's L2)"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kname, "kernel_ms": round(k_ms, 4), "products_timed": k_count,
-                "launches_per_product": max(n_panels, 1),
+                "launches_per_product": launches,
                 "algorithmic_bytes": alg_bytes,
-                "gather_model_GBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
+                "gather_model_GBs": round(gather / (k_ms * 1e-3) / 1e9, 1) if k_ms else None,
                 "fp32_frac": round(synth.flops(my_nnz, my_h) / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5) if k_ms else None,
-                # the level the sweep actually works at (profiles/r02_pmc_summary.txt: TCC_BUSY = 97 % of the launch, one 128-byte
-                # request per L2 channel every two cycles): every stored entry pulls one 128-byte line per feature slice out of
-                # the L2; the reference rate is 128 channels x 64 B/clk
-                "l2": {"gather_bytes": synth.gather_bytes(my_rows, my_nnz, my_h, 4),
-                       "achieved_TBs": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
-                       "peak_TBs": L2_PEAK_TBS,
-                       "frac": round(synth.gather_bytes(my_rows, my_nnz, my_h, 4) / (k_ms * 1e-3) / 1e12 / L2_PEAK_TBS, 4) if k_ms else None}}
+                "on_chip": on_chip}
 
     result = {
         "metric": ("SpMM GFLOP/s, Reddit-shaped CSR h=256 fp32" if (args.shape, h) == ("reddit", 256) else
@@ -837,12 +859,37 @@ def main():
         "roofline": roofline,
     }
 
+    if rank == 0 and world == 1 and not args.clustered and not args.no_extra:
+        # SURVEY.md 8(d) asks for both column shapes: the same product on the community-like variant of the graph (columns within
+        # ~1 % of the row id), measured here OUTSIDE the timed region and reported beside the headline
+        rp_c, col_c = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=True)
+        hd_c = _lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+        out_c = torch.empty((n, h), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            _lib.spmm_run_group(hd_c, [x.data_ptr()], out_c.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        for i in range(10):
+            ev[i].record(main_stream)
+            _lib.spmm_run_group(hd_c, [x.data_ptr()], out_c.data_ptr(), stream)
+        ev[10].record(main_stream)
+        torch.cuda.synchronize()
+        ts_c = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
+        cc = torch.bincount(col_c.long(), minlength=n).double()
+        result["extra"] = {"clustered_ms_per_step": round(ts_c[len(ts_c) // 2], 4),
+                           "clustered_GFLOPs": round(total_flops / (ts_c[len(ts_c) // 2] * 1e-3) / 1e9, 1),
+                           "clustered_lds_plan": _lib.group_lds_plan(hd_c),
+                           "clustered_check": "column-count checksum exact" if torch.equal(out_c.double().sum(0), cc @ x.double()) else "MISMATCH",
+                           "note": "same N / nnz / degrees, columns within ~1 % of the row id (synth.make_csr clustered=True); 10 steps, median, outside the timed region"}
+        _lib.group_free(hd_c)
+        del rp_c, col_c, out_c
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, cpu_out = cpu_baseline(rowptr, col, x, args)
         result["cpu_baseline"] = base
         if not args.no_check:
             got = plan.full_c()[: cpu_out.shape[0]].cpu().numpy()
-            result["check"] = "bit-exact vs oracle on the sampled rows" if np.array_equal(got, cpu_out) else "MISMATCH"
+            result["check"] = ((f"bit-exact vs oracle on all {cpu_out.shape[0]} rows" if cpu_out.shape[0] == n else
+                                f"bit-exact vs oracle on rows [0, {cpu_out.shape[0]})") if np.array_equal(got, cpu_out) else "MISMATCH")
             # real-valued features, whole graph (exercises the floating-point bar of north_star: 1e-5 relative): the same
             # product on X ~ U(-1, 1) against the oracle's row-parallel loop; error relative to |result| and to |A|.|x|
             import oracle

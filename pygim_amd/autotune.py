@@ -26,6 +26,15 @@ RATE_STREAM = 5.0e12        # streaming reads/writes (index arrays, C)
 XGMI_IN = 7 * 45e9          # inbound bytes/s per GPU, 7 links (spec 7 x ~64 GB/s per direction; 70 % assumed)
 PANEL_BYTES = 4 << 20
 LAUNCH = 6e-6               # per kernel launch incl. ramp, back to back
+# LDS-staged product (k_lds_spmm, round 3; profiles/r03_lds_kernel.md): one 1024-thread workgroup per CU and (row tile, 64-feature slice)
+CUS = 256
+LDS_CLOCK = 2.3e9           # Hz held under this kernel (GRBM_GUI_ACTIVE / 8 / time)
+LDS_ROWS_MAX = 16 * 96      # rows of a tile (waves x accumulators per wave)
+LDS_CYC_PER_TOKEN = 4.0     # CU cycles per stored entry and slice (measured: clustered columns, nothing else in the way)
+LDS_CYC_PER_SLOT = 800      # CU cycles per 64 KiB chunk of X beside the tokens (barrier skew, DMA issue, touches)
+LDS_CYC_FILL = 2300         # CU cycles to land 64 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
+LDS_PAD = 1.085             # tokens incl. batch padding per stored entry (uniform columns)
+LDS_MIN_REUSE = 1.5         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
 @dataclass
@@ -38,10 +47,42 @@ class Choice:
     panel: bool
 
 
+def lds_rows_per_tile(nrows, nslices, rmax=LDS_ROWS_MAX, cus=CUS):
+    """lds_plan.hpp lds_rows_per_tile: tile height such that tiles x slices workgroups fill whole rounds of CUs"""
+    tiles = -(-nrows // rmax)
+    wgs = tiles * nslices
+    rounds = -(-wgs // cus)
+    if rounds > 8 or wgs % cus == 0:
+        return rmax
+    tiles2 = -(-rounds * cus // nslices)
+    if tiles2 <= tiles:
+        return rmax
+    return min(rmax, max(16, -(-nrows // tiles2)))
+
+
+def lds_product_seconds(nrows, ncols, nnz, h, es):
+    """the LDS-staged product on one GPU, or None where the library keeps the sweep (4-byte elements, rows of at least 33
+    elements, enough stored entries per staged column); uniform columns assumed (every tile streams every chunk)"""
+    if es != 4 or h < 33 or nrows == 0 or nnz == 0:
+        return None
+    nsl = -(-h // 64)
+    rpt = lds_rows_per_tile(int(nrows), nsl)
+    tiles = -(-int(nrows) // rpt)
+    if nnz / (tiles * ncols) < LDS_MIN_REUSE:
+        return None
+    slots = -(-int(ncols) // 256)
+    per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * LDS_CYC_PER_SLOT, slots * LDS_CYC_FILL)
+    rounds = -(-tiles * nsl // CUS)
+    return rounds * per_wg / LDS_CLOCK + ncols * h * es * 2 / RATE_STREAM + LAUNCH
+
+
 def product_seconds(nrows, ncols, nnz, h, es):
     """one GPU: rows x all columns, h features"""
     if nrows == 0 or nnz == 0 or h == 0:
         return 0.0, False
+    t_lds = lds_product_seconds(nrows, ncols, nnz, h, es)
+    if t_lds is not None:
+        return t_lds, True
     row_bytes = h * es
     line_bytes = max(row_bytes, 128) if row_bytes < 128 else row_bytes  # at least one cache line per entry
     gather = nnz * line_bytes

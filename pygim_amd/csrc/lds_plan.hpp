@@ -50,6 +50,7 @@ struct LdsGeometry {
     uint32_t KA = 208;    // accumulators (rows) per wave; accumulator KA is the dummy
     uint32_t KC = 256;    // columns per chunk
     uint32_t BATCH = 16;  // tokens per batch (one scalar load)
+    uint32_t rows_per_tile = 0;  // 0 = NW * KA; fewer rows per tile = more, lighter tiles (to fill whole rounds of workgroups)
 };
 
 struct LdsPlanHost {
@@ -58,6 +59,7 @@ struct LdsPlanHost {
     uint64_t ntokens = 0;            // incl. padding
     uint64_t slots = 0;              // sum over tiles of nch: 64 KiB chunk fills per 64-feature slice
     std::vector<uint32_t> tok;       // ntokens + LDS_TOK_SLACK (the kernel loads one batch ahead and touches lines 4 KiB ahead)
+    std::vector<uint32_t> wts;       // valued matrices: the entries' 4-byte values (raw bits) in token order, 0 for padding; else empty
     std::vector<uint32_t> nb, chunks, rowmap;
     std::vector<LdsTile> tiles;      // heaviest tile first (workgroups are dispatched in index order)
 };
@@ -65,16 +67,17 @@ struct LdsPlanHost {
 // rowptr / col: CSR with sorted column ids inside every row (checked by the caller).
 // threads = 0: std::thread::hardware_concurrency().
 inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
-                           LdsPlanHost &out, unsigned threads = 0) {
+                           LdsPlanHost &out, unsigned threads = 0, const uint32_t *vals = nullptr) {
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, B = geo.BATCH;
-    const uint32_t R = NW * KA;
+    const uint32_t RS = NW * KA;                                                       // row-map stride of a tile
+    const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, RS) : RS;     // rows of a tile
     const uint32_t ntiles = (nrows + R - 1) / R;
     const uint32_t nchunks = (ncols + KC - 1) / KC;
     out.geo = geo;
     out.ntiles = ntiles;
     out.nchunks = nchunks;
     out.tiles.assign(ntiles, LdsTile());
-    out.rowmap.assign((size_t)ntiles * R, 0xFFFFFFFFu);
+    out.rowmap.assign((size_t)ntiles * RS, 0xFFFFFFFFu);
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = std::min<unsigned>(threads, std::max(1u, ntiles));
 
@@ -157,6 +160,8 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     out.slots = slots;
     out.ntokens = tokb * B;
     out.tok.assign((size_t)out.ntokens + LDS_TOK_SLACK, KA);  // everything starts as padding (column 0 -> the dummy accumulator)
+    if (vals) out.wts.assign(out.tok.size(), 0u);
+    else out.wts.clear();
     out.nb.assign((size_t)nbo + 256, 0);      // (+ slack: the kernel touches lines a few slots ahead)
     out.chunks.assign((size_t)cho + 128, 0);
     run([&](uint32_t t) {
@@ -185,7 +190,9 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
                 for (uint32_t e = rowptr[row]; e < rowptr[row + 1]; e++) {
                     const uint32_t c = col[e];
                     const uint32_t j = slot_of[c / KC];
-                    out.tok[cursor[(size_t)j * NW + w]++] = ((c % KC) << 8) | k;
+                    const uint64_t at = cursor[(size_t)j * NW + w]++;
+                    out.tok[at] = ((c % KC) << 8) | k;
+                    if (vals) out.wts[at] = vals[e];
                 }
             }
         (void)nr;
@@ -198,16 +205,31 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     std::vector<uint32_t> rowmap2(out.rowmap.size());
     for (uint32_t i = 0; i < ntiles; i++) {
         tiles2[i] = out.tiles[ord[i]];
-        std::copy(out.rowmap.begin() + (size_t)ord[i] * R, out.rowmap.begin() + (size_t)(ord[i] + 1) * R, rowmap2.begin() + (size_t)i * R);
+        std::copy(out.rowmap.begin() + (size_t)ord[i] * RS, out.rowmap.begin() + (size_t)(ord[i] + 1) * RS, rowmap2.begin() + (size_t)i * RS);
     }
     out.tiles.swap(tiles2);
     out.rowmap.swap(rowmap2);
 }
 
+// Rows per tile such that the tiles x slices workgroups of one product fill whole rounds of the device's compute units
+// (one workgroup per CU at a time): 152 tiles x 4 slices on 256 CUs would run as three rounds with the third 37 % full;
+// 192 lighter tiles run as three full, shorter ones.  Only worth it for a handful of rounds.
+inline uint32_t lds_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32_t nslices, uint32_t cus) {
+    if (!nrows || !nslices || !cus) return rmax;
+    const uint64_t tiles = (nrows + rmax - 1) / rmax, wgs = tiles * nslices;
+    const uint64_t rounds = (wgs + cus - 1) / cus;
+    if (rounds > 8 || wgs % cus == 0) return rmax;
+    // as many tiles as fit the same number of rounds (less than one round: enough tiles to give every CU a workgroup --
+    // the caller's reuse rule then decides whether such light tiles are still worth staging X for)
+    const uint64_t tiles2 = (rounds * cus + nslices - 1) / nslices;
+    if (tiles2 <= tiles) return rmax;
+    return (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(16, (nrows + tiles2 - 1) / tiles2));
+}
+
 // Cheap pre-check from the row pointers alone: stored entries per staged column if every tile streamed every chunk
 // (the uniform-graph bound; community-structured graphs stream fewer chunks and do better).
 inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo) {
-    const uint64_t R = (uint64_t)geo.NW * geo.KA;
+    const uint64_t R = geo.rows_per_tile ? geo.rows_per_tile : (uint64_t)geo.NW * geo.KA;
     const uint64_t ntiles = (nrows + R - 1) / R;
     if (!ntiles || !ncols) return 0;
     return (double)nnz / ((double)ntiles * (double)ncols);

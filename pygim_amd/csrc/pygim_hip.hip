@@ -79,11 +79,12 @@ struct Tunables {
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
-    int64_t lds_mode = 2;               // LDS-staged product (k_lds_spmm): 0 = auto (reuse rule), 1 = whenever a part has the plan, 2 = never
+    int64_t lds_mode = 0;               // LDS-staged product (k_lds_spmm): 0 = auto (reuse rule), 1 = whenever a part has the plan, 2 = never
     int64_t lds_min_reuse_x100 = 150;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product
     int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
-    int64_t lds_waves = 8;              // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
+    int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
+    int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
 
@@ -125,7 +126,7 @@ struct Part {
     // LDS-staged product (lds_plan.hpp): token streams and tile table on the device; lds_tiles == nullptr: no such plan
     uint32_t *lds_tok = nullptr, *lds_nb = nullptr, *lds_chunks = nullptr, *lds_rowmap = nullptr;
     LdsTile *lds_tiles = nullptr;
-    uint32_t lds_ntiles = 0, lds_nw = 8;
+    uint32_t lds_ntiles = 0, lds_nw = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
     uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
@@ -683,18 +684,19 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.nslices = nslices;
     a.ntiles = p.lds_ntiles;
     a.accumulate = accumulate ? 1 : 0;
+    a.wdelta = p.lds_wdelta;
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);
     KernelFn fn = nullptr;
     if constexpr (std::is_same<T, float>::value) {
-        fn = p.lds_nw == 16 ? k_lds_spmm_f32_w16 : k_lds_spmm_f32_w8;
+        fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_f32_w16_val : k_lds_spmm_f32_w16) : k_lds_spmm_f32_w8;
         if (p.lds_nw == 8 && g_tune.lds_ablate == 1) fn = k_lds_spmm_f32_w8_ab1;
         if (p.lds_nw == 8 && g_tune.lds_ablate == 2) fn = k_lds_spmm_f32_w8_ab2;
         if (p.lds_nw == 8 && g_tune.lds_ablate == 3) fn = k_lds_spmm_f32_w8_ab3;
         if (p.lds_nw == 8 && g_tune.lds_ablate == 4) fn = k_lds_spmm_f32_w8_ab4;
     } else {
-        fn = p.lds_nw == 16 ? k_lds_spmm_i32_w16 : k_lds_spmm_i32_w8;
+        fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }
     {
         static std::set<KernelFn> attr_done;
@@ -712,7 +714,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
 
 template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc) {
     if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return false;
-    if (!p.lds_tiles || g_tune.lds_mode == 2 || p.vals || g->deq_out || g->pre_xs) return false;
+    if (!p.lds_tiles || g_tune.lds_mode == 2 || (p.vals != nullptr) != (p.lds_wdelta != 0) || g->deq_out || g->pre_xs) return false;
+    if (g_tune.lds_mode == 0 && (g_tune.panel_mode == 1 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0)) return false;  // another kernel was asked for by name
     if ((int64_t)w < g_tune.lds_min_width) return false;
     if ((uint64_t)ldc * sizeof(T) >= (1ull << 32)) return false;
     return true;
@@ -937,7 +940,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // One-time plans of a part (needs its row pointers on the host): the long-row segment plans and the
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
-int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr);
+int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint);
 
 int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
@@ -1087,19 +1090,23 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
             }
         }
     }
-    return build_lds_plan(p, es, d_flag_sorted, st, h_rowptr);
+    return build_lds_plan(p, es, d_flag_sorted, st, h_rowptr, h_hint);
 }
 
 // One-time: the schedule of the LDS-staged product (lds_plan.hpp) for parts it pays for.  Built on the host from
 // the row pointers and column ids (the reference balances its DPU row ranges on the host too, spmm_mul_csr.c:118-259).
-int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr) {
-    if (g_tune.lds_mode == 2 || es != 4 || p.vals || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
+int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint) {
+    if (g_tune.lds_mode == 2 || es != 4 || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
+    if (p.vals && g_tune.lds_waves != 16) return 0;  // the valued kernels exist for the 16-wave geometry
     if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
     LdsGeometry geo;
     geo.NW = g_tune.lds_waves == 16 ? 16 : 8;
     geo.KA = lds_ka(geo.NW);
     geo.KC = LDS_KC;
     geo.BATCH = lds_batch(geo.NW);
+    // tiles sized so that one product of the group's width runs as whole rounds of workgroups (lds_plan.hpp)
+    if (g_tune.lds_round_tiles && h_hint > 0)
+        geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint + 63) / 64), (uint32_t)std::max(g_ctx.cu_count, 1));
     if (g_tune.lds_mode == 0 &&
         lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
         return 0;
@@ -1111,9 +1118,23 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     if (unsorted) return 0;  // stored order inside a row must be column order for the chunk walk
     std::vector<uint32_t> h_col((size_t)p.nnz);
     if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
+    std::vector<uint32_t> h_val;
+    if (p.vals) {
+        h_val.resize((size_t)p.nnz);
+        if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+    }
     LdsPlanHost plan;
-    lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+    lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
+                   p.vals ? h_val.data() : nullptr);
     std::vector<uint32_t>().swap(h_col);
+    std::vector<uint32_t>().swap(h_val);
+    if (p.vals) {
+        // one buffer: the token stream, then the value stream at the same positions (the kernel adds a 32-bit byte offset)
+        if ((uint64_t)plan.tok.size() * 8 >= (1ull << 32)) return 0;
+        p.lds_wdelta = (uint32_t)(plan.tok.size() * 4);
+        plan.tok.insert(plan.tok.end(), plan.wts.begin(), plan.wts.end());
+        std::vector<uint32_t>().swap(plan.wts);
+    }
     auto up = [&](auto **dst, const auto &v) {
         using E = typename std::remove_reference<decltype(v[0])>::type;
         const size_t bytes = std::max<size_t>(v.size() * sizeof(E), 64);
@@ -1763,6 +1784,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_threads") slot = &g_tune.lds_threads;
     else if (n == "lds_waves") slot = &g_tune.lds_waves;
     else if (n == "lds_ablate") slot = &g_tune.lds_ablate;
+    else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

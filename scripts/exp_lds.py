@@ -71,11 +71,15 @@ def small(nrows, ncols, h, dtype, avg=12, seed=0, long_row=0):
 
 
 ok = True
-for dt in (torch.float32, torch.int32):
+for waves in (8, 16):
+  _lib.set_tunable("lds_waves", waves)
+  print(f"--- {waves} waves per workgroup", flush=True)
+  for dt in (torch.float32, torch.int32):
     ok &= small(300, 700, 64, dt)
     ok &= small(3000, 2500, 100, dt, long_row=3000)
     ok &= small(1700, 5000, 256, dt, seed=3)
     ok &= small(20000, 20000, 130, dt, avg=40, seed=5)
+    ok &= small(6000, 300, 64, dt, avg=300, seed=7)     # few chunks, long slots (the in-loop touches)
 print("small cases:", "all bit-exact" if ok else "MISMATCHES", flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "quick":

@@ -38,8 +38,8 @@ class Geo:
     VGPRs: temporaries v[T0..T0+7], two x / address sets of BATCH registers from X0, accumulators v[ACC0..ACC0+KA] (the last
     one is the dummy that padding tokens add into).  SGPRs: three token sets from TOK0, control registers from CTL0."""
 
-    def __init__(self, NW, KA, BATCH, T0):
-        self.NW, self.KA, self.BATCH, self.T0 = NW, KA, BATCH, T0
+    def __init__(self, NW, KA, BATCH, T0, weighted=False):
+        self.NW, self.KA, self.BATCH, self.T0, self.weighted = NW, KA, BATCH, T0, weighted
         self.X0 = T0 + 8
         self.ACC0 = self.X0 + 2 * BATCH
         self.vmax = 512 // (NW // 4)          # VGPRs per lane at NW / 4 waves per SIMD
@@ -47,30 +47,33 @@ class Geo:
         self.pieces = 64 // NW                # 1 KiB DMA pieces of a 64 KiB chunk per wave
         self.threads = NW * 64
         self.CTL0 = 84                        # control registers s84..s101; token sets below them (s32 is reserved: start at s36)
-        self.TOK0 = self.CTL0 - 3 * BATCH
+        self.TOK0 = self.CTL0 - (6 if weighted else 3) * BATCH   # weighted: three more sets for the entries' values
         assert self.TOK0 % 4 == 0 and self.TOK0 >= 36
 
 
 GEOS = {8: Geo(8, 192, 16, 16), 16: Geo(16, 96, 8, 4)}
+GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 
 
-def body(op_add, g, ablate=0):
+def body(op_add, g, ablate=0, op_mul=None):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
     3 = no address computation and no LDS reads, 4 = no accumulation"""
     KA, BATCH, NW, ACC0 = g.KA, g.BATCH, g.NW, g.ACC0
     VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = (f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
     XS = [g.X0, g.X0 + BATCH]
     TOK = [g.TOK0 + i * BATCH for i in range(3)]
+    WGT = [g.TOK0 + (3 + i) * BATCH for i in range(3)] if g.weighted else None
+    assert bool(op_mul) == bool(g.weighted)
     c = g.CTL0
     # control SGPRs
     NBL, NLEFT, CIDN, TMP = (f"s{c + i}" for i in range(4))              # batches left, slots left, next chunk id, temporary
     PA_LO, PA_HI, PA = f"s{c + 4}", f"s{c + 5}", f"s[{c + 4}:{c + 5}]"   # 64-bit temporary (touch / DMA source address); even
     DLDS, BUF = f"s{c + 6}", f"s{c + 7}"                                   # DMA LDS base (also a temporary), buffer select (0 / 0x10000)
     TMP2 = DLDS
-    TP_LO, TP_HI, TP = f"s{c + 8}", f"s{c + 9}", f"s[{c + 8}:{c + 9}]"      # token pointer (address of the newest loaded batch)
+    TP_LO, TP_HI, TP = f"s{c + 8}", f"s{c + 9}", f"s[{c + 8}:{c + 9}]"      # token stream of this wave (fixed)
     NP_LO, NP_HI, NP = f"s{c + 10}", f"s{c + 11}", f"s[{c + 10}:{c + 11}]"  # batch-count pointer (this slot's entry)
     CP_LO, CP_HI, CP = f"s{c + 12}", f"s{c + 13}", f"s[{c + 12}:{c + 13}]"  # chunk-id pointer (this slot's entry)
-    NBN, NBN2, CIDN2, ROT = (f"s{c + 14 + i}" for i in range(4))           # batches of slot+1 / +2, chunk id of slot+2, token-set rotation
+    NBN, NBN2, TOFF, ROT = (f"s{c + 14 + i}" for i in range(4))            # batches of slot+1 / +2, token offset (newest loaded batch), token-set rotation
     assert c + 17 <= 101 and c % 2 == 0
     # result stage (aliases of loop registers)
     KREG, ROWID, EX_LO = NBL, NLEFT, c + 2
@@ -92,14 +95,19 @@ def body(op_add, g, ablate=0):
     a(f"s_mov_b32 {NLEFT}, %[nch]")
     a(f"s_mov_b32 {BUF}, 0")
     a(f"s_mov_b32 {ROT}, 0")
+    a(f"s_mov_b32 {TOFF}, 0")
     a(f"s_cmp_eq_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_out_%=")
     a(f"s_load_dword {CIDN}, {CP}, 0x0")                 # chunk id of slot 0
-    a(f"s_load_dword {CIDN2}, {CP}, 0x4")                # chunk id of slot 1
     a(f"s_load_dword {NBL}, {NP}, 0x0")                  # batches of slot 0
     a(f"s_load_dword {NBN}, {NP}, {hex(NW * 4)}")        # batches of slot 1
     a(f"{tokload} s[{TOK[0]}:{TOK[0] + BATCH - 1}], {TP}, 0x0")
+    if g.weighted:
+        a(f"s_mov_b32 {TMP}, %[wdelta]")
+        a(f"{tokload} s[{WGT[0]}:{WGT[0] + BATCH - 1}], {TP}, {TMP}")
     a("s_waitcnt lgkmcnt(0)")
+
+    next_id = [0]
 
     def dma(cid, bufsel_reg):
         # this wave's 1 KiB pieces of the 64 KiB chunk `cid` -> LDS buffer `bufsel`
@@ -117,29 +125,28 @@ def body(op_add, g, ablate=0):
                 a(f"s_add_u32 {DLDS}, {DLDS}, 0x400")
 
     dma(CIDN, BUF)
-    a("s_waitcnt vmcnt(0)")
+    a(f"s_load_dword {CIDN}, {CP}, 0x4")                 # CIDN = chunk id of the NEXT slot from here on
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a("s_barrier")
-    a(f"s_mov_b32 {CIDN}, {CIDN2}")               # CIDN = chunk id of the NEXT slot from here on
     # ---- slot loop
     a("L_slot_%=:")
-    # Touch (one vector load, result unused) the lines of the NEXT slot's tokens so that the scalar loads of the batch loop hit the
-    # XCD's L2.  Lane l touches line l of the range; 63 lines per load, as many loads as the range needs.  Issued BEFORE the chunk
-    # DMA, so the slot's closing vmcnt(0) never waits for a young touch.  TP = this slot's first batch.
+    # Touch (one vector load, result unused) the first lines of the NEXT slot's tokens so that the scalar loads of the batch loop hit
+    # the XCD's L2: lane l touches line l, at most 17 lines (2 KiB); longer slots touch 2 KiB ahead batch by batch (below).  Issued
+    # BEFORE the chunk DMA, so the slot's closing vmcnt(0) never waits for a young touch.  TP + TOFF = this slot's first batch.
     a(f"s_mul_i32 {TMP}, {NBL}, {BATCH * 4}")
+    a(f"s_add_u32 {TMP}, {TMP}, {TOFF}")
     a(f"s_add_u32 {PA_LO}, {TP_LO}, {TMP}")
     a(f"s_addc_u32 {PA_HI}, {TP_HI}, 0")
     a(f"s_mul_i32 {TMP}, {NBN}, {BATCH * 4}")
     a(f"s_add_u32 {TMP}, {TMP}, 0xff")
     a(f"s_lshr_b32 {TMP}, {TMP}, 7")              # lines of the next slot's tokens, + 1
-    a("L_touch_%=:")
-    a(f"s_min_u32 {TMP2}, {TMP}, 63")
-    a(f"s_bfm_b64 exec, {TMP2}, 0")
+    a(f"s_min_u32 {TMP}, {TMP}, 17")
+    a(f"s_bfm_b64 exec, {TMP}, 0")
     a(f"global_load_dword {VT1}, {VL128}, {PA}")
-    a(f"s_add_u32 {PA_LO}, {PA_LO}, 0x1f80")
-    a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
-    a(f"s_sub_u32 {TMP}, {TMP}, {TMP2}")
-    a(f"s_cmp_gt_u32 {TMP}, 0")
-    a("s_cbranch_scc1 L_touch_%=")
+    if g.weighted:   # the same lines of the value stream (it sits wdelta bytes behind the tokens)
+        a(f"s_add_u32 {PA_LO}, {PA_LO}, %[wdelta]")
+        a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
+        a(f"global_load_dword {VT1}, {VL128}, {PA}")
     a("s_mov_b64 exec, -1")
     # ... and the lines of the batch counts / chunk ids a few slots on (all lanes one address = one request each)
     a(f"global_load_dword {VT1}, {VZ}, {NP} offset:{NW * 4 * 8}")
@@ -149,11 +156,12 @@ def body(op_add, g, ablate=0):
     a(f"s_xor_b32 {TMP2}, {BUF}, 0x10000")
     dma(CIDN, TMP2)
     a("L_nodma_%=:")
-    a(f"s_load_dword {CIDN2}, {CP}, 0x8")                # chunk id of slot j + 2 (the list is padded by two)
+    a(f"s_load_dword {CIDN}, {CP}, 0x8")                 # chunk id of slot j + 2 (the list is padded by two): the DMA above has read CIDN
     a(f"s_load_dword {NBN2}, {NP}, {hex(NW * 8)}")       # batches of slot j + 2 (two closing rows of zeros)
     a(f"v_add_u32 {VB}, {BUF}, {VL4}")
     a(f"s_cmp_eq_u32 {NBL}, 0")
     a("s_cbranch_scc1 L_slotend_%=")
+    a(f"s_sub_u32 {NBL}, {NBL}, 1")               # batches left after the one in hand
     a(f"s_cmp_eq_u32 {ROT}, 0")
     a("s_cbranch_scc1 L_E0_%=")
     a(f"s_cmp_eq_u32 {ROT}, 1")
@@ -161,9 +169,22 @@ def body(op_add, g, ablate=0):
     a("s_branch L_E2_%=")
 
     def load_next(r):
-        a(f"s_add_u32 {TP_LO}, {TP_LO}, {hex(BATCH * 4)}")
-        a(f"s_addc_u32 {TP_HI}, {TP_HI}, 0")
-        a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, 0x0")
+        a(f"s_add_u32 {TOFF}, {TOFF}, {hex(BATCH * 4)}")
+        a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, {TOFF}")
+        if g.weighted:
+            a(f"s_add_u32 {TMP}, {TOFF}, %[wdelta]")
+            a(f"{tokload} s[{WGT[r]}:{WGT[r] + BATCH - 1}], {TP}, {TMP}")
+        # long slots: the line 2 KiB ahead (all lanes one address = one request), except in the slot's last batches
+        # (a touch issued there would still be in flight at the slot's closing vmcnt(0))
+        a(f"s_cmp_gt_u32 {NBL}, {max(4, 128 // BATCH)}")
+        a(f"s_cbranch_scc0 L_nt{next_id[0]}_%=")
+        a(f"v_mov_b32 {VT0}, {TOFF}")
+        a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
+        if g.weighted:
+            a(f"v_add_u32 {VT0}, %[wdelta], {VT0}")
+            a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
+        a(f"L_nt{next_id[0]}_%=:")
+        next_id[0] += 1
 
     def reads(r, x):
         if ablate != 3:
@@ -176,6 +197,9 @@ def body(op_add, g, ablate=0):
     def adds(r, x):
         if ablate == 4:
             return
+        if g.weighted:   # product and sum round separately, as in the CPU loop (no FMA)
+            for i in range(BATCH):
+                a(f"{op_mul} v{XS[x] + i}, s{WGT[r] + i}, v{XS[x] + i}")
         a(f"s_set_gpr_idx_on s{TOK[r]}, gpr_idx(SRC1,DST)")
         a(f"{op_add} v{ACC0}, v{XS[x]}, v{ACC0}")
         for i in range(1, BATCH):
@@ -185,8 +209,7 @@ def body(op_add, g, ablate=0):
         a("s_set_gpr_idx_off")
 
     def count_and_exit(r_next, x_next):
-        a(f"s_sub_u32 {NBL}, {NBL}, 1")
-        a(f"s_cmp_eq_u32 {NBL}, 0")
+        a(f"s_sub_u32 {NBL}, {NBL}, 1")               # SCC = borrow: no batch was left
         a(f"s_cbranch_scc1 L_D{r_next}{x_next}_%=")
 
     # entries: tokens of the slot's first batch sit in set r
@@ -217,12 +240,11 @@ def body(op_add, g, ablate=0):
             a(f"s_mov_b32 {ROT}, {(r + 1) % 3}")
             a("s_branch L_slotend_%=")
     a("L_slotend_%=:")
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # my pieces of the next chunk have landed; NBN2 / CIDN2 are in
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # my pieces of the next chunk have landed; NBN2 / CIDN are in
     a("s_barrier")                               # ... and everybody is done reading the current one
     a(f"s_xor_b32 {BUF}, {BUF}, 0x10000")
     a(f"s_mov_b32 {NBL}, {NBN}")
     a(f"s_mov_b32 {NBN}, {NBN2}")
-    a(f"s_mov_b32 {CIDN}, {CIDN2}")
     a(f"s_add_u32 {CP_LO}, {CP_LO}, 4")
     a(f"s_addc_u32 {CP_HI}, {CP_HI}, 0")
     a(f"s_add_u32 {NP_LO}, {NP_LO}, {hex(NW * 4)}")
@@ -291,6 +313,7 @@ struct LdsArgs {
     char *c;                  // row-major result
     uint64_t slice_stride;    // bytes between two slices of xs
     uint32_t ldc_bytes, w, nslices, ntiles, accumulate, xcd_group;
+    uint32_t wdelta;          // weighted kernels: bytes from a token to its value (the value stream follows the token stream)
 };
 """
 
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
         :
         : [lane] "v"(lane), [tok] "s"(tok_s), [nb] "s"(nb_s), [chunks] "s"(ch_s), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
-          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw)
+          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta)
         : %(clobbers)s, "vcc", "scc", "memory");
 }
 """
@@ -349,10 +372,14 @@ def main():
         variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
     for ab in (1, 2, 3, 4):
         variants.append((f"k_lds_spmm_f32_w8_ab{ab}", "v_add_f32", 8, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
-    for name, op, nw, ab, doc in variants:
-        g = GEOS[nw]
+    variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
+    variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
+    for v in variants:
+        name, op, nw, ab, doc = v[:5]
+        op_mul = v[5] if len(v) > 5 else None
+        g = GEO_W16 if op_mul else GEOS[nw]
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab))
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul))
         text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,
                               piece=g.pieces * 1024)
     text += "\n}  // namespace pygim\n"

@@ -9,13 +9,15 @@ using namespace pygim;
 
 template <typename T>
 static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
+                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const T *vals) {
     LdsGeometry geo;
     geo.NW = nw;
     geo.KA = KA;
     geo.BATCH = batch;
     LdsPlanHost plan;
-    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads);
+    static_assert(sizeof(T) == 4, "4-byte values");
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
+    if ((vals != nullptr) != !plan.wts.empty() || (vals && plan.wts.size() != plan.tok.size())) return 9;
     const uint32_t NW = geo.NW, KC = geo.KC;
     const uint32_t nslices = (h + 63) / 64;
     if (stats) {
@@ -43,11 +45,22 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
                         if (k > KA) return 4;
                         const uint64_t xr = (uint64_t)chunk * KC + c;
                         if (k < KA && xr >= ncols) return 5;
+                        T wv = T(1);
+                        if (vals) std::memcpy(&wv, &plan.wts[at], 4);
+                        if (vals && k == KA && plan.wts[at] != 0) return 10;  // padding carries the value 0
                         for (uint32_t l = 0; l < wvalid; l++) {
-                            const T x = xr < ncols ? X[xr * h + s * 64 + l] : T(0);
+                            T x = xr < ncols ? X[xr * h + s * 64 + l] : T(0);
                             T &a = acc[(size_t)k * 64 + l];
-                            if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)x);
-                            else a = a + x;
+                            if constexpr (std::is_integral<T>::value) {
+                                if (vals) x = (T)((uint32_t)wv * (uint32_t)x);
+                                a = (T)((uint32_t)a + (uint32_t)x);
+                            } else {
+                                if (vals) {
+                                    volatile T prod = wv * x;  // product and sum round separately (no FMA), as the kernel and the oracle do
+                                    x = prod;
+                                }
+                                a = a + x;
+                            }
                         }
                     }
                 }
@@ -69,11 +82,11 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
 
 extern "C" {
 int lds_emul_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
-    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const float *vals) {
+    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals);
 }
 int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw) {
-    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const int32_t *vals) {
+    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals);
 }
 }

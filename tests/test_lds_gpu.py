@@ -1,0 +1,211 @@
+"""GPU parity of the LDS-staged product (k_lds_spmm_*: X chunks in LDS, a tile's running sums in registers, the
+reference's scratchpad loop spmm_default/dpu_kernels/spmm_mul_csr_dpu.c:108-126) against the CPU oracle, through the C ABI.
+
+Every row is summed by one wave in stored order, so FLOAT results must equal the oracle's sequential loop bit for bit
+(BASELINE.json asks for 1e-5 relative; this path gives 0), integers are two's-complement modular.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import coalesce, random_csr
+from pygim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+CODE = {np.dtype(np.float32): _lib.FLT32, np.dtype(np.int32): _lib.INT32}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def backend():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.init_ranks(1)
+    yield
+    _lib.release()
+
+
+@pytest.fixture()
+def lds_forced():
+    old = _lib.set_tunable("lds_mode", 1)
+    yield
+    _lib.set_tunable("lds_mode", old)
+    _lib.set_tunable("lds_waves", 16)
+
+
+def features(rng, n, h, dt):
+    if dt == np.float32:
+        return (rng.random((n, h), dtype=np.float32) * 2 - 1).astype(np.float32)   # sums round at every step
+    return rng.integers(-2**31, 2**31 - 1, size=(n, h), dtype=np.int64).astype(np.int32)  # sums wrap
+
+
+def product(rowptr, col, x, ncols=None, fmt="CSR", row=None, vals=None, want_plan=True):
+    n = len(rowptr) - 1
+    ncols = x.shape[0] if ncols is None else ncols
+    h = x.shape[1]
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    idx0 = rp if fmt == "CSR" else np.ascontiguousarray(row, np.int32)
+    v = None if vals is None else [np.ascontiguousarray(vals, x.dtype).ctypes.data]
+    hd = _lib.group_create(_lib.CSR if fmt == "CSR" else _lib.COO, CODE[x.dtype], [idx0.ctypes.data], [ci.ctypes.data], v,
+                           [n], [ncols], [len(ci)], [1], [h], h)
+    try:
+        plan = _lib.group_lds_plan(hd)
+        if want_plan is not None:
+            assert (plan["tiles"] > 0) == want_plan, plan
+        out = np.full((n, h), 77, dtype=x.dtype)
+        xx = np.ascontiguousarray(x)
+        _lib.spmm_run_group(hd, [xx.ctypes.data], out.ctypes.data)
+    finally:
+        _lib.group_free(hd)
+    return out, plan
+
+
+@pytest.mark.parametrize("waves", [16, 8])
+@pytest.mark.parametrize("dt", [np.float32, np.int32])
+def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
+    _lib.set_tunable("lds_waves", waves)
+    # (rows, cols, h, mean degree): widths around the 64-feature slice, ragged tiles, one and many chunks, a 5 000-entry row
+    for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),
+                             (4000, 4000, 33, 30), (2000, 9000, 300, 25)):
+        rowptr, col = random_csr(rng, n, ncols, avg, long_rows=[(0, 5000)] if n > 100 else ())
+        x = features(rng, ncols, h, dt)
+        want = oracle.spmm_csr(rowptr, col, None, x)
+        got, plan = product(rowptr, col, x)
+        assert got.tobytes() == want.tobytes(), (waves, dt, n, ncols, h)
+        assert plan["nnz"] == len(col) and plan["tokens"] >= len(col)
+
+
+def test_empty_rows_and_empty_matrix(rng, lds_forced):
+    rowptr, col = random_csr(rng, 2000, 1500, 9, empty_frac=0.6)
+    x = features(rng, 1500, 128, np.float32)
+    got, _ = product(rowptr, col, x)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes()
+    z = np.zeros(51, dtype=np.int64)
+    got, plan = product(z, np.zeros(0, dtype=np.int64), features(rng, 9, 64, np.float32), want_plan=False)  # nothing stored: no plan
+    assert not got.any()
+
+
+def test_accumulate_strides_and_device_pointers(rng, lds_forced):
+    """pygim_block_run: C += A.X into a wider matrix (ldc > width), X a window of a wider matrix (ldx > width)"""
+    n, ncols, w = 3000, 2000, 96
+    rowptr, col = random_csr(rng, n, ncols, 20)
+    rp, ci = torch.from_numpy(rowptr.astype(np.int32)).cuda(), torch.from_numpy(col.astype(np.int32)).cuda()
+    for dt, code in ((np.float32, _lib.FLT32), (np.int32, _lib.INT32)):
+        xw = features(rng, ncols, w + 40, dt)
+        c0 = features(rng, n, w + 24, dt)
+        hd = _lib.group_create(_lib.CSR, code, [rp.data_ptr()], [ci.data_ptr()], None, [n], [ncols], [len(col)], [1], [w], w)
+        try:
+            assert _lib.group_lds_plan(hd)["tiles"] > 0
+            xd, cd = torch.from_numpy(xw).cuda(), torch.from_numpy(c0).cuda()
+            es = xd.element_size()
+            _lib.block_run(hd, 0, xd.data_ptr() + 8 * es, w + 40, cd.data_ptr() + 16 * es, w + 24, w, accumulate=True)
+            torch.cuda.synchronize()
+            got = cd.cpu().numpy()
+        finally:
+            _lib.group_free(hd)
+        prod = oracle.spmm_csr(rowptr, col, None, np.ascontiguousarray(xw[:, 8:8 + w]))
+        want = c0.copy()
+        if dt == np.float32:
+            want[:, 16:16 + w] = c0[:, 16:16 + w] + prod     # the kernel adds its finished sum to what C held
+        else:
+            want[:, 16:16 + w] = (c0[:, 16:16 + w].astype(np.int64) + prod).astype(np.int32)
+        assert got.tobytes() == want.tobytes(), dt
+
+
+def test_coo_groups_and_merged_column_blocks(rng, lds_forced):
+    """COO through the derived row pointers (unit weights), and sp_parts column blocks merged into one matrix"""
+    n, ncols, h = 2500, 3000, 128
+    rowptr, col = random_csr(rng, n, ncols, 15)
+    r, c, v = coalesce(rowptr, col, np.float32)
+    keep = np.ones(len(c), dtype=bool)  # a simple graph: all weights 1 after dropping duplicates
+    rp2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp2, r.astype(np.int64) + 1, 1)
+    rp2 = np.cumsum(rp2)
+    x = features(rng, ncols, h, np.float32)
+    want = oracle.spmm_csr(rp2, c, None, x)
+    got, _ = product(rp2, c, x, fmt="COO", row=r, vals=np.ones(len(c), np.float32))
+    assert got.tobytes() == want.tobytes() and keep.all()
+    # three column blocks with local ids (backend_pim/spmm.py:127-136): the group's merged matrix carries the plan
+    import scipy.sparse as sp
+    a = sp.csr_matrix((np.ones(len(c), np.float32), c.copy(), rp2.copy()), shape=(n, ncols))
+    step = (ncols + 2) // 3
+    blocks = [a[:, i * step:min(ncols, (i + 1) * step)].tocsr() for i in range(3)]
+    for b in blocks:
+        b.sort_indices()
+    rps = [np.ascontiguousarray(b.indptr, np.int32) for b in blocks]
+    cis = [np.ascontiguousarray(b.indices, np.int32) for b in blocks]
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [p.ctypes.data for p in rps], [q.ctypes.data for q in cis], None, [n] * 3,
+                           [b.shape[1] for b in blocks], [b.nnz for b in blocks], [1] * 3, [h] * 3, h)
+    try:
+        assert _lib.group_lds_plan(hd)["tiles"] > 0 and _lib.group_plan(hd)["merged"] == 1
+        out = np.empty((n, h), np.float32)
+        _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+    finally:
+        _lib.group_free(hd)
+    assert out.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.int32])
+def test_valued_entries_are_bit_exact(rng, lds_forced, dt):
+    """acc += val * x in stored order, product and sum rounded separately (the valued device loop spmm_mul_csr_dpu.c:113;
+    the oracle's spmm_grande/spmm_mul_csr.c:119-136): equal to the CPU loop bit for bit, floats too"""
+    for n, ncols, h in ((3000, 2500, 100), (1700, 5000, 256), (20000, 20000, 64)):
+        rowptr, col = random_csr(rng, n, ncols, 25, long_rows=[(1, 4000)])
+        x = features(rng, ncols, h, dt)
+        vals = features(rng, len(col), 1, dt)[:, 0]
+        got, plan = product(rowptr, col, x, vals=vals)
+        assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (dt, n, h)
+    _lib.set_tunable("lds_waves", 8)   # no valued kernel in the 8-wave geometry: the sweep answers (floats within the bound)
+    got, plan = product(rowptr, col, x, vals=vals, want_plan=False)
+    want = oracle.spmm_csr(rowptr, col, vals, x)
+    assert np.array_equal(got, want) if dt == np.int32 else np.allclose(got, want, rtol=0, atol=1e-3)
+
+
+def test_auto_rule_and_unsorted_rows_keep_the_sweep(rng):
+    """lds_mode = 0 (default): planned only where a staged column of X serves enough stored entries; rows whose stored order
+    is not column order never take it (and still give the oracle's result)"""
+    assert _lib.set_tunable("lds_mode", 0) == 0
+    xd = features(rng, 1000, 64, np.float32)
+    rowptr, col = random_csr(rng, 4000, 1000, 200)         # ~2.9 stored entries per staged column of X and tile: planned
+    got, plan = product(rowptr, col, xd, want_plan=True)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xd).tobytes()
+    x = features(rng, 3000, 64, np.float32)
+    rowptr, col = random_csr(rng, 3000, 3000, 0.5)         # ~0.2: not worth staging
+    got, plan = product(rowptr, col, x, want_plan=False)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes()
+    rowptr, col = random_csr(rng, 3000, 3000, 20)
+    col2 = col.copy()
+    s, e = rowptr[5], rowptr[6]
+    if e - s > 1:
+        col2[s:e] = col2[s:e][::-1]                         # one row stored in descending column order
+    got, plan = product(rowptr, col2, x, want_plan=False)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col2, None, x).tobytes()
+
+
+def test_same_features_reuse_the_slice_major_copy(rng, lds_forced):
+    n, h = 3000, 128
+    rowptr, col = random_csr(rng, n, n, 12)
+    rp, ci = torch.from_numpy(rowptr.astype(np.int32)).cuda(), torch.from_numpy(col.astype(np.int32)).cuda()
+    x = torch.from_numpy(features(rng, n, h, np.float32)).cuda()
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rp.data_ptr()], [ci.data_ptr()], None, [n], [n], [len(col)], [1], [h], h)
+    try:
+        a, b = torch.empty((n, h), device="cuda"), torch.empty((n, h), device="cuda")
+        _lib.spmm_run_group(hd, [x.data_ptr()], a.data_ptr())
+        _lib.spmm_run_group(hd, [x.data_ptr()], b.data_ptr(), x_unchanged=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.group_free(hd)
+    assert torch.equal(a, b) and a.cpu().numpy().tobytes() == oracle.spmm_csr(rowptr, col, None, x.cpu().numpy()).tobytes()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes(seed, lds_forced):
+    rng = np.random.default_rng(1000 + seed)
+    _lib.set_tunable("lds_waves", int(rng.choice([8, 16])))
+    dt = [np.float32, np.int32][seed % 2]
+    n, ncols = int(rng.integers(1, 6000)), int(rng.integers(1, 6000))
+    h = int(rng.integers(33, 320))
+    rowptr, col = random_csr(rng, n, ncols, float(rng.uniform(0.5, 60)), empty_frac=float(rng.uniform(0, 0.5)),
+                             long_rows=[(int(rng.integers(0, n)), int(rng.integers(1, 20000)))])
+    x = features(rng, ncols, h, dt)
+    got, _ = product(rowptr, col, x, want_plan=None)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (seed, n, ncols, h)

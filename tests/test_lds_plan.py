@@ -22,11 +22,11 @@ _SO = os.path.join(ROOT, "tests", "native", "liblds_emul.so")
 def emul():
     deps = [_SRC, os.path.join(ROOT, "pygim_amd", "csrc", "lds_plan.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", _SRC, "-o", _SO])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-pthread", _SRC, "-o", _SO])
     return ctypes.CDLL(_SO)
 
 
-def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8):
+def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8, vals=None):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -35,7 +35,8 @@ def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8):
     rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
     xx = np.ascontiguousarray(x)
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols,
-            xx.ctypes.data_as(ctypes.c_void_p), h, out.ctypes.data_as(ctypes.c_void_p), ka, batch, threads, stats, nw)
+            xx.ctypes.data_as(ctypes.c_void_p), h, out.ctypes.data_as(ctypes.c_void_p), ka, batch, threads, stats, nw,
+            None if vals is None else np.ascontiguousarray(vals, x.dtype).ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, f"emulator rejected the plan (code {rc})"
     return out, list(stats)
 
@@ -55,6 +56,23 @@ def test_plan_walk_equals_oracle(emul, dtype, shape):
         got, stats = _run(emul, rowptr, col, ncols, x, ka=ka, batch=batch, nw=nw)
         assert got.tobytes() == want.tobytes()           # bit-exact, floats included (stored-order sums)
         assert stats[2] % batch == 0 and stats[3] == stats[2] + 4096 + 64   # slack the kernel may read past the last token
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_valued_entries_ride_with_their_tokens(emul, dtype):
+    # a valued matrix: the plan carries each entry's value at its token's position (0 under padding); acc += val * x in stored order
+    rng = np.random.default_rng(21)
+    nrows, ncols, h = 2000, 1500, 96
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=14, long_rows=[(3, 2500)])
+    if dtype == np.float32:
+        x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+        vals = (rng.random(len(col), dtype=np.float32) * 2 - 1).astype(np.float32)
+    else:
+        x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+        vals = rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64).astype(np.int32)
+    want = oracle.spmm_csr(rowptr, col, vals, x)
+    got, _ = _run(emul, rowptr, col, ncols, x, ka=96, batch=8, nw=16, vals=vals)
+    assert got.tobytes() == want.tobytes()
 
 
 def test_small_geometry_many_tiles_and_ragged_tail(emul):
