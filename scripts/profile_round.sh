@@ -11,7 +11,7 @@ cp gpurun_out/pmc_round/summary.txt $out/pmc_summary.txt 2>/dev/null
 cp gpurun_out/pmc_round/traffic.json $out/traffic.json 2>/dev/null
 cp $out/traffic.json profiles/traffic_latest.json 2>/dev/null
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 > $out/bench_under_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-extra > $out/bench_under_rocprof.log 2>&1
 cd $R
 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400

@@ -74,7 +74,30 @@ class FakeLib:
             return oracle.spmm_csr(part["idx0"], part["col"], part["val"], x)
         return oracle.spmm_coo(part["idx0"], part["col"], part["val"], x, part["nrows"])
 
-    def spmm_run_group(self, handle, b_ptrs, out_ptr, stream=0):
+    def block_run(self, handle, part, x_ptr, ldx, c_ptr, ldc, width, accumulate=False, stream=0, x_unchanged=False):
+        """pygim_block_run: C[:, :width] (+)= A_part . X[:, :width] on strided windows (row strides ldx / ldc in elements)"""
+        g = self.groups[int(handle)]
+        p = g["parts"][int(part)]
+        es = np.dtype(g["dt"]).itemsize
+
+        def window(ptr, rows, ld):
+            if rows == 0:
+                return np.zeros((0, width), dtype=g["dt"])
+            flat = _view(ptr, (rows - 1) * ld + width, g["dt"])
+            return np.lib.stride_tricks.as_strided(flat, shape=(rows, width), strides=(ld * es, es), writeable=True)
+
+        xw = np.ascontiguousarray(window(x_ptr, p["ncols"], int(ldx)))
+        cw = window(c_ptr, p["nrows"], int(ldc))
+        prod = self._product(g, p, xw)
+        if accumulate:
+            cw += prod
+        else:
+            cw[:] = prod
+
+    def group_kernel_events(self, handle, on=True):
+        pass
+
+    def spmm_run_group(self, handle, b_ptrs, out_ptr, stream=0, x_unchanged=False):
         g = self.groups[int(handle)]
         total_cols = sum(p["ncols"] for p in g["parts"])
         widths = g["dense_cols"][: g["n_dense"][0]]

@@ -173,8 +173,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_multi_gpu_layer_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -182,7 +182,7 @@ def test_multi_gpu_layer_over_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=150) for _ in procs]
+    res = [q.get(timeout=280) for _ in procs]
     for p in procs:
         p.join(30)
     assert all(r[1] == "ok" for r in res), res
