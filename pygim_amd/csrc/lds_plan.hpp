@@ -19,8 +19,11 @@
 //     (column inside the chunk) << 8 | accumulator index, so that one stored entry costs the wave
 //     one ds_read_b32 and one indexed v_add.  Every row is summed by one wave in stored order:
 //     float results are bit-identical to the sequential CPU loop.
-//   * every (slot, wave) list is padded to whole batches of BATCH tokens with tokens that add a
-//     row of the chunk into a dummy accumulator.
+//   * every (slot, wave) list is padded to whole batches of BATCH tokens -- at least one batch -- with tokens that add
+//     a row of the chunk into a dummy accumulator.  The first batch of a list is also the slot's HEADER: the upper halves
+//     of its tokens 0, 1, 2 carry the list's batch count, the NEXT slot's batch count and the NEXT slot's chunk id (what
+//     the wave needs to size its loop, its token prefetch and its share of the next chunk's DMA) -- the token stream is
+//     the only array the kernel's scalar unit follows.
 //
 // Pure C++ (no HIP): built here for the device, and by the CPU tests against an emulator.
 #pragma once
@@ -39,7 +42,8 @@ struct LdsTile {            // 96 bytes, read by the kernel with scalar loads
     uint32_t nb_off;        // first entry of its batch counts, [nch + 2][NW] (two closing rows of zeros)
     uint32_t row0;          // first row of the tile
     uint32_t nnz;           // stored entries of the tile
-    uint32_t pad[3];
+    uint32_t chunk0;        // chunk id of slot 0 (the later ones travel in the token stream's slot headers)
+    uint32_t pad[2];
     uint32_t tokstart[16];  // per wave: first batch of its token stream (units of BATCH tokens)
 };
 
@@ -62,6 +66,7 @@ struct LdsPlanHost {
     std::vector<uint32_t> wts;       // valued matrices: the entries' 4-byte values (raw bits) in token order, 0 for padding; else empty
     std::vector<uint32_t> nb, chunks, rowmap;
     std::vector<LdsTile> tiles;      // heaviest tile first (workgroups are dispatched in index order)
+    bool header_overflow = false;    // a batch count or chunk id does not fit a 16-bit header field: the plan cannot be used
 };
 
 // rowptr / col: CSR with sorted column ids inside every row (checked by the caller).
@@ -136,10 +141,11 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             for (uint32_t w = 0; w < NW; w++) {
                 const uint32_t n = cnt[(size_t)c * NW + w];
                 tt.cnt.push_back(n);
-                tt.batches[w] += (n + B - 1) / B;
+                tt.batches[w] += std::max<uint32_t>(1, (n + B - 1) / B);   // at least the header batch
             }
         }
         out.tiles[t].nch = (uint32_t)tt.chunk_ids.size();
+        out.tiles[t].chunk0 = tt.chunk_ids.empty() ? 0 : tt.chunk_ids[0];
         out.tiles[t].row0 = r0;
         out.tiles[t].nnz = rowptr[r1] - rowptr[r0];
     });
@@ -177,11 +183,12 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             uint64_t at = (uint64_t)d.tokstart[w] * B;
             for (uint32_t j = 0; j < nch; j++) {
                 cursor[(size_t)j * NW + w] = at;
-                const uint32_t nbat = (tt.cnt[(size_t)j * NW + w] + B - 1) / B;
+                const uint32_t nbat = std::max<uint32_t>(1, (tt.cnt[(size_t)j * NW + w] + B - 1) / B);
                 out.nb[(size_t)d.nb_off + (size_t)j * NW + w] = nbat;
                 at += (uint64_t)nbat * B;
             }
         }
+        auto batches_of = [&](uint32_t j, uint32_t w) { return j < nch ? std::max<uint32_t>(1, (tt.cnt[(size_t)j * NW + w] + B - 1) / B) : 0u; };
         // rows in accumulator order per wave == any order that visits a wave's rows k = 0, 1, ...: walk k-major
         for (uint32_t k = 0; k < KA; k++)
             for (uint32_t w = 0; w < NW; w++) {
@@ -195,6 +202,18 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
                     if (vals) out.wts[at] = vals[e];
                 }
             }
+        // slot headers: upper halves of tokens 0..2 of every list's first batch
+        for (uint32_t w = 0; w < NW; w++) {
+            uint64_t at = (uint64_t)d.tokstart[w] * B;
+            for (uint32_t j = 0; j < nch; j++) {
+                const uint32_t nbj = batches_of(j, w), nbn = batches_of(j + 1, w), cidn = j + 1 < nch ? tt.chunk_ids[j + 1] : 0;
+                if (nbj > 0xFFFFu || nbn > 0xFFFFu || cidn > 0xFFFFu) out.header_overflow = true;
+                out.tok[at] |= nbj << 16;
+                out.tok[at + 1] |= nbn << 16;
+                out.tok[at + 2] |= cidn << 16;
+                at += (uint64_t)nbj * B;
+            }
+        }
         (void)nr;
     });
     // heaviest tile first

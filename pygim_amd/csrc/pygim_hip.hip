@@ -672,8 +672,6 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     }
     LdsArgs a;
     a.tok = p.lds_tok;
-    a.nb = p.lds_nb;
-    a.chunks = p.lds_chunks;
     a.tiles = p.lds_tiles;
     a.rowmap = p.lds_rowmap;
     a.xs = (const char *)xs_use;
@@ -691,10 +689,16 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     KernelFn fn = nullptr;
     if constexpr (std::is_same<T, float>::value) {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_f32_w16_val : k_lds_spmm_f32_w16) : k_lds_spmm_f32_w8;
-        if (p.lds_nw == 8 && g_tune.lds_ablate == 1) fn = k_lds_spmm_f32_w8_ab1;
-        if (p.lds_nw == 8 && g_tune.lds_ablate == 2) fn = k_lds_spmm_f32_w8_ab2;
-        if (p.lds_nw == 8 && g_tune.lds_ablate == 3) fn = k_lds_spmm_f32_w8_ab3;
-        if (p.lds_nw == 8 && g_tune.lds_ablate == 4) fn = k_lds_spmm_f32_w8_ab4;
+        if (p.lds_nw == 16 && !p.lds_wdelta) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py)
+            switch (g_tune.lds_ablate) {
+                case 6: fn = k_lds_spmm_f32_w16_ab6; break;
+                case 7: fn = k_lds_spmm_f32_w16_ab7; break;
+                case 10: fn = k_lds_spmm_f32_w16_ab10; break;
+                case 11: fn = k_lds_spmm_f32_w16_ab11; break;
+                case 12: fn = k_lds_spmm_f32_w16_ab12; break;
+                default: break;
+            }
+        }
     } else {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }
@@ -1141,8 +1145,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         if (hipMalloc((void **)dst, bytes) != hipSuccess) return false;
         return v.empty() || hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_nb, plan.nb) || !up(&p.lds_chunks, plan.chunks) || !up(&p.lds_rowmap, plan.rowmap) ||
-        !up(&p.lds_tiles, plan.tiles))
+    if (plan.header_overflow) return 0;  // a slot header field would not fit 16 bits (a wave with > 65 535 batches in one chunk)
+    if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles))
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;

@@ -43,7 +43,7 @@ for _ in range(args.reps):
     ts.append(a.elapsed_time(b))
 lp = _lib.group_lds_plan(hd)
 ok = ""
-if args.ablate == 0:
+if args.ablate in (0, 13):
     colcount = torch.bincount(col.long(), minlength=n).double()
     ok = " checksum " + ("OK" if torch.equal(out.double().sum(0), colcount @ x.double()) else "MISMATCH")
 print(f"waves={args.waves} ablate={args.ablate} clustered={args.clustered} mode={args.mode} {args.dtype} h={args.h} {args.tune}: "

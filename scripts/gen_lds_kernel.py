@@ -46,7 +46,7 @@ class Geo:
         assert self.ACC0 + KA + 1 <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
         self.pieces = 64 // NW                # 1 KiB DMA pieces of a 64 KiB chunk per wave
         self.threads = NW * 64
-        self.CTL0 = 84                        # control registers s84..s101; token sets below them (s32 is reserved: start at s36)
+        self.CTL0 = 88                        # control registers s88..s100; token sets below them (s32 is reserved: start at s36)
         self.TOK0 = self.CTL0 - (6 if weighted else 3) * BATCH   # weighted: three more sets for the entries' values
         assert self.TOK0 % 4 == 0 and self.TOK0 >= 36
 
@@ -57,7 +57,10 @@ GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 
 def body(op_add, g, ablate=0, op_mul=None):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
-    3 = no address computation and no LDS reads, 4 = no accumulation"""
+    3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
+    6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
+    # codes 10..12: the bare batch loop (no scalar token loads, barrier, DMA or touches), whole / LDS side only / accumulate side only
+    AB = {0: set(), 10: {5, 6, 7, 8}, 11: {5, 6, 7, 8, 4}, 12: {5, 6, 7, 8, 3}}.get(ablate, {ablate})
     KA, BATCH, NW, ACC0 = g.KA, g.BATCH, g.NW, g.ACC0
     VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = (f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
     XS = [g.X0, g.X0 + BATCH]
@@ -71,16 +74,22 @@ def body(op_add, g, ablate=0, op_mul=None):
     DLDS, BUF = f"s{c + 6}", f"s{c + 7}"                                   # DMA LDS base (also a temporary), buffer select (0 / 0x10000)
     TMP2 = DLDS
     TP_LO, TP_HI, TP = f"s{c + 8}", f"s{c + 9}", f"s[{c + 8}:{c + 9}]"      # token stream of this wave (fixed)
-    NP_LO, NP_HI, NP = f"s{c + 10}", f"s{c + 11}", f"s[{c + 10}:{c + 11}]"  # batch-count pointer (this slot's entry)
-    CP_LO, CP_HI, CP = f"s{c + 12}", f"s{c + 13}", f"s[{c + 12}:{c + 13}]"  # chunk-id pointer (this slot's entry)
-    NBN, NBN2, TOFF, ROT = (f"s{c + 14 + i}" for i in range(4))            # batches of slot+1 / +2, token offset (newest loaded batch), token-set rotation
-    assert c + 17 <= 101 and c % 2 == 0
+    NBN, TOFF, ROT = (f"s{c + 10 + i}" for i in range(3))                  # batches of the next slot, token offset (newest loaded batch), token-set rotation
+    assert c + 12 <= 101 and c % 2 == 0
     # result stage (aliases of loop registers)
     KREG, ROWID, EX_LO = NBL, NLEFT, c + 2
     EX = f"s[{EX_LO}:{EX_LO + 1}]"
+    NP_LO, NP_HI, NP = TP_LO, TP_HI, TP                                    # (the row map is walked with the token pointer's registers)
     tokload = f"s_load_dwordx{BATCH}"
     L = []
     a = L.append
+
+    def header(r):
+        # slot header (lds_plan.hpp): upper halves of tokens 0..2 of the slot's first batch, here in token set r
+        a(f"s_lshr_b32 {NBL}, s{TOK[r]}, 16")         # batches of the slot
+        a(f"s_lshr_b32 {NBN}, s{TOK[r] + 1}, 16")     # batches of the slot after it (token prefetch)
+        a(f"s_lshr_b32 {CIDN}, s{TOK[r] + 2}, 16")    # chunk id of the slot after it (DMA)
+
     # ---- set-up
     a(f"v_lshlrev_b32 {VL4}, 2, %[lane]")
     a(f"v_lshlrev_b32 {VL16}, 4, %[lane]")
@@ -90,22 +99,16 @@ def body(op_add, g, ablate=0, op_mul=None):
     for i in range(KA + 1):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
     a(f"s_mov_b64 {TP}, %[tok]")
-    a(f"s_mov_b64 {NP}, %[nb]")
-    a(f"s_mov_b64 {CP}, %[chunks]")
     a(f"s_mov_b32 {NLEFT}, %[nch]")
     a(f"s_mov_b32 {BUF}, 0")
     a(f"s_mov_b32 {ROT}, 0")
     a(f"s_mov_b32 {TOFF}, 0")
     a(f"s_cmp_eq_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_out_%=")
-    a(f"s_load_dword {CIDN}, {CP}, 0x0")                 # chunk id of slot 0
-    a(f"s_load_dword {NBL}, {NP}, 0x0")                  # batches of slot 0
-    a(f"s_load_dword {NBN}, {NP}, {hex(NW * 4)}")        # batches of slot 1
     a(f"{tokload} s[{TOK[0]}:{TOK[0] + BATCH - 1}], {TP}, 0x0")
     if g.weighted:
         a(f"s_mov_b32 {TMP}, %[wdelta]")
         a(f"{tokload} s[{WGT[0]}:{WGT[0] + BATCH - 1}], {TP}, {TMP}")
-    a("s_waitcnt lgkmcnt(0)")
 
     next_id = [0]
 
@@ -115,53 +118,52 @@ def body(op_add, g, ablate=0, op_mul=None):
         a(f"s_add_u32 {PA_LO}, %[xs_lo], {TMP}")
         a(f"s_addc_u32 {PA_HI}, %[xs_hi], 0")
         a(f"s_add_u32 {DLDS}, {bufsel_reg}, %[ldsw]")
+        # one M0 per four pieces: the instruction offset moves the global AND the LDS address of an LDS-DMA load (measured: the
+        # product stays bit-exact; 26 -> 10 instructions per wave and chunk, 4.20 -> 4.00 ms)
         for i in range(g.pieces):
-            a(f"s_mov_b32 m0, {DLDS}")
-            a("s_nop 0")
-            a(f"global_load_lds_dwordx4 {VL16}, {PA}")
-            if i < g.pieces - 1:
-                a(f"s_add_u32 {PA_LO}, {PA_LO}, 0x400")
-                a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
-                a(f"s_add_u32 {DLDS}, {DLDS}, 0x400")
+            if i % 4 == 0:
+                if i:
+                    a(f"s_add_u32 {PA_LO}, {PA_LO}, 0x1000")
+                    a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
+                    a(f"s_add_u32 {DLDS}, {DLDS}, 0x1000")
+                a(f"s_mov_b32 m0, {DLDS}")
+                a("s_nop 0")
+            if 7 not in AB:
+                a(f"global_load_lds_dwordx4 {VL16}, {PA} offset:{(i % 4) * 1024}")
 
+    a(f"s_mov_b32 {CIDN}, %[cid0]")
     dma(CIDN, BUF)
-    a(f"s_load_dword {CIDN}, {CP}, 0x4")                 # CIDN = chunk id of the NEXT slot from here on
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    header(0)
     a("s_barrier")
-    # ---- slot loop
+    # ---- slot loop: NBL / NBN / CIDN hold this slot's batches, the next slot's batches and the next slot's chunk id
     a("L_slot_%=:")
-    # Touch (one vector load, result unused) the first lines of the NEXT slot's tokens so that the scalar loads of the batch loop hit
-    # the XCD's L2: lane l touches line l, at most 17 lines (2 KiB); longer slots touch 2 KiB ahead batch by batch (below).  Issued
-    # BEFORE the chunk DMA, so the slot's closing vmcnt(0) never waits for a young touch.  TP + TOFF = this slot's first batch.
-    a(f"s_mul_i32 {TMP}, {NBL}, {BATCH * 4}")
-    a(f"s_add_u32 {TMP}, {TMP}, {TOFF}")
-    a(f"s_add_u32 {PA_LO}, {TP_LO}, {TMP}")
-    a(f"s_addc_u32 {PA_HI}, {TP_HI}, 0")
-    a(f"s_mul_i32 {TMP}, {NBN}, {BATCH * 4}")
-    a(f"s_add_u32 {TMP}, {TMP}, 0xff")
-    a(f"s_lshr_b32 {TMP}, {TMP}, 7")              # lines of the next slot's tokens, + 1
-    a(f"s_min_u32 {TMP}, {TMP}, 17")
-    a(f"s_bfm_b64 exec, {TMP}, 0")
-    a(f"global_load_dword {VT1}, {VL128}, {PA}")
-    if g.weighted:   # the same lines of the value stream (it sits wdelta bytes behind the tokens)
-        a(f"s_add_u32 {PA_LO}, {PA_LO}, %[wdelta]")
-        a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
-        a(f"global_load_dword {VT1}, {VL128}, {PA}")
-    a("s_mov_b64 exec, -1")
-    # ... and the lines of the batch counts / chunk ids a few slots on (all lanes one address = one request each)
-    a(f"global_load_dword {VT1}, {VZ}, {NP} offset:{NW * 4 * 8}")
-    a(f"global_load_dword {VT1}, {VZ}, {CP} offset:256")
+    # The NEXT chunk first (LDS-DMA), then ONE touch: a vector load (result unused) of the first lines of the NEXT slot's tokens, so
+    # that the scalar loads of the batch loop hit the XCD's L2 -- lane l touches line l, at most 17 lines (2 KiB); longer slots
+    # touch 2 KiB ahead batch by batch (below).  vmcnt retires in issue order, so the slot's closing s_waitcnt vmcnt(NT) (all but
+    # the NT youngest) covers the DMA without waiting for the touch.  TP + TOFF = this slot's first batch.
     a(f"s_cmp_gt_u32 {NLEFT}, 1")
     a("s_cbranch_scc0 L_nodma_%=")
     a(f"s_xor_b32 {TMP2}, {BUF}, 0x10000")
     dma(CIDN, TMP2)
     a("L_nodma_%=:")
-    a(f"s_load_dword {CIDN}, {CP}, 0x8")                 # chunk id of slot j + 2 (the list is padded by two): the DMA above has read CIDN
-    a(f"s_load_dword {NBN2}, {NP}, {hex(NW * 8)}")       # batches of slot j + 2 (two closing rows of zeros)
+    a(f"s_mul_i32 {TMP}, {NBL}, {BATCH * 4}")
+    a(f"s_add_u32 {TMP}, {TMP}, {TOFF}")
+    a(f"s_add_u32 {PA_LO}, {TP_LO}, {TMP}")
+    a(f"s_addc_u32 {PA_HI}, {TP_HI}, 0")
+    a(f"s_add_u32 {TMP}, {NBN}, {2 * (128 // (BATCH * 4)) - 1}")
+    a(f"s_lshr_b32 {TMP}, {TMP}, {(128 // (BATCH * 4)).bit_length() - 1}")   # 128-byte lines of the next slot's tokens, + 1
+    a(f"s_min_u32 {TMP}, {TMP}, 17")
+    a(f"s_bfm_b64 exec, {TMP}, 0")
+    if 8 not in AB:
+        a(f"global_load_dword {VT1}, {VL128}, {PA}")
+    if g.weighted:   # the same lines of the value stream (it sits wdelta bytes behind the tokens)
+        a(f"s_add_u32 {PA_LO}, {PA_LO}, %[wdelta]")
+        a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
+        a(f"global_load_dword {VT1}, {VL128}, {PA}")
+    a("s_mov_b64 exec, -1")
     a(f"v_add_u32 {VB}, {BUF}, {VL4}")
-    a(f"s_cmp_eq_u32 {NBL}, 0")
-    a("s_cbranch_scc1 L_slotend_%=")
-    a(f"s_sub_u32 {NBL}, {NBL}, 1")               # batches left after the one in hand
+    a(f"s_sub_u32 {NBL}, {NBL}, 1")               # batches left after the one in hand (every list has at least its header batch)
     a(f"s_cmp_eq_u32 {ROT}, 0")
     a("s_cbranch_scc1 L_E0_%=")
     a(f"s_cmp_eq_u32 {ROT}, 1")
@@ -170,7 +172,8 @@ def body(op_add, g, ablate=0, op_mul=None):
 
     def load_next(r):
         a(f"s_add_u32 {TOFF}, {TOFF}, {hex(BATCH * 4)}")
-        a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, {TOFF}")
+        if 5 not in AB:
+            a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, {TOFF}")
         if g.weighted:
             a(f"s_add_u32 {TMP}, {TOFF}, %[wdelta]")
             a(f"{tokload} s[{WGT[r]}:{WGT[r] + BATCH - 1}], {TP}, {TMP}")
@@ -179,7 +182,8 @@ def body(op_add, g, ablate=0, op_mul=None):
         a(f"s_cmp_gt_u32 {NBL}, {max(4, 128 // BATCH)}")
         a(f"s_cbranch_scc0 L_nt{next_id[0]}_%=")
         a(f"v_mov_b32 {VT0}, {TOFF}")
-        a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
+        if 8 not in AB:
+            a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
         if g.weighted:
             a(f"v_add_u32 {VT0}, %[wdelta], {VT0}")
             a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
@@ -187,15 +191,30 @@ def body(op_add, g, ablate=0, op_mul=None):
         next_id[0] += 1
 
     def reads(r, x):
-        if ablate != 3:
+        if 3 not in AB:
             for i in range(BATCH):
                 a(f"v_bfi_b32 v{XS[x] + i}, {VM}, s{TOK[r] + i}, {VB}")
-        if ablate not in (2, 3):
+        if not (AB & {2, 3}):
             for i in range(BATCH):
                 a(f"ds_read_b32 v{XS[x] + i}, v{XS[x] + i}")
 
+    def reads_adds_interleaved(rn, xn, r, x):
+        # the next batch's LDS reads between an accumulator-index write and the add that depends on it
+        for i in range(BATCH):
+            a(f"v_bfi_b32 v{XS[xn] + i}, {VM}, s{TOK[rn] + i}, {VB}")
+        if g.weighted:
+            for i in range(BATCH):
+                a(f"{op_mul} v{XS[x] + i}, s{WGT[r] + i}, v{XS[x] + i}")
+        a(f"s_set_gpr_idx_on s{TOK[r]}, gpr_idx(SRC1,DST)")
+        for i in range(BATCH):
+            if i:
+                a(f"s_set_gpr_idx_idx s{TOK[r] + i}")
+            a(f"ds_read_b32 v{XS[xn] + i}, v{XS[xn] + i}")
+            a(f"{op_add} v{ACC0}, v{XS[x] + i}, v{ACC0}")
+        a("s_set_gpr_idx_off")
+
     def adds(r, x):
-        if ablate == 4:
+        if 4 in AB:
             return
         if g.weighted:   # product and sum round separately, as in the CPU loop (no FMA)
             for i in range(BATCH):
@@ -203,7 +222,7 @@ def body(op_add, g, ablate=0, op_mul=None):
         a(f"s_set_gpr_idx_on s{TOK[r]}, gpr_idx(SRC1,DST)")
         a(f"{op_add} v{ACC0}, v{XS[x]}, v{ACC0}")
         for i in range(1, BATCH):
-            if ablate != 1:
+            if 1 not in AB:
                 a(f"s_set_gpr_idx_idx s{TOK[r] + i}")
             a(f"{op_add} v{ACC0}, v{XS[x] + i}, v{ACC0}")
         a("s_set_gpr_idx_off")
@@ -226,8 +245,11 @@ def body(op_add, g, ablate=0, op_mul=None):
         a(f"L_B{rr}{xx}_%=:")
         a("s_waitcnt lgkmcnt(0)")            # batch i's reads (issued a phase ago) and batch i + 1's tokens are in
         load_next((rr + 2) % 3)
-        reads((rr + 1) % 3, 1 - xx)
-        adds(rr, xx)
+        if ablate == 9:
+            reads_adds_interleaved((rr + 1) % 3, 1 - xx, rr, xx)
+        else:
+            reads((rr + 1) % 3, 1 - xx)
+            adds(rr, xx)
         rr, xx = (rr + 1) % 3, 1 - xx
         count_and_exit(rr, xx)
     a("s_branch L_B00_%=")
@@ -237,18 +259,15 @@ def body(op_add, g, ablate=0, op_mul=None):
             a(f"L_D{r}{x}_%=:")
             a("s_waitcnt lgkmcnt(0)")
             adds(r, x)
+            header((r + 1) % 3)                  # the next slot's first batch is in (loaded a body ago, waited for above)
             a(f"s_mov_b32 {ROT}, {(r + 1) % 3}")
             a("s_branch L_slotend_%=")
     a("L_slotend_%=:")
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # my pieces of the next chunk have landed; NBN2 / CIDN are in
-    a("s_barrier")                               # ... and everybody is done reading the current one
+    nt = (2 if g.weighted else 1) - (1 if 8 in AB else 0)
+    a(f"s_waitcnt vmcnt({nt}) lgkmcnt(0)")        # my pieces of the next chunk have landed (the touch behind them may not have)
+    if 6 not in AB:
+        a("s_barrier")                           # ... and everybody is done reading the current one
     a(f"s_xor_b32 {BUF}, {BUF}, 0x10000")
-    a(f"s_mov_b32 {NBL}, {NBN}")
-    a(f"s_mov_b32 {NBN}, {NBN2}")
-    a(f"s_add_u32 {CP_LO}, {CP_LO}, 4")
-    a(f"s_addc_u32 {CP_HI}, {CP_HI}, 0")
-    a(f"s_add_u32 {NP_LO}, {NP_LO}, {hex(NW * 4)}")
-    a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
     a(f"s_sub_u32 {NLEFT}, {NLEFT}, 1")
     a(f"s_cmp_gt_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_slot_%=")
@@ -304,9 +323,7 @@ constexpr uint32_t lds_ka(uint32_t nw) { return nw == 16 ? %(KA16)du : %(KA8)du;
 constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du; }
 
 struct LdsArgs {
-    const uint32_t *tok;      // token streams
-    const uint32_t *nb;       // batch counts
-    const uint32_t *chunks;   // chunk-id lists
+    const uint32_t *tok;      // token streams (with the slot headers, lds_plan.hpp)
     const LdsTile *tiles;
     const uint32_t *rowmap;   // [ntiles][NW][KA] row of C (0xffffffff = none)
     const char *xs;           // slice-major X: [nslices][ncols_pad][64] elements of 4 bytes
@@ -338,24 +355,21 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const LdsTile *t = a.tiles + ti;
     const uint32_t nch = __builtin_amdgcn_readfirstlane(t->nch);
     const uint64_t tok = (uint64_t)(a.tok + (uint64_t)t->tokstart[wave] * BATCH);
-    const uint64_t nb = (uint64_t)(a.nb + t->nb_off + wave);
-    const uint64_t chunks = (uint64_t)(a.chunks + t->chunk_off);
+    const uint32_t cid0 = __builtin_amdgcn_readfirstlane(t->chunk0);
     const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * PIECE);
     const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * KA);
     const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * PIECE);
 #define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
-    const uint32_t tok_lo = PYGIM_SU(tok), tok_hi = PYGIM_SU(tok >> 32), nb_lo = PYGIM_SU(nb), nb_hi = PYGIM_SU(nb >> 32);
-    const uint32_t ch_lo = PYGIM_SU(chunks), ch_hi = PYGIM_SU(chunks >> 32), xs_lo = PYGIM_SU(xs), xs_hi = PYGIM_SU(xs >> 32);
+    const uint32_t tok_lo = PYGIM_SU(tok), tok_hi = PYGIM_SU(tok >> 32), xs_lo = PYGIM_SU(xs), xs_hi = PYGIM_SU(xs >> 32);
     const uint32_t rm_lo = PYGIM_SU(rowmap), rm_hi = PYGIM_SU(rowmap >> 32), c_lo = PYGIM_SU(cb), c_hi = PYGIM_SU(cb >> 32);
 #undef PYGIM_SU
-    const uint64_t tok_s = ((uint64_t)tok_hi << 32) | tok_lo, nb_s = ((uint64_t)nb_hi << 32) | nb_lo;
-    const uint64_t ch_s = ((uint64_t)ch_hi << 32) | ch_lo, rm_s = ((uint64_t)rm_hi << 32) | rm_lo;
+    const uint64_t tok_s = ((uint64_t)tok_hi << 32) | tok_lo, rm_s = ((uint64_t)rm_hi << 32) | rm_lo;
     asm volatile(
 %(asm)s
         :
-        : [lane] "v"(lane), [tok] "s"(tok_s), [nb] "s"(nb_s), [chunks] "s"(ch_s), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
+        : [lane] "v"(lane), [tok] "s"(tok_s), [cid0] "s"(cid0), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
           [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta)
         : %(clobbers)s, "vcc", "scc", "memory");
@@ -370,8 +384,8 @@ def main():
     for nw in (8, 16):
         variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
         variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
-    for ab in (1, 2, 3, 4):
-        variants.append((f"k_lds_spmm_f32_w8_ab{ab}", "v_add_f32", 8, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
+    for ab in (6, 7, 10, 11, 12):
+        variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
     for v in variants:

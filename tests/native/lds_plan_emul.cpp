@@ -17,6 +17,7 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
     LdsPlanHost plan;
     static_assert(sizeof(T) == 4, "4-byte values");
     lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
+    if (plan.header_overflow) return 13;
     if ((vals != nullptr) != !plan.wts.empty() || (vals && plan.wts.size() != plan.tok.size())) return 9;
     const uint32_t NW = geo.NW, KC = geo.KC;
     const uint32_t nslices = (h + 63) / 64;
@@ -34,14 +35,20 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
             for (uint32_t w = 0; w < NW; w++) {
                 std::vector<T> acc((size_t)(KA + 1) * 64, T(0));
                 uint64_t at = (uint64_t)t.tokstart[w] * batch;
-                for (uint32_t j = 0; j < t.nch; j++) {
-                    const uint32_t chunk = plan.chunks[t.chunk_off + j];
-                    const uint32_t nb = plan.nb[t.nb_off + (size_t)j * NW + w];
+                uint32_t chunk = t.chunk0, chunk_next = 0;
+                for (uint32_t j = 0; j < t.nch; j++, chunk = chunk_next) {
+                    // the kernel's scalar side reads nothing but the token stream: batch count / next count / next chunk id
+                    // sit in the upper halves of the first three tokens of the slot's first batch
+                    if (at + 2 >= plan.tok.size()) return 2;
+                    const uint32_t nb = plan.tok[at] >> 16, nb_next = plan.tok[at + 1] >> 16;
+                    chunk_next = plan.tok[at + 2] >> 16;
+                    if (nb == 0 || nb != plan.nb[t.nb_off + (size_t)j * NW + w] || chunk != plan.chunks[t.chunk_off + j]) return 11;
+                    if (nb_next != (j + 1 < t.nch ? plan.nb[t.nb_off + (size_t)(j + 1) * NW + w] : 0u)) return 12;
                     for (uint32_t b = 0; b < nb * batch; b++, at++) {
                         if (at >= plan.tok.size()) return 2;
                         const uint32_t tk = plan.tok[at];
                         const uint32_t k = tk & 0xFF, c = (tk >> 8) & 0xFF;
-                        if (tk >> 16) return 3;
+                        if ((tk >> 16) && b > 2) return 3;   // upper halves are header space in tokens 0..2 of the first batch only
                         if (k > KA) return 4;
                         const uint64_t xr = (uint64_t)chunk * KC + c;
                         if (k < KA && xr >= ncols) return 5;

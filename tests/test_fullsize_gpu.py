@@ -239,3 +239,41 @@ def test_reddit_spmv_end_full_size(w, tdt, code, weighted):
         sample_rows_vs_oracle(rowptr, col, vals, x, c1, [(longest, longest + 1)])
     finally:
         _lib.group_free(hd)
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_reddit_lds_staged_product_is_the_cpu_loop_bit_for_bit(clustered):
+    """configs[1] on the LDS-staged kernel (the default for this shape since round 3), uniform and community-like columns:
+    every output of the real-valued product equals the oracle's sequential loop bit for bit (with and without entry values),
+    and the driver-feature product equals the L2 sweep's."""
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["reddit"]
+    h = 256
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=clustered)
+    rp_h, col_h = rowptr.cpu().numpy().astype(np.uint32), col.cpu().numpy().astype(np.uint32)
+    xr = synth.features(n, h, torch.float32, seed=1, device=dev, kind="uniform")
+    x1 = synth.features(n, h, torch.float32, seed=0, device=dev)
+    vals = (torch.rand(nnz, device=dev) * 2 - 1).float()
+    for v in (None, vals):
+        hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None if v is None else [v.data_ptr()],
+                               [n], [n], [nnz], [1], [h], h)
+        try:
+            plan = _lib.group_lds_plan(hd)
+            assert plan["tiles"] > 0 and plan["nnz"] == nnz, plan
+            if clustered:
+                assert plan["chunk_fills"] * 5 < plan["tiles"] * ((n + 255) // 256)   # a tile streams only the chunks it touches
+            got = run(hd, xr, n, h).cpu().numpy()
+            ref = np.zeros((n, h), dtype=np.float32)
+            oracle.spmm_csr_rowpar(rp_h, col_h, None if v is None else v.cpu().numpy(), xr.cpu().numpy(),
+                                   nthreads=oracle.max_threads(), out=ref)
+            assert got.tobytes() == ref.tobytes()
+            if v is None:
+                c_lds = run(hd, x1, n, h)
+                old = _lib.set_tunable("lds_mode", 2)      # the same group, the sweep
+                try:
+                    c_sweep = run(hd, x1, n, h)
+                finally:
+                    _lib.set_tunable("lds_mode", old)
+                assert torch.equal(c_lds, c_sweep)
+        finally:
+            _lib.group_free(hd)
