@@ -914,7 +914,7 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
 template <typename T, int VEC, int LOG_LPR>
 __global__ void k_slice_pack_quant(const float *__restrict__ X, int64_t ldx, uint32_t nrows, uint32_t w, uint32_t nslices,
                                    const uint32_t *__restrict__ absmax_bits, int log2_range, T *__restrict__ Xs,
-                                   float *__restrict__ scale_out) {
+                                   float *__restrict__ scale_out, uint32_t slice_rows) {  // slice_rows >= nrows, as k_slice_pack
     constexpr int LPR = 1 << LOG_LPR;
     constexpr uint32_t F = LPR * VEC;
     static_assert(VEC * sizeof(T) == 16 && VEC % 4 == 0, "16-byte pieces of at least four elements");
@@ -942,7 +942,7 @@ __global__ void k_slice_pack_quant(const float *__restrict__ X, int64_t ldx, uin
 #pragma unroll
         for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? (T)rintf(src[k] / scale) : T(0);
     }
-    store_vec<T, VEC>(Xs + ((int64_t)sl * nrows + j) * F + li * VEC, v);
+    store_vec<T, VEC>(Xs + ((int64_t)sl * slice_rows + j) * F + li * VEC, v);
 }
 
 // panel pointers: pp[p * nrows + i] = first stored entry of sorted row i whose column

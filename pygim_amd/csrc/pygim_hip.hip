@@ -625,16 +625,19 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
 // LDS-staged product (lds_kernel_gen.hpp / lds_plan.hpp): X is copied slice-major in 256-byte slices (64 features, rows padded to
 // whole 256-column chunks), then ONE launch: a 512-thread workgroup per (tile of rows, slice) streams the tile's chunks of X
 // through a double-buffered 128 KiB LDS ring and keeps the tile's running sums in registers; C is written once.
+// lds_xs: a slice-major copy the caller already made on this stream (the fused quantiser); deq_amax != nullptr: the store
+// dequantises, C is then the FLOAT result (row stride ldc elements of 4 bytes)
 template <typename T>
-int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate, hipStream_t st) {
+int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate, hipStream_t st,
+               const void *lds_xs = nullptr, const uint32_t *deq_amax = nullptr, int deq_log2 = 0) {
     static_assert(sizeof(T) == 4, "4-byte elements");
     const uint32_t nslices = (w + 63) / 64;
     const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
     const size_t need = (size_t)rows_pad * nslices * 256;
     KernelTimer kt(g, st, !p.is_extra);
     XsPin pin;
-    void *xs_use = nullptr;
-    {
+    void *xs_use = const_cast<void *>(lds_xs);
+    if (!xs_use) {
         std::lock_guard<std::mutex> lk(g_ctx.mu);
         if (g->x_unchanged) {
             int dev = 0;
@@ -683,11 +686,17 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.ntiles = p.lds_ntiles;
     a.accumulate = accumulate ? 1 : 0;
     a.wdelta = p.lds_wdelta;
+    a.deq_amax = deq_amax;
+    a.deq_log2 = deq_log2;
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);
     KernelFn fn = nullptr;
-    if constexpr (std::is_same<T, float>::value) {
+    if (deq_amax) {
+        if (p.lds_nw != 16 || p.lds_wdelta) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
+        if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16_deq;
+        else fn = k_lds_spmm_i32_w16_deq;
+    } else if constexpr (std::is_same<T, float>::value) {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_f32_w16_val : k_lds_spmm_f32_w16) : k_lds_spmm_f32_w8;
         if (p.lds_nw == 16 && !p.lds_wdelta) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py)
             switch (g_tune.lds_ablate) {
@@ -702,6 +711,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     } else {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }
+    if (deq_amax && g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate is a timing experiment of the plain kernel");
     {
         static std::set<KernelFn> attr_done;
         std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -972,7 +982,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
         // groups whose rows of X hold at most 4 elements never take the wide sweep: their panels are sized for the LDS-staged
         // SpMV kernel instead (a panel of X, h elements per column, inside 128 KiB of a workgroup's LDS; the rest parks results)
         if (h_hint >= 1 && h_hint <= 4 && g_tune.vec_lds && g_tune.vec_kernel)
-            budget_rows = std::max<int64_t>(1, std::min<int64_t>(budget_rows, (int64_t)((128 * 1024 - 64) / ((size_t)h_hint * es))));
+            budget_rows = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(budget_rows, 65536),  // (16-bit panel-local ids)
+                                                                 (int64_t)((128 * 1024 - 64) / ((size_t)h_hint * es))));
         uint32_t npan = (uint32_t)std::max<int64_t>(1, (p.ncols + budget_rows - 1) / budget_rows);
         bool worth = g_tune.panel_mode == 1 || npan == 1 ||
                      (double)p.nnz / ((double)p.nrows * npan) >= (double)g_tune.panel_min_seg;
@@ -1577,6 +1588,20 @@ static Part *fusable_part(Group *g) {
     return p;
 }
 
+// the part whose LDS-staged plan can carry the conv layers' quantised aggregation with the dequantisation in its store
+// (INT32 / FLT32 adjacency types; no per-column epilogue: that one stays with the sweep's store)
+template <typename T>
+static Part *lds_fusable_part(Group *g) {
+    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return nullptr;
+    if (!g->all_ones || g->post_mul || g_tune.lds_mode == 2 || (int64_t)g->h < g_tune.lds_min_width) return nullptr;
+    if (g_tune.lds_mode == 0 && (g_tune.panel_mode != 0 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0 || !g_tune.fuse_windows)) return nullptr;
+    Part *p = nullptr;
+    if (g->parts.size() == 1) p = &g->parts[0];
+    else if (g->merged && g_tune.merge_parts) p = g->merged.get();
+    if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || p->lds_nw != 16 || p->nrows == 0 || p->ncols == 0) return nullptr;
+    return p;
+}
+
 static int launch_post(Group *g, float *out, hipStream_t st) {
     if (!g->post_mul) return 0;
     const uint64_t total = (uint64_t)g->total_rows * (uint64_t)g->h;
@@ -1595,6 +1620,29 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, amax);
     if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
     if (rows * h == 0 && scale_out) hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, (uint32_t *)scale_out);
+    if constexpr (sizeof(T) == 4) {
+        if (Part *p = lds_fusable_part<T>(g)) {
+            // FUSED on the LDS-staged kernel: the 256-byte-slice copy is written quantised from the float features, the kernel's
+            // store dequantises (no quantised matrix, no integer result)
+            const uint32_t nslices = (h + 63) / 64;
+            const uint64_t rows_pad = ((uint64_t)p->ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
+            void *xs = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_ctx.mu);
+                Context::XsBuf *b = nullptr;
+                if (int rc = xs_buffer_locked(st, std::max<size_t>((size_t)rows_pad * nslices * 256, 256), &b)) return rc;
+                b->src = nullptr;  // quantised values of a float matrix: never matched by x_unchanged
+                xs = b->ptr;
+            }
+            XsPin pin;
+            pin.hold(xs);
+            const uint64_t threads = (uint64_t)p->ncols * nslices * 16;
+            hipLaunchKernelGGL((k_slice_pack_quant<T, 4, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
+                               (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out, (uint32_t)rows_pad);
+            HIP_TRY(hipGetLastError());
+            return launch_lds<T>(g, *p, (const T *)nullptr, (int64_t)h, (T *)out, (int64_t)h, h, false, st, xs, amax, log2_range);
+        }
+    }
     if (Part *p = fusable_part<T>(g)) {
         // FUSED: |max| reduction, then the slice-major copy is written quantised straight from the float features,
         // and every row's last panel item stores float(sum) * scale (no row-major quantised matrix, no integer result,
@@ -1615,7 +1663,7 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
         pin.hold(xs);
         const uint64_t threads = (uint64_t)p->ncols * nslices * (1u << LOG_LPR);
         hipLaunchKernelGGL((k_slice_pack_quant<T, VEC, LOG_LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
-                           (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out);
+                           (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out, (uint32_t)p->ncols);
         HIP_TRY(hipGetLastError());
         // running sums between panels (rows whose entries span several panels) live in the group's integer buffer
         if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
@@ -1654,6 +1702,10 @@ template <typename T>
 static int dequant_run_t(Group *g, const void *Xq, int64_t ldx, float *out, const uint32_t *amax, int log2_range, hipStream_t st) {
     const uint64_t orows = (uint64_t)g->total_rows;
     const uint32_t h = (uint32_t)g->h;
+    if constexpr (sizeof(T) == 4) {
+        if (Part *pl = lds_fusable_part<T>(g))  // the LDS-staged kernel packs the quantised rows itself and dequantises in its store
+            return launch_lds<T>(g, *pl, (const T *)Xq, ldx, (T *)out, (int64_t)h, h, false, st, nullptr, amax, log2_range);
+    }
     if (int rc = ensure(&g->oq, &g->oq_bytes, std::max<size_t>(orows * h * sizeof(T), 256))) return rc;
     Part *p = fusable_part<T>(g);
     // the dequantising store rides the sweep's slice-major gather modes: whole 16-byte pieces (so that the copy is made from
@@ -1794,6 +1846,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
         return -1;
     }
     const int64_t old = *slot;
+    if (slot == &g_tune.panel_lds_pad) value = std::min<int64_t>(std::max<int64_t>(value, 0), 64 << 10);  // goes into a launch's dynamic LDS size
     *slot = value;
     return old;
 }

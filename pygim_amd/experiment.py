@@ -195,6 +195,12 @@ class Experiment:
         (``.failed`` appended on a non-zero exit, and -- unless ``silent`` -- a RuntimeError after they are written)."""
         # (the reference tests the truth of `tune`, whose default is the non-empty string 'FALSE': experiment.py:176, 402;
         #  here 'FALSE' means off)
+        # result files carry the DECLARED parameters (the reference computes its stdout path before it tunes and keeps that name on
+        # success, experiment.py:396-405): status_at / run_experiments / the plot scripts look a run up by what was asked for
+        declared_out = declared_err = None
+        if result_root is not None:
+            declared_out = {f: self.stdout_path(result_root, failed=f) for f in (False, True)}
+            declared_err = {f: self.stderr_path(result_root, failed=f) for f in (False, True)}
         if self.tune not in (None, False, "", "FALSE", "False"):
             self._apply_tuned_partition(data_root)
         cmd = self.command(src_root, data_root, build_root, repeat)
@@ -209,9 +215,9 @@ class Experiment:
             os.makedirs(result_root, exist_ok=True)
             pipe = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             rc = pipe.returncode
-            with open(self.stdout_path(result_root, failed=rc != 0), "wb") as w:
+            with open(declared_out[rc != 0], "wb") as w:
                 w.write(pipe.stdout)
-            with open(self.stderr_path(result_root, failed=rc != 0), "wb") as w:
+            with open(declared_err[rc != 0], "wb") as w:
                 w.write(pipe.stderr)
         if rc != 0:
             message = f"The following command failed with return code {rc}\n==> {' '.join(cmd)}\n"

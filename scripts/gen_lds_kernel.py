@@ -55,7 +55,7 @@ GEOS = {8: Geo(8, 192, 16, 16), 16: Geo(16, 96, 8, 4)}
 GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 
 
-def body(op_add, g, ablate=0, op_mul=None):
+def body(op_add, g, ablate=0, op_mul=None, deq=None):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
     3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
     6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
@@ -290,12 +290,18 @@ def body(op_add, g, ablate=0, op_mul=None):
     a(f"s_set_gpr_idx_on {KREG}, gpr_idx(SRC0)")
     a(f"v_mov_b32 {VT0}, v{ACC0}")
     a("s_set_gpr_idx_off")
-    a("s_cmp_eq_u32 %[accum], 0")
-    a("s_cbranch_scc1 L_ost_%=")
-    a(f"global_load_dword {VT1}, {VL4}, {PA}")
-    a("s_waitcnt vmcnt(0)")
-    a(f"{op_add} {VT0}, {VT1}, {VT0}")
-    a("L_ost_%=:")
+    if deq:
+        # the conv layers' dequantisation in the store (models/quantize.py:35-38): float(sum) * scale, as the sweep's fused store
+        if deq == "i32":
+            a(f"v_cvt_f32_i32 {VT0}, {VT0}")
+        a(f"v_mul_f32 {VT0}, %[scale], {VT0}")
+    else:
+        a("s_cmp_eq_u32 %[accum], 0")
+        a("s_cbranch_scc1 L_ost_%=")
+        a(f"global_load_dword {VT1}, {VL4}, {PA}")
+        a("s_waitcnt vmcnt(0)")
+        a(f"{op_add} {VT0}, {VT1}, {VT0}")
+        a("L_ost_%=:")
     a(f"global_store_dword {VL4}, {VT0}, {PA}")
     a("L_oskip_%=:")
     a(f"s_add_u32 {NP_LO}, {NP_LO}, 4")
@@ -331,6 +337,8 @@ struct LdsArgs {
     uint64_t slice_stride;    // bytes between two slices of xs
     uint32_t ldc_bytes, w, nslices, ntiles, accumulate, xcd_group;
     uint32_t wdelta;          // weighted kernels: bytes from a token to its value (the value stream follows the token stream)
+    const uint32_t *deq_amax; // dequantising kernels: bits of max|x| (device), and the quantiser's log2 range
+    int deq_log2;
 };
 """
 
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * PIECE);
+    const uint32_t scale = %(scale_expr)s;
 #define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
     const uint32_t tok_lo = PYGIM_SU(tok), tok_hi = PYGIM_SU(tok >> 32), xs_lo = PYGIM_SU(xs), xs_hi = PYGIM_SU(xs >> 32);
     const uint32_t rm_lo = PYGIM_SU(rowmap), rm_hi = PYGIM_SU(rowmap >> 32), c_lo = PYGIM_SU(cb), c_hi = PYGIM_SU(cb >> 32);
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
         :
         : [lane] "v"(lane), [tok] "s"(tok_s), [cid0] "s"(cid0), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
-          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta)
+          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale)
         : %(clobbers)s, "vcc", "scc", "memory");
 }
 """
@@ -388,14 +397,19 @@ def main():
         variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
+    variants.append(("k_lds_spmm_f32_w16_deq", "v_add_f32", 16, 0, "FLT32 quantised features, the store dequantises: out = sum * scale", None, "f32"))
+    variants.append(("k_lds_spmm_i32_w16_deq", "v_add_u32", 16, 0, "INT32 quantised features, the store dequantises: out = float(sum) * scale", None, "i32"))
     for v in variants:
         name, op, nw, ab, doc = v[:5]
         op_mul = v[5] if len(v) > 5 else None
+        deq = v[6] if len(v) > 6 else None
         g = GEO_W16 if op_mul else GEOS[nw]
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul))
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq))
         text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,
-                              piece=g.pieces * 1024)
+                              piece=g.pieces * 1024,
+                              scale_expr=("__builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(*a.deq_amax) * 2.0f / (float)(1u << a.deq_log2)))"
+                                          if deq else "0u"))
     text += "\n}  // namespace pygim\n"
     with open(out, "w") as f:
         f.write(text)
