@@ -170,15 +170,18 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a("s_cbranch_scc1 L_E1_%=")
     a("s_branch L_E2_%=")
 
-    def load_next(r):
+    def load_next(r, touch=True):
         a(f"s_add_u32 {TOFF}, {TOFF}, {hex(BATCH * 4)}")
         if 5 not in AB:
             a(f"{tokload} s[{TOK[r]}:{TOK[r] + BATCH - 1}], {TP}, {TOFF}")
         if g.weighted:
             a(f"s_add_u32 {TMP}, {TOFF}, %[wdelta]")
             a(f"{tokload} s[{WGT[r]}:{WGT[r] + BATCH - 1}], {TP}, {TMP}")
+        if not touch:
+            return
         # long slots: the line 2 KiB ahead (all lanes one address = one request), except in the slot's last batches
-        # (a touch issued there would still be in flight at the slot's closing vmcnt(0))
+        # (a touch issued there would still be in flight at the slot's closing vmcnt(0)).  With 8-token batches (32 bytes)
+        # only every third body carries the touch: consecutive touches are then 96 bytes apart, no 128-byte line is skipped
         a(f"s_cmp_gt_u32 {NBL}, {max(4, 128 // BATCH)}")
         a(f"s_cbranch_scc0 L_nt{next_id[0]}_%=")
         a(f"v_mov_b32 {VT0}, {TOFF}")
@@ -244,7 +247,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     for _ in range(6):
         a(f"L_B{rr}{xx}_%=:")
         a("s_waitcnt lgkmcnt(0)")            # batch i's reads (issued a phase ago) and batch i + 1's tokens are in
-        load_next((rr + 2) % 3)
+        load_next((rr + 2) % 3, touch=(rr == 0 or BATCH * 4 * 3 > 128))
         if ablate == 9:
             reads_adds_interleaved((rr + 1) % 3, 1 - xx, rr, xx)
         else:

@@ -138,3 +138,20 @@ def test_bench_two_ranks_logic_check(partition):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["check"].startswith("column-count checksum")
     assert d["config"]["ms_per_step_products_only"] > 0
+
+
+def test_bench_launches_its_own_ranks_as_a_plain_command():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run (the driver's command form at N > 1): bench.py starts its own
+    ranks as child processes, relays their output and exits with their code -- one JSON line, n_gpus 2, rc 0 (2 ranks over
+    gloo on this one GPU: a logic check, not a measurement).  A rank that fails must make the command fail."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYGIM_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "products-mini"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["check"].startswith("column-count checksum")
+    bad = subprocess.run(cmd + ["--shape", "no-such-shape"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
