@@ -84,6 +84,7 @@ struct Tunables {
     int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
+    int64_t lds_long_slots = 128;       // tokens per (wave, chunk) from which the 16-token-batch geometry is planned (0 = never)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
@@ -126,7 +127,7 @@ struct Part {
     // LDS-staged product (lds_plan.hpp): token streams and tile table on the device; lds_tiles == nullptr: no such plan
     uint32_t *lds_tok = nullptr, *lds_nb = nullptr, *lds_chunks = nullptr, *lds_rowmap = nullptr;
     LdsTile *lds_tiles = nullptr;
-    uint32_t lds_ntiles = 0, lds_nw = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
+    uint32_t lds_ntiles = 0, lds_nw = 8, lds_batch = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
     uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
@@ -692,13 +693,17 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);
     KernelFn fn = nullptr;
+    const bool long16 = p.lds_nw == 16 && p.lds_batch == LDS_L16_BATCH;   // the 16-token-batch geometry (no values)
     if (deq_amax) {
         if (p.lds_nw != 16 || p.lds_wdelta) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
-        if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16_deq;
-        else fn = k_lds_spmm_i32_w16_deq;
+        if constexpr (std::is_same<T, float>::value) fn = long16 ? k_lds_spmm_f32_w16b_deq : k_lds_spmm_f32_w16_deq;
+        else fn = long16 ? k_lds_spmm_i32_w16b_deq : k_lds_spmm_i32_w16_deq;
+    } else if (long16) {
+        if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16b;
+        else fn = k_lds_spmm_i32_w16b;
     } else if constexpr (std::is_same<T, float>::value) {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_f32_w16_val : k_lds_spmm_f32_w16) : k_lds_spmm_f32_w8;
-        if (p.lds_nw == 16 && !p.lds_wdelta) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py)
+        if (p.lds_nw == 16 && !p.lds_wdelta && !long16) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py)
             switch (g_tune.lds_ablate) {
                 case 6: fn = k_lds_spmm_f32_w16_ab6; break;
                 case 7: fn = k_lds_spmm_f32_w16_ab7; break;
@@ -1141,6 +1146,23 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     LdsPlanHost plan;
     lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
                    p.vals ? h_val.data() : nullptr);
+    // long slots (a community-structured graph: a tile streams few chunks, a wave gets hundreds of tokens per chunk): the per-batch
+    // bookkeeping is what is left to save -- the 16-token-batch geometry, when the tiles fit its 80 accumulators per wave
+    if (geo.NW == 16 && !p.vals && g_tune.lds_long_slots && plan.slots > 0 &&
+        (double)plan.ntokens / ((double)plan.slots * geo.NW) >= (double)g_tune.lds_long_slots) {
+        LdsGeometry gl = geo;
+        gl.KA = LDS_L16_KA;
+        gl.BATCH = LDS_L16_BATCH;
+        gl.rows_per_tile = g_tune.lds_round_tiles && h_hint > 0
+                               ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)((h_hint + 63) / 64), (uint32_t)std::max(g_ctx.cu_count, 1))
+                               : 0;
+        const uint32_t r_now = geo.rows_per_tile ? geo.rows_per_tile : geo.NW * geo.KA, r_new = gl.rows_per_tile ? gl.rows_per_tile : gl.NW * gl.KA;
+        if (r_new >= r_now) {  // no more tiles than before
+            lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, gl, plan,
+                           (unsigned)std::max<int64_t>(0, g_tune.lds_threads), nullptr);
+            geo = gl;
+        }
+    }
     std::vector<uint32_t>().swap(h_col);
     std::vector<uint32_t>().swap(h_val);
     if (p.vals) {
@@ -1161,6 +1183,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
+    p.lds_batch = geo.BATCH;
     p.lds_slots = plan.slots;
     p.lds_tokens = plan.ntokens;
     return 0;
@@ -1841,6 +1864,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_waves") slot = &g_tune.lds_waves;
     else if (n == "lds_ablate") slot = &g_tune.lds_ablate;
     else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
+    else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
         return -1;

@@ -53,6 +53,7 @@ class Geo:
 
 GEOS = {8: Geo(8, 192, 16, 16), 16: Geo(16, 96, 8, 4)}
 GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
+GEO_L16 = Geo(16, 80, 16, 4)                 # long slots (community-structured graphs): 16-token batches halve the per-batch bookkeeping
 
 
 def body(op_add, g, ablate=0, op_mul=None, deq=None):
@@ -281,35 +282,38 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a("s_and_b64 exec, exec, vcc")
     a(f"s_mov_b64 {NP}, %[rowmap]")
     a(f"s_mov_b32 {KREG}, 0")
-    a("L_orow_%=:")
-    a(f"s_load_dword {ROWID}, {NP}, 0x0")
+    a("L_orow_%=:")                                # eight rows per scalar load of the row map
+    a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
     a("s_waitcnt lgkmcnt(0)")
-    a(f"s_cmp_eq_u32 {ROWID}, -1")
-    a("s_cbranch_scc1 L_oskip_%=")
-    a(f"s_mul_i32 {PA_LO}, {ROWID}, %[ldc]")
-    a(f"s_mul_hi_u32 {PA_HI}, {ROWID}, %[ldc]")
-    a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
-    a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
-    a(f"s_set_gpr_idx_on {KREG}, gpr_idx(SRC0)")
-    a(f"v_mov_b32 {VT0}, v{ACC0}")
-    a("s_set_gpr_idx_off")
-    if deq:
-        # the conv layers' dequantisation in the store (models/quantize.py:35-38): float(sum) * scale, as the sweep's fused store
-        if deq == "i32":
-            a(f"v_cvt_f32_i32 {VT0}, {VT0}")
-        a(f"v_mul_f32 {VT0}, %[scale], {VT0}")
-    else:
-        a("s_cmp_eq_u32 %[accum], 0")
-        a("s_cbranch_scc1 L_ost_%=")
-        a(f"global_load_dword {VT1}, {VL4}, {PA}")
-        a("s_waitcnt vmcnt(0)")
-        a(f"{op_add} {VT0}, {VT1}, {VT0}")
-        a("L_ost_%=:")
-    a(f"global_store_dword {VL4}, {VT0}, {PA}")
-    a("L_oskip_%=:")
-    a(f"s_add_u32 {NP_LO}, {NP_LO}, 4")
+    for i in range(8):
+        rid = f"s{TOK[0] + i}"
+        a(f"s_cmp_eq_u32 {rid}, -1")
+        a(f"s_cbranch_scc1 L_oskip{i}_%=")
+        a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
+        a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
+        a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
+        a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
+        a(f"s_add_u32 {DLDS}, {KREG}, {i}")            # (TMP holds half of the saved exec mask here)
+        a(f"s_set_gpr_idx_on {DLDS}, gpr_idx(SRC0)")
+        a(f"v_mov_b32 {VT0}, v{ACC0}")
+        a("s_set_gpr_idx_off")
+        if deq:
+            # the conv layers' dequantisation in the store (models/quantize.py:35-38): float(sum) * scale, as the sweep's fused store
+            if deq == "i32":
+                a(f"v_cvt_f32_i32 {VT0}, {VT0}")
+            a(f"v_mul_f32 {VT0}, %[scale], {VT0}")
+        else:
+            a("s_cmp_eq_u32 %[accum], 0")
+            a(f"s_cbranch_scc1 L_ost{i}_%=")
+            a(f"global_load_dword {VT1}, {VL4}, {PA}")
+            a("s_waitcnt vmcnt(0)")
+            a(f"{op_add} {VT0}, {VT1}, {VT0}")
+            a(f"L_ost{i}_%=:")
+        a(f"global_store_dword {VL4}, {VT0}, {PA}")
+        a(f"L_oskip{i}_%=:")
+    a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
     a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
-    a(f"s_add_u32 {KREG}, {KREG}, 1")
+    a(f"s_add_u32 {KREG}, {KREG}, 8")
     a(f"s_cmp_lt_u32 {KREG}, {KA}")
     a("s_cbranch_scc1 L_orow_%=")
     a(f"s_mov_b64 exec, {EX}")
@@ -330,6 +334,8 @@ constexpr uint32_t LDS_KC = 256, LDS_BYTES = 131072;
 // kernel variants: waves per workgroup -> accumulators per wave, tokens per batch
 constexpr uint32_t lds_ka(uint32_t nw) { return nw == 16 ? %(KA16)du : %(KA8)du; }
 constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du; }
+// ... and the 16-wave geometry for long slots (16-token batches, fewer accumulators)
+constexpr uint32_t LDS_L16_KA = %(KAL)du, LDS_L16_BATCH = %(BL)du;
 
 struct LdsArgs {
     const uint32_t *tok;      // token streams (with the slot headers, lds_plan.hpp)
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
 
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pygim_amd", "csrc", "lds_kernel_gen.hpp")
-    text = HEADER % dict(KA8=GEOS[8].KA, KA16=GEOS[16].KA, B8=GEOS[8].BATCH, B16=GEOS[16].BATCH)
+    text = HEADER % dict(KA8=GEOS[8].KA, KA16=GEOS[16].KA, B8=GEOS[8].BATCH, B16=GEOS[16].BATCH, KAL=GEO_L16.KA, BL=GEO_L16.BATCH)
     variants = []
     for nw in (8, 16):
         variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
@@ -402,11 +408,14 @@ def main():
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
     variants.append(("k_lds_spmm_f32_w16_deq", "v_add_f32", 16, 0, "FLT32 quantised features, the store dequantises: out = sum * scale", None, "f32"))
     variants.append(("k_lds_spmm_i32_w16_deq", "v_add_u32", 16, 0, "INT32 quantised features, the store dequantises: out = float(sum) * scale", None, "i32"))
+    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32")):
+        variants.append((f"k_lds_spmm_{base}_w16b" + ("_deq" if deq else ""), op, "L16", 0,
+                         "the same for plans with long slots: 16-token batches, 80 accumulators per wave", None, deq))
     for v in variants:
         name, op, nw, ab, doc = v[:5]
         op_mul = v[5] if len(v) > 5 else None
         deq = v[6] if len(v) > 6 else None
-        g = GEO_W16 if op_mul else GEOS[nw]
+        g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq))
         text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,

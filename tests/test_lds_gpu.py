@@ -59,10 +59,12 @@ def product(rowptr, col, x, ncols=None, fmt="CSR", row=None, vals=None, want_pla
     return out, plan
 
 
-@pytest.mark.parametrize("waves", [16, 8])
+@pytest.mark.parametrize("waves", [16, 8, "16-long"])
 @pytest.mark.parametrize("dt", [np.float32, np.int32])
 def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
-    _lib.set_tunable("lds_waves", waves)
+    # "16-long": the 16-token-batch geometry the plan picks for long slots, forced here for every shape
+    old_long = _lib.set_tunable("lds_long_slots", 1 if waves == "16-long" else 0)
+    _lib.set_tunable("lds_waves", 16 if waves == "16-long" else waves)
     # (rows, cols, h, mean degree): widths around the 64-feature slice, ragged tiles, one and many chunks, a 5 000-entry row
     for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),
                              (4000, 4000, 33, 30), (2000, 9000, 300, 25)):
@@ -72,6 +74,7 @@ def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
         got, plan = product(rowptr, col, x)
         assert got.tobytes() == want.tobytes(), (waves, dt, n, ncols, h)
         assert plan["nnz"] == len(col) and plan["tokens"] >= len(col)
+    _lib.set_tunable("lds_long_slots", old_long)
 
 
 def test_empty_rows_and_empty_matrix(rng, lds_forced):

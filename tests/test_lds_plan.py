@@ -52,7 +52,7 @@ def test_plan_walk_equals_oracle(emul, dtype, shape):
     else:
         x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)  # sums wrap
     want = oracle.spmm_csr(rowptr, col, None, x)
-    for nw, ka, batch in ((8, 192, 16), (16, 96, 8)):   # the two kernel geometries (scripts/gen_lds_kernel.py GEOS)
+    for nw, ka, batch in ((8, 192, 16), (16, 96, 8), (16, 80, 16)):   # the kernel geometries (scripts/gen_lds_kernel.py GEOS, GEO_L16)
         got, stats = _run(emul, rowptr, col, ncols, x, ka=ka, batch=batch, nw=nw)
         assert got.tobytes() == want.tobytes()           # bit-exact, floats included (stored-order sums)
         assert stats[2] % batch == 0 and stats[3] == stats[2] + 4096 + 64   # slack the kernel may read past the last token
