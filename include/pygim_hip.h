@@ -29,6 +29,10 @@
  * streams itself (an event after the first product, as bench.py does) and must not
  * pass the flag after writing to X.
  * Scratch buffers are sized on first use (hipMalloc), so capture a product into a hipGraph only after one warm-up call.
+ * A captured graph bakes in the addresses of the slice-major buffer of its capture stream and of the group's scratch
+ * buffers: while such a graph may still be replayed, do not run products on four or more OTHER streams of the same
+ * device (the least recently used slice-major buffer is freed), do not run a LARGER product on the capture stream
+ * (its buffer is re-allocated) and do not free the group -- inference.py --graph 1 keeps to one stream and one shape.
  */
 #ifndef PYGIM_HIP_H
 #define PYGIM_HIP_H

@@ -212,3 +212,34 @@ def test_random_shapes(seed, lds_forced):
     x = features(rng, ncols, h, dt)
     got, _ = product(rowptr, col, x, want_plan=None)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (seed, n, ncols, h)
+
+
+@pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64", "FLT32", "DBL64"])
+def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
+    """lds_mode = 1 with every val_dt (support/common.h:39-60): INT32 / FLT32 take the LDS-staged kernel, the other four keep their
+    kernels -- all equal the oracle (integers bit-exact; floats bit-exact here too: real-valued features, rows of <= 512 entries per
+    panel for the sweep's types, empty rows, one long row)"""
+    from conftest import NP_DTYPES
+
+    npdt = NP_DTYPES[dt]
+    code = {"INT8": _lib.INT8, "INT16": _lib.INT16, "INT32": _lib.INT32, "INT64": _lib.INT64, "FLT32": _lib.FLT32, "DBL64": _lib.DBL64}[dt]
+    n, ncols, h = 2500, 1800, 96
+    rowptr, col = random_csr(rng, n, ncols, 14, empty_frac=0.2, long_rows=[(9, 400)])
+    if np.issubdtype(npdt, np.floating):
+        x = (rng.random((ncols, h)) * 2 - 1).astype(npdt)
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+    else:
+        info = np.iinfo(npdt)
+        x = rng.integers(info.min, info.max, size=(ncols, h), dtype=np.int64, endpoint=True).astype(npdt)
+        vals = rng.integers(info.min, info.max, size=len(col), dtype=np.int64, endpoint=True).astype(npdt)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    for v in (None, vals):
+        hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data], [n], [ncols],
+                               [len(ci)], [1], [h], h)
+        try:
+            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT32", "FLT32")), dt
+            out = np.full((n, h), 77, dtype=npdt)
+            _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+        finally:
+            _lib.group_free(hd)
+        assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (dt, v is not None)
