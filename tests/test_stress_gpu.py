@@ -56,7 +56,10 @@ def test_random_configurations(seed):
              "panel_coop": int(rng.choice([64, 512, 1 << 20])), "long_row_threshold": int(rng.choice([128, 4096])),
              "long_segment": int(rng.choice([64, 512])), "coo_chunk": int(rng.choice([64, 512])),
              "panel_pack": int(rng.choice([0, 1])), "slice_group_bytes": int(rng.choice([0, 1, ncols * 128 * 3, 640 << 20])),
-             "panel_col16": int(rng.choice([0, 1]))}
+             "panel_col16": int(rng.choice([0, 1])),
+             # round 3: the LDS-staged product (INT32 / FLT32, rows of >= 33 features) in all its geometries, beside the others
+             "lds_mode": int(rng.choice([0, 1, 1, 2])), "lds_waves": int(rng.choice([8, 16])),
+             "lds_long_slots": int(rng.choice([0, 1, 128])), "lds_round_tiles": int(rng.choice([0, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
@@ -107,7 +110,8 @@ def test_random_groups(seed):
     knobs = {"fuse_windows": int(rng.choice([0, 1])), "panel_mode": int(rng.choice([0, 1, 2])),
              "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20])),
              "panel_col16": int(rng.choice([0, 1])), "merge_parts": int(rng.choice([0, 1])),
-             "split_unit_pattern": int(rng.choice([0, 1]))}
+             "split_unit_pattern": int(rng.choice([0, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
+             "lds_long_slots": int(rng.choice([0, 1, 128]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
@@ -285,7 +289,8 @@ def test_random_quantised_aggregations(seed):
              "panel_coop": int(rng.choice([64, 512])), "long_row_threshold": int(rng.choice([128, 4096])),
              "panel_pack": int(rng.choice([0, 1, 1])), "panel_col16": int(rng.choice([0, 1])),
              "slice_group_bytes": int(rng.choice([0, 1, 640 << 20])), "merge_parts": int(rng.choice([0, 1, 1])),
-             "fuse_windows": int(rng.choice([0, 1, 1]))}
+             "fuse_windows": int(rng.choice([0, 1, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
+             "lds_long_slots": int(rng.choice([0, 1, 128]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         parts = _col_split(rowptr, col, nrows, ncols, sp_parts)
