@@ -34,7 +34,7 @@ LDS_CYC_PER_TOKEN = 3.9     # CU cycles per stored entry and slice (measured: cl
 LDS_CYC_PER_SLOT = 650      # CU cycles per 64 KiB chunk of X beside the tokens (barrier skew, DMA issue, touches)
 LDS_CYC_FILL = 2300         # CU cycles to land 64 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
 LDS_PAD = 1.085             # tokens incl. batch padding per stored entry (uniform columns)
-LDS_MIN_REUSE = 1.5         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
+LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
 @dataclass

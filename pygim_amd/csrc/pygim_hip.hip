@@ -80,7 +80,7 @@ struct Tunables {
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
     int64_t lds_mode = 0;               // LDS-staged product (k_lds_spmm): 0 = auto (reuse rule), 1 = whenever a part has the plan, 2 = never
-    int64_t lds_min_reuse_x100 = 150;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product
+    int64_t lds_min_reuse_x100 = 110;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product (measured crossing: profiles/r03_exp_lds_share.txt)
     int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)

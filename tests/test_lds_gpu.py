@@ -243,3 +243,19 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         finally:
             _lib.group_free(hd)
         assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (dt, v is not None)
+
+
+def test_denormals_and_infinities_follow_the_cpu_loop(rng, lds_forced):
+    """the assembly inherits the kernel's float mode (denormals kept, round to nearest even): sums of subnormal features stay
+    subnormal exactly as on the CPU, an infinite feature makes its rows infinite"""
+    n, ncols, h = 1500, 1200, 64
+    rowptr, col = random_csr(rng, n, ncols, 10)
+    x = (rng.random((ncols, h), dtype=np.float32) * np.float32(3e-42)).astype(np.float32)   # all subnormal
+    assert np.all(np.abs(x) < np.finfo(np.float32).tiny)
+    x[7, :] = np.inf
+    x[9, 3] = -np.inf
+    got, _ = product(rowptr, col, x)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    both_nan = np.isnan(got) & np.isnan(want)        # inf - inf: a NaN on both sides (its payload is not part of the contract)
+    assert np.array_equal(got.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
+    assert np.any((want != 0) & (np.abs(want) < np.finfo(np.float32).tiny)) and np.any(np.isinf(want))
