@@ -631,8 +631,11 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
 template <typename T>
 int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate, hipStream_t st,
                const void *lds_xs = nullptr, const uint32_t *deq_amax = nullptr, int deq_log2 = 0) {
-    static_assert(sizeof(T) == 4, "4-byte elements");
-    const uint32_t nslices = (w + 63) / 64;
+    static_assert(sizeof(T) == 4 || sizeof(T) == 2, "4-byte elements, or INT16 two to a lane");
+    constexpr uint32_t EPS = 256 / sizeof(T);              // elements of a 256-byte slice
+    constexpr int PVEC = 16 / (int)sizeof(T);
+    const uint32_t w_lanes = (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);
+    const uint32_t nslices = (w + EPS - 1) / EPS;
     const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
     const size_t need = (size_t)rows_pad * nslices * 256;
     KernelTimer kt(g, st, !p.is_extra);
@@ -670,7 +673,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             b->kind = 1;
             const uint64_t threads = (uint64_t)p.ncols * nslices * 16;
             if (threads > 0)
-                hipLaunchKernelGGL((k_slice_pack<T, 4, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
+                hipLaunchKernelGGL((k_slice_pack<T, PVEC, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
                                    (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)rows_pad);
         }
     }
@@ -682,7 +685,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.c = (char *)C;
     a.slice_stride = rows_pad * 256;
     a.ldc_bytes = (uint32_t)((size_t)ldc * sizeof(T));
-    a.w = w;
+    a.w = w_lanes;
     a.nslices = nslices;
     a.ntiles = p.lds_ntiles;
     a.accumulate = accumulate ? 1 : 0;
@@ -695,9 +698,12 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     KernelFn fn = nullptr;
     const bool long16 = p.lds_nw == 16 && p.lds_batch == LDS_L16_BATCH;   // the 16-token-batch geometry (no values)
     if (deq_amax) {
-        if (p.lds_nw != 16 || p.lds_wdelta) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
+        if (p.lds_nw != 16 || p.lds_wdelta || sizeof(T) != 4) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
         if constexpr (std::is_same<T, float>::value) fn = long16 ? k_lds_spmm_f32_w16b_deq : k_lds_spmm_f32_w16_deq;
-        else fn = long16 ? k_lds_spmm_i32_w16b_deq : k_lds_spmm_i32_w16_deq;
+        else if constexpr (std::is_same<T, int32_t>::value) fn = long16 ? k_lds_spmm_i32_w16b_deq : k_lds_spmm_i32_w16_deq;
+    } else if constexpr (sizeof(T) == 2) {
+        if (p.lds_nw != 16) return fail(PYGIM_ERR_INVALID, "internal: INT16 LDS-staged product needs the 16-wave plan");
+        fn = long16 ? k_lds_spmm_i16_w16b : (p.lds_wdelta ? k_lds_spmm_i16_w16_val : k_lds_spmm_i16_w16);
     } else if (long16) {
         if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16b;
         else fn = k_lds_spmm_i32_w16b;
@@ -731,11 +737,14 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     return 0;
 }
 
-template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc) {
-    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return false;
+template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc, const void *C) {
+    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int16_t>::value)) return false;
+    if constexpr (sizeof(T) == 2) {  // two features to a lane: whole lanes, dword-aligned rows of C, the 16-wave plan
+        if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || p.lds_nw != 16) return false;
+    }
     if (!p.lds_tiles || g_tune.lds_mode == 2 || (p.vals != nullptr) != (p.lds_wdelta != 0) || g->deq_out || g->pre_xs) return false;
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode == 1 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0)) return false;  // another kernel was asked for by name
-    if ((int64_t)w < g_tune.lds_min_width) return false;
+    if ((int64_t)((size_t)w * sizeof(T) / 4) < g_tune.lds_min_width) return false;   // (lanes: 4-byte units of a row)
     if ((uint64_t)ldc * sizeof(T) >= (1ull << 32)) return false;
     return true;
 }
@@ -746,8 +755,8 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     const T *x = (const T *)X;
     T *c = (T *)C;
     const uint32_t ww = (uint32_t)w;
-    if constexpr (sizeof(T) == 4) {
-        if (want_lds<T>(g, p, ww, ldc)) return launch_lds<T>(g, p, x, ldx, c, ldc, ww, accumulate, st);
+    if constexpr (sizeof(T) == 4 || std::is_same<T, int16_t>::value) {
+        if (want_lds<T>(g, p, ww, ldc, C)) return launch_lds<T>(g, p, x, ldx, c, ldc, ww, accumulate, st);
     }
     // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
     if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
@@ -1116,8 +1125,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
 // One-time: the schedule of the LDS-staged product (lds_plan.hpp) for parts it pays for.  Built on the host from
 // the row pointers and column ids (the reference balances its DPU row ranges on the host too, spmm_mul_csr.c:118-259).
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint) {
-    if (g_tune.lds_mode == 2 || es != 4 || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
-    if (p.vals && g_tune.lds_waves != 16) return 0;  // the valued kernels exist for the 16-wave geometry
+    if (g_tune.lds_mode == 2 || (es != 4 && es != 2) || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
+    if ((p.vals || es == 2) && g_tune.lds_waves != 16) return 0;  // the valued and the INT16 kernels exist for the 16-wave geometry
     if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
     LdsGeometry geo;
     geo.NW = g_tune.lds_waves == 16 ? 16 : 8;
@@ -1126,7 +1135,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     geo.BATCH = lds_batch(geo.NW);
     // tiles sized so that one product of the group's width runs as whole rounds of workgroups (lds_plan.hpp)
     if (g_tune.lds_round_tiles && h_hint > 0)
-        geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint + 63) / 64), (uint32_t)std::max(g_ctx.cu_count, 1));
+        geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1));
     if (g_tune.lds_mode == 0 &&
         lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
         return 0;
@@ -1141,7 +1150,13 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     std::vector<uint32_t> h_val;
     if (p.vals) {
         h_val.resize((size_t)p.nnz);
-        if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+        if (es == 4) {
+            if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+        } else {  // INT16: the value in both halves of its dword (packed multiply)
+            std::vector<uint16_t> v16((size_t)p.nnz);
+            if (hipMemcpy(v16.data(), p.vals, v16.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+            for (size_t i = 0; i < v16.size(); i++) h_val[i] = (uint32_t)v16[i] * 0x10001u;
+        }
     }
     LdsPlanHost plan;
     lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
@@ -1154,7 +1169,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         gl.KA = LDS_L16_KA;
         gl.BATCH = LDS_L16_BATCH;
         gl.rows_per_tile = g_tune.lds_round_tiles && h_hint > 0
-                               ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)((h_hint + 63) / 64), (uint32_t)std::max(g_ctx.cu_count, 1))
+                               ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1))
                                : 0;
         const uint32_t r_now = geo.rows_per_tile ? geo.rows_per_tile : geo.NW * geo.KA, r_new = gl.rows_per_tile ? gl.rows_per_tile : gl.NW * gl.KA;
         if (r_new >= r_now) {  // no more tiles than before

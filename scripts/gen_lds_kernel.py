@@ -344,7 +344,7 @@ struct LdsArgs {
     const char *xs;           // slice-major X: [nslices][ncols_pad][64] elements of 4 bytes
     char *c;                  // row-major result
     uint64_t slice_stride;    // bytes between two slices of xs
-    uint32_t ldc_bytes, w, nslices, ntiles, accumulate, xcd_group;
+    uint32_t ldc_bytes, w, nslices, ntiles, accumulate, xcd_group;   // w: width of the product in LANES (4-byte units)
     uint32_t wdelta;          // weighted kernels: bytes from a token to its value (the value stream follows the token stream)
     const uint32_t *deq_amax; // dequantising kernels: bits of max|x| (device), and the quantiser's log2 range
     int deq_log2;
@@ -406,9 +406,13 @@ def main():
         variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
+    # INT16: a lane holds TWO features (a slice is 128 features = the same 256 bytes), packed 16-bit adds wrap each half on its own
+    variants.append(("k_lds_spmm_i16_w16", "v_pk_add_u16", 16, 0, "INT16, unit weights: 128 features per slice, packed modular sums"))
+    variants.append(("k_lds_spmm_i16_w16_val", "v_pk_add_u16", 16, 0, "INT16 with values (the value in both halves of its dword)", "v_pk_mul_lo_u16"))
     variants.append(("k_lds_spmm_f32_w16_deq", "v_add_f32", 16, 0, "FLT32 quantised features, the store dequantises: out = sum * scale", None, "f32"))
     variants.append(("k_lds_spmm_i32_w16_deq", "v_add_u32", 16, 0, "INT32 quantised features, the store dequantises: out = float(sum) * scale", None, "i32"))
-    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32")):
+    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32"),
+                          ("i16", "v_pk_add_u16", None)):
         variants.append((f"k_lds_spmm_{base}_w16b" + ("_deq" if deq else ""), op, "L16", 0,
                          "the same for plans with long slots: 16-token batches, 80 accumulators per wave", None, deq))
     for v in variants:

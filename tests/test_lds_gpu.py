@@ -216,8 +216,8 @@ def test_random_shapes(seed, lds_forced):
 
 @pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64", "FLT32", "DBL64"])
 def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
-    """lds_mode = 1 with every val_dt (support/common.h:39-60): INT32 / FLT32 take the LDS-staged kernel, the other four keep their
-    kernels -- all equal the oracle (integers bit-exact; floats bit-exact here too: real-valued features, rows of <= 512 entries per
+    """lds_mode = 1 with every val_dt (support/common.h:39-60): INT16 / INT32 / FLT32 take the LDS-staged kernel, the other three
+    keep their kernels -- all equal the oracle (integers bit-exact; floats bit-exact here too: real-valued features, rows of <= 512 entries per
     panel for the sweep's types, empty rows, one long row)"""
     from conftest import NP_DTYPES
 
@@ -237,7 +237,7 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data], [n], [ncols],
                                [len(ci)], [1], [h], h)
         try:
-            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT32", "FLT32")), dt
+            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32")), dt
             out = np.full((n, h), 77, dtype=npdt)
             _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
         finally:
@@ -259,3 +259,25 @@ def test_denormals_and_infinities_follow_the_cpu_loop(rng, lds_forced):
     both_nan = np.isnan(got) & np.isnan(want)        # inf - inf: a NaN on both sides (its payload is not part of the contract)
     assert np.array_equal(got.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
     assert np.any((want != 0) & (np.abs(want) < np.finfo(np.float32).tiny)) and np.any(np.isinf(want))
+
+
+def test_int16_two_features_to_a_lane(rng, lds_forced):
+    """INT16 on the LDS-staged kernel: a lane holds two features (a 256-byte slice is 128 of them), packed 16-bit adds and
+    multiplies wrap each half on its own -- modular at the element width, as support/common.h:39-60 asks; odd widths or rows of C
+    that are not dword-aligned keep the sweep (and the same result)"""
+    info = np.iinfo(np.int16)
+    for n, ncols, h in ((3000, 2500, 100), (1700, 5000, 256), (2000, 3000, 66), (2500, 2000, 300), (2000, 1500, 101)):
+        rowptr, col = random_csr(rng, n, ncols, 20, empty_frac=0.2, long_rows=[(1, 3000)])
+        x = rng.integers(info.min, info.max, size=(ncols, h), endpoint=True).astype(np.int16)
+        vals = rng.integers(info.min, info.max, size=len(col), endpoint=True).astype(np.int16)
+        rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+        for v in (None, vals):
+            hd = _lib.group_create(_lib.CSR, _lib.INT16, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data],
+                                   [n], [ncols], [len(ci)], [1], [h], h)
+            try:
+                assert _lib.group_lds_plan(hd)["tiles"] > 0
+                out = np.full((n, h), 77, dtype=np.int16)
+                _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+            finally:
+                _lib.group_free(hd)
+            assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (n, h, v is not None)
