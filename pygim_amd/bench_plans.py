@@ -402,6 +402,10 @@ def build(env):
             self.hw = h // world
             self.f0 = rank * self.hw
             self.hip = ctypes.CDLL("libamdhip64.so")
+            # hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, kind, stream)
+            self.hip.hipMemcpy2DAsync.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                  ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+            self.hip.hipMemcpy2DAsync.restype = ctypes.c_int
             self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz],
                                               [1], [self.hw], self.hw)]
             self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]

@@ -970,7 +970,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint);
 
-int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0) {
+int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0, bool allow_lds = true) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
     if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PYGIM_ERR_HIP, "rowptr D2H");
@@ -1119,7 +1119,8 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
             }
         }
     }
-    return build_lds_plan(p, es, d_flag_sorted, st, h_rowptr, h_hint);
+    // (the column blocks of a group that also has its merged matrix run through the merged plan: no second token stream for them)
+    return allow_lds ? build_lds_plan(p, es, d_flag_sorted, st, h_rowptr, h_hint) : 0;
 }
 
 // One-time: the schedule of the LDS-staged product (lds_plan.hpp) for parts it pays for.  Built on the host from
@@ -2000,7 +2001,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
             p.own_vals = false;
         }
         if (!g->all_ones && (rc = split_unit_pattern(p, dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st))) return bail(rc);
-        if ((rc = build_plans(p, es, g->d_flags + 4, st, g->h))) return bail(rc);
+        if ((rc = build_plans(p, es, g->d_flags + 4, st, g->h, /*allow_lds=*/!(g->merged && g_tune.merge_parts)))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;

@@ -97,3 +97,7 @@ int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, ui
     return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals);
 }
 }
+
+extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32_t nslices, uint32_t cus) {
+    return lds_rows_per_tile(nrows, rmax, nslices, cus);
+}

@@ -114,3 +114,20 @@ def test_empty_matrix_and_empty_rows(emul):
     x = np.ones((7, 64), dtype=np.float32)
     got, stats = _run(emul, rowptr, col, 7, x)
     assert not got.any() and stats[1] == 0
+
+
+def test_tile_height_rule_matches_its_python_mirror(emul):
+    """lds_plan.hpp lds_rows_per_tile (tiles x slices fill whole rounds of CUs) and pygim_amd/autotune.py's restatement of it, which
+    the partition chooser prices products with, must agree; spot values from profiles/r03_lds_kernel.md"""
+    from pygim_amd import autotune
+
+    emul.lds_emul_rows_per_tile.restype = ctypes.c_uint32
+    rng = np.random.default_rng(3)
+    for _ in range(400):
+        nrows = int(rng.integers(1, 3_000_000))
+        nsl = int(rng.integers(1, 9))
+        rmax = int(rng.choice([1536, 1280]))
+        assert emul.lds_emul_rows_per_tile(nrows, rmax, nsl, 256) == autotune.lds_rows_per_tile(nrows, nsl, rmax=rmax, cus=256), (nrows, nsl)
+    assert emul.lds_emul_rows_per_tile(232965, 1536, 4, 256) == 1214      # Reddit h = 256: 192 tiles x 4 slices = 3 full rounds
+    assert emul.lds_emul_rows_per_tile(232965, 1536, 2, 256) == 911       # h = 128: 256 tiles x 2 slices = 2 rounds
+    assert emul.lds_emul_rows_per_tile(29471, 1536, 4, 256) == 461        # a 1/8 row share: 64 tiles, one workgroup per CU
