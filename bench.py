@@ -372,7 +372,10 @@ def main():
         # LDS-staged product (pygim_amd/csrc/lds_kernel_gen.hpp): one launch; every stored entry reads its 256-byte row slice
         # of X from LDS (ds_read_b32), the chunks of X are staged L2 -> LDS once per (tile, slice)
         nsl = (my_h + 63) // 64
-        kname = f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16 (ONE launch per product: {lds_info['tiles']} row tiles x {nsl} slices)"
+        # (plans with long slots -- >= 128 tokens per wave and chunk -- take the 16-token-batch form of the kernel, pygim_hip.hip lds_long_slots)
+        long_slots = lds_info["chunk_fills"] > 0 and lds_info["tokens"] / (lds_info["chunk_fills"] * 16) >= 128
+        kname = (f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16{'b' if long_slots else ''} (ONE launch per product: {lds_info['tiles']} row tiles x "
+                 f"{nsl} slices)")
         launches = 1
         staged = lds_info["chunk_fills"] * 65536 * nsl
         on_chip = {"level": "LDS (ds_read_b32, one 256-byte row slice per stored entry and slice)", "gather_bytes": gather,
