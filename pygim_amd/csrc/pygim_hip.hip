@@ -709,7 +709,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
         else fn = k_lds_spmm_i32_w16b;
     } else if constexpr (std::is_same<T, float>::value) {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_f32_w16_val : k_lds_spmm_f32_w16) : k_lds_spmm_f32_w8;
-        if (p.lds_nw == 16 && !p.lds_wdelta && !long16) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py)
+#ifdef PYGIM_LDS_ABLATE
+        if (p.lds_nw == 16 && !p.lds_wdelta && !long16) {  // timing experiments (wrong results, scripts/gen_lds_kernel.py; make ablate)
             switch (g_tune.lds_ablate) {
                 case 6: fn = k_lds_spmm_f32_w16_ab6; break;
                 case 7: fn = k_lds_spmm_f32_w16_ab7; break;
@@ -719,6 +720,9 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
                 default: break;
             }
         }
+#else
+        if (g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate needs the ablation build (make -C pygim_amd/csrc ablate)");
+#endif
     } else {
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }

@@ -422,10 +422,15 @@ def main():
         g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq))
+        guard = "_ab" in name   # ablation builds (timing experiments, wrong results) only with -DPYGIM_LDS_ABLATE (make ablate)
+        if guard:
+            text += "\n#ifdef PYGIM_LDS_ABLATE"
         text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,
                               piece=g.pieces * 1024,
                               scale_expr=("__builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(*a.deq_amax) * 2.0f / (float)(1u << a.deq_log2)))"
                                           if deq else "0u"))
+        if guard:
+            text += "#endif  // PYGIM_LDS_ABLATE\n"
     text += "\n}  // namespace pygim\n"
     with open(out, "w") as f:
         f.write(text)
