@@ -127,6 +127,7 @@ struct Part {
     // LDS-staged product (lds_plan.hpp): token streams and tile table on the device; lds_tiles == nullptr: no such plan
     uint32_t *lds_tok = nullptr, *lds_nb = nullptr, *lds_chunks = nullptr, *lds_rowmap = nullptr;
     LdsTile *lds_tiles = nullptr;
+    int cols_sorted = -1;   // stored order inside every row is column order: -1 = not checked yet, 0 / 1
     uint32_t lds_ntiles = 0, lds_nw = 8, lds_batch = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
     uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
@@ -1014,6 +1015,7 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
                                p.colind, (uint32_t)p.nrows, d_flag_sorted);
             if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
                 return fail(PYGIM_ERR_HIP, "sortedness check");
+            p.cols_sorted = unsorted ? 0 : 1;
             if (unsorted) worth = false;
         }
         if (!worth) {
@@ -1144,12 +1146,15 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     if (g_tune.lds_mode == 0 &&
         lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
         return 0;
-    int unsorted = 0;
-    if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
-    hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr, p.colind,
-                       (uint32_t)p.nrows, d_flag_sorted);
-    if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "sortedness check");
-    if (unsorted) return 0;  // stored order inside a row must be column order for the chunk walk
+    if (p.cols_sorted < 0) {  // (the panel plan may have asked already)
+        int unsorted = 0;
+        if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
+        hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr, p.colind,
+                           (uint32_t)p.nrows, d_flag_sorted);
+        if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "sortedness check");
+        p.cols_sorted = unsorted ? 0 : 1;
+    }
+    if (!p.cols_sorted) return 0;  // stored order inside a row must be column order for the chunk walk
     std::vector<uint32_t> h_col((size_t)p.nnz);
     if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
     std::vector<uint32_t> h_val;
