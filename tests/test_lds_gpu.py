@@ -67,7 +67,7 @@ def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
     _lib.set_tunable("lds_waves", 16 if waves == "16-long" else waves)
     # (rows, cols, h, mean degree): widths around the 64-feature slice, ragged tiles, one and many chunks, a 5 000-entry row
     for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),
-                             (4000, 4000, 33, 30), (2000, 9000, 300, 25)):
+                             (4000, 4000, 33, 30), (2000, 9000, 300, 25), (1500, 300, 64, 250)):   # (the last: hundreds of entries per row and chunk)
         rowptr, col = random_csr(rng, n, ncols, avg, long_rows=[(0, 5000)] if n > 100 else ())
         x = features(rng, ncols, h, dt)
         want = oracle.spmm_csr(rowptr, col, None, x)
