@@ -16,6 +16,7 @@
 #include "lds_kernel_gen.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -718,6 +719,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
                 case 10: fn = k_lds_spmm_f32_w16_ab10; break;
                 case 11: fn = k_lds_spmm_f32_w16_ab11; break;
                 case 12: fn = k_lds_spmm_f32_w16_ab12; break;
+                case 15: fn = k_lds_spmm_f32_w16_ab15; break;
+                case 16: fn = k_lds_spmm_f32_w16_ab16; break;
                 default: break;
             }
         }
@@ -729,11 +732,13 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     }
     if (deq_amax && g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate is a timing experiment of the plain kernel");
     {
-        static std::set<KernelFn> attr_done;
+        static std::set<std::pair<int, KernelFn>> attr_done;   // (the attribute is per device)
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lk(g_ctx.mu);
-        if (!attr_done.count(fn)) {
+        if (!attr_done.count({dev, fn})) {
             HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-            attr_done.insert(fn);
+            attr_done.insert({dev, fn});
         }
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(p.lds_nw * 64), LDS_BYTES, st, a);
@@ -852,11 +857,14 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
                 const uint32_t blocks = std::min(p.n_spmv_units, cu);
 #define PYGIM_SPMV_LDS(W, HV)                                                                                                  \
     {                                                                                                                          \
-        static bool attr_set = false;                                                                                          \
-        if (!attr_set) {                                                                                                       \
+        static std::atomic<uint64_t> attr_devs{0};   /* the attribute is per device: one bit per device ordinal */            \
+        int dev_ = 0;                                                                                                          \
+        HIP_TRY(hipGetDevice(&dev_));                                                                                          \
+        const uint64_t bit_ = 1ull << (dev_ & 63);                                                                             \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                                             \
             HIP_TRY(hipFuncSetAttribute((const void *)k_spmv_lds<T, W, HV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                         (int)(LDS_TOTAL + 64)));                                                               \
-            attr_set = true;                                                                                                   \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                                               \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_spmv_lds<T, W, HV>), dim3(blocks), dim3(1024), shmem, st, p.d_spmv_units, p.n_spmv_units, ir, ib, \
                            il, p.col16, (const T *)p.vals, x, ldx, part, (uint32_t)p.nrows, (uint32_t)panel_lds, F16, merge4); \

@@ -13,6 +13,14 @@ formats are plain numpy / scipy / csv / pickle -- and rebuilds the same ``adj_t`
                                          (+ the inverse edges where the dataset's meta says add_inverse_edge)
     generic                              <datadir>/<name>/adj.npz                       scipy.sparse.save_npz of the adjacency
 
+    processed caches                     <root>/processed/data.pt | geometric_data_processed.pt: what the PyG / OGB dataset
+                                         classes torch.save after their first run -- ``(Data, slices)`` pickles of
+                                         torch_geometric objects (PyG 1.x / 2.0-2.3) or ``(dict, slices, class)``
+                                         (PyG >= 2.4).  Read WITHOUT torch_geometric: a restricted unpickler rebuilds
+                                         tensors and plain containers and turns every torch_geometric / torch_sparse /
+                                         ogb class into an inert attribute bag (``load_processed``); anything else
+                                         (``os.system`` ...) is refused.  Used when the raw files are gone.
+
 ``adj_t`` is the TRANSPOSED adjacency in CSR (row = target, col = source, columns sorted), which is what
 ``T.ToSparseTensor`` stores.  Returns None when the files are absent; the drivers then fall back to the seeded
 synthetic graph of the dataset's shape (no network on the GPU box).
@@ -97,6 +105,137 @@ def _generic(root):
     return _csr_t(a.row, a.col, int(a.shape[0]), coalesce=False)
 
 
+# ---------------------------------------------------------------------------
+# processed/*.pt of the PyG / OGB dataset classes, without those packages
+# ---------------------------------------------------------------------------
+_STUB_PREFIXES = ("torch_geometric", "torch_sparse", "ogb")
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"),
+    ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "int"), ("builtins", "float"),
+    ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"), ("builtins", "complex"), ("builtins", "slice"),
+    ("builtins", "object"), ("_codecs", "encode"), ("copyreg", "_reconstructor"),
+    ("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+}
+
+
+class _Bag:
+    """stands in for any torch_geometric / torch_sparse / ogb object: keeps the pickled state, runs none of its code"""
+
+    def __init__(self, *args, **kwargs):
+        self.__dict__["_args"] = args
+        self.__dict__.update(kwargs)
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):  # (dict state, slots state)
+            state = {**(state[0] or {}), **state[1]}
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+
+_bag_classes: dict = {}
+
+
+def _bag_class(module, name):
+    key = (module, name)
+    if key not in _bag_classes:
+        _bag_classes[key] = type(name, (_Bag,), {"__module__": "pygim_amd.datasets", "_origin": f"{module}.{name}"})
+    return _bag_classes[key]
+
+
+class _PygUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.split(".")[0] in _STUB_PREFIXES:
+            return _bag_class(module, name)
+        # tensor / storage rebuilders, dtypes, Size -- and nothing else of torch
+        if (module == "torch._utils" and name.startswith("_rebuild_")) or (module == "torch._tensor" and name.startswith("_rebuild_")) or \
+                (module == "torch" and (name.endswith("Storage") or name in ("Size", "Tensor", "device", "dtype") or
+                                        isinstance(getattr(__import__("torch"), name, None), __import__("torch").dtype))) or \
+                (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage")) or \
+                (module == "torch.serialization" and name == "_get_layout"):
+            return super().find_class(module, name)
+        if (module, name) in _SAFE_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"processed dataset file refers to {module}.{name}: not a tensor, a container or a PyG object")
+
+
+class _PickleShim:
+    """what torch.load expects of ``pickle_module``"""
+    __name__ = "pickle"
+    Unpickler = _PygUnpickler
+
+    @staticmethod
+    def load(f, **kwargs):
+        return _PygUnpickler(f, **kwargs).load()
+
+
+def _walk(obj, found, depth=0):
+    """collect named tensors / sizes from dicts, attribute bags and sequences (first hit of a name wins)"""
+    import torch
+
+    if depth > 6 or obj is None:
+        return
+    if isinstance(obj, _Bag):
+        obj = obj.__dict__
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(k, str) and (torch.is_tensor(v) or isinstance(v, (int, tuple, list)) and k in ("num_nodes", "_num_nodes", "_sparse_sizes")):
+                found.setdefault(k.lstrip("_") if k in ("_num_nodes",) else k, v)
+        for k, v in obj.items():
+            if isinstance(v, (dict, _Bag)):
+                _walk(v, found, depth + 1)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj[:4]:
+            if isinstance(v, (dict, _Bag)):
+                _walk(v, found, depth + 1)
+
+
+def load_processed(path):
+    """(rowptr, col, n) of ``adj_t`` from one processed ``.pt`` of a single-graph PyG dataset (Planetoid, Reddit,
+    PygNodePropPredDataset ...), as ``T.ToSparseTensor`` would build it from ``data.edge_index`` (row = target, col = source,
+    sorted, duplicates kept) -- or from a stored ``adj_t`` when the cache was made with ``pre_transform=ToSparseTensor``."""
+    import torch
+
+    obj = torch.load(path, map_location="cpu", pickle_module=_PickleShim, weights_only=False)
+    data = obj[0] if isinstance(obj, (tuple, list)) and obj else obj   # (data, slices[, class]): one graph -> slices are trivial
+    found: dict = {}
+    _walk(data, found)
+    n = found.get("num_nodes")
+    if isinstance(n, (tuple, list)):
+        n = n[0] if n else None
+    if torch.is_tensor(n):
+        n = int(n.reshape(-1)[0]) if n.numel() else None
+    if "edge_index" in found and found["edge_index"].dim() == 2 and found["edge_index"].shape[0] == 2:
+        ei = found["edge_index"].numpy().astype(np.int64)
+        if n is None:
+            n = int(found["x"].shape[0]) if "x" in found and found["x"].dim() >= 1 else int(ei.max(initial=-1)) + 1
+        return _csr_t(ei[0], ei[1], int(n), coalesce=False)
+    if "_col" in found and ("_rowptr" in found or "_row" in found):  # torch_sparse.SparseStorage of adj_t
+        col = found["_col"].numpy().astype(np.int64)
+        sizes = found.get("_sparse_sizes")
+        if "_rowptr" in found and found["_rowptr"] is not None:
+            rowptr = found["_rowptr"].numpy().astype(np.int64)
+            return rowptr, col, int(sizes[0]) if sizes else len(rowptr) - 1
+        row = found["_row"].numpy().astype(np.int64)
+        n = int(sizes[0]) if sizes else int(max(row.max(initial=-1), col.max(initial=-1))) + 1
+        return _csr_t(col, row, n, coalesce=False)
+    return None
+
+
+def _processed(root, name):
+    sub = {True: [os.path.join(root, name.replace("-", "_")), root]}.get(name.startswith("ogbn-"), [os.path.join(root, name), root])
+    for d in sub:
+        for fname in ("geometric_data_processed.pt", "data.pt"):
+            path = os.path.join(d, "processed", fname)
+            if os.path.isfile(path):
+                got = load_processed(path)
+                if got is not None:
+                    return got
+    return None
+
+
 def load_adjacency(datadir, name):
     """(rowptr int64 [n+1], col int64 [nnz], n) of ``adj_t`` for dataset ``name`` under ``datadir`` (the directory layout
     the reference's ``osp.join(args.datadir, args.dataset)`` roots produce), or None when nothing usable is there."""
@@ -111,7 +250,9 @@ def load_adjacency(datadir, name):
         got = _ogb(root, name)
     else:
         got = None
+    if got is None:
+        got = _processed(root, name)
     return got if got is not None else _generic(root)
 
 
-__all__ = ["load_adjacency", "OGB_ADD_INVERSE"]
+__all__ = ["load_adjacency", "load_processed", "OGB_ADD_INVERSE"]

@@ -132,6 +132,11 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
             if 7 not in AB:
                 a(f"global_load_lds_dwordx4 {VL16}, {PA} offset:{(i % 4) * 1024}")
 
+    if 15 in AB:   # experiment: static priority for the later-dispatched half of the workgroup (waves NW/2 ..)
+        a("s_cmp_ge_u32 %[wave], " + str(NW // 2))
+        a("s_cbranch_scc0 L_noprio_%=")
+        a("s_setprio 1")
+        a("L_noprio_%=:")
     a(f"s_mov_b32 {CIDN}, %[cid0]")
     dma(CIDN, BUF)
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -223,6 +228,8 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
         if g.weighted:   # product and sum round separately, as in the CPU loop (no FMA)
             for i in range(BATCH):
                 a(f"{op_mul} v{XS[x] + i}, s{WGT[r] + i}, v{XS[x] + i}")
+        if 16 in AB:   # experiment: the accumulate phase at raised priority
+            a("s_setprio 2")
         a(f"s_set_gpr_idx_on s{TOK[r]}, gpr_idx(SRC1,DST)")
         a(f"{op_add} v{ACC0}, v{XS[x]}, v{ACC0}")
         for i in range(1, BATCH):
@@ -230,6 +237,8 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
                 a(f"s_set_gpr_idx_idx s{TOK[r] + i}")
             a(f"{op_add} v{ACC0}, v{XS[x] + i}, v{ACC0}")
         a("s_set_gpr_idx_off")
+        if 16 in AB:
+            a("s_setprio 0")
 
     def count_and_exit(r_next, x_next):
         a(f"s_sub_u32 {NBL}, {NBL}, 1")               # SCC = borrow: no batch was left
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
         :
         : [lane] "v"(lane), [tok] "s"(tok_s), [cid0] "s"(cid0), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
-          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale)
+          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale), [wave] "s"(wave)
         : %(clobbers)s, "vcc", "scc", "memory");
 }
 """
@@ -402,7 +411,7 @@ def main():
     for nw in (8, 16):
         variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
         variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
-    for ab in (6, 7, 10, 11, 12):
+    for ab in (6, 7, 10, 11, 12, 15, 16):
         variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))

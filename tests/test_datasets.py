@@ -98,3 +98,136 @@ def test_driver_reads_datadir(tmp_path):
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "Cora Dataset Info: Node(12), Edge(24)" in r.stdout and "[INFO] Cora: adj_t read from" in r.stdout
+
+
+# ---------------------------------------------------------------------------
+# processed/*.pt of the PyG / OGB dataset classes, read without those packages
+# ---------------------------------------------------------------------------
+def _fake_pyg_modules():
+    """minimal stand-ins for the classes whose pickles the processed files hold -- only to WRITE the test files; they are
+    removed from sys.modules again before the loader runs"""
+    import types
+
+    mods = {}
+    for name in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage"):
+        mods[name] = types.ModuleType(name)
+
+    class Data:          # PyG 1.x: attributes in __dict__; PyG 2.0-2.3: __dict__ = {'_store': GlobalStorage}
+        pass
+
+    class GlobalStorage:
+        pass
+
+    Data.__module__ = "torch_geometric.data.data"
+    Data.__qualname__ = "Data"
+    GlobalStorage.__module__ = "torch_geometric.data.storage"
+    GlobalStorage.__qualname__ = "GlobalStorage"
+    mods["torch_geometric.data.data"].Data = Data
+    mods["torch_geometric.data.storage"].GlobalStorage = GlobalStorage
+    return mods, Data, GlobalStorage
+
+
+def _write_processed(path, style, edge_index, n, with_num_nodes):
+    import torch
+
+    mods, Data, GlobalStorage = _fake_pyg_modules()
+    x = torch.zeros(n, 3)
+    fields = {"x": x, "edge_index": edge_index, "y": torch.zeros(n, dtype=torch.long)}
+    if with_num_nodes:
+        fields["num_nodes"] = n
+        del fields["x"]
+    slices = {k: torch.tensor([0, v.shape[-1] if k == "edge_index" else v.shape[0]]) for k, v in fields.items() if torch.is_tensor(v)}
+    sys.modules.update(mods)
+    try:
+        if style == "v1":
+            d = Data()
+            d.__dict__.update(fields)
+            torch.save((d, slices), path)
+        elif style == "v2":
+            d = Data()
+            st = GlobalStorage()
+            st.__dict__["_mapping"] = fields
+            st.__dict__["_parent"] = d          # (a cycle, as the real pickles have)
+            d.__dict__["_store"] = st
+            torch.save((d, slices), path)
+        else:                                   # PyG >= 2.4: (data.to_dict(), slices, data.__class__)
+            torch.save((fields, slices, Data), path)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("style", ["v1", "v2", "v3"])
+@pytest.mark.parametrize("with_num_nodes", [False, True])
+def test_processed_pt_without_torch_geometric(tmp_path, style, with_num_nodes):
+    import torch
+
+    rng = np.random.default_rng(11)
+    n, e = 37, 300
+    src, dst = rng.integers(0, n - 2, size=e), rng.integers(0, n - 2, size=e)   # the last two nodes are isolated
+    ei = torch.from_numpy(np.stack([src, dst])).long()
+    proc = tmp_path / "Reddit" / "processed"
+    proc.mkdir(parents=True)
+    _write_processed(str(proc / "data.pt"), style, ei, n, with_num_nodes)
+    assert "torch_geometric" not in sys.modules
+    rowptr, col, nn = datasets.load_adjacency(str(tmp_path), "Reddit")
+    want_ptr, want_col = _csr_with_dups(src, dst, n)
+    assert nn == n and np.array_equal(rowptr, want_ptr) and np.array_equal(col, want_col)
+
+
+def test_processed_pt_ogb_layout_and_stored_adj_t(tmp_path):
+    """OGB keeps <root>/<name_>/processed/geometric_data_processed.pt; a cache made with pre_transform=ToSparseTensor holds
+    adj_t (torch_sparse.SparseTensor -> SparseStorage with _rowptr / _col) instead of edge_index"""
+    import types
+    import torch
+
+    rng = np.random.default_rng(12)
+    n, e = 25, 120
+    src, dst = rng.integers(0, n, size=e), rng.integers(0, n, size=e)
+    want_ptr, want_col = _csr_with_dups(src, dst, n)
+    mod = types.ModuleType("torch_sparse")
+    sub = types.ModuleType("torch_sparse.tensor")
+    sub2 = types.ModuleType("torch_sparse.storage")
+
+    class SparseTensor:
+        pass
+
+    class SparseStorage:
+        pass
+
+    SparseTensor.__module__, SparseTensor.__qualname__ = "torch_sparse.tensor", "SparseTensor"
+    SparseStorage.__module__, SparseStorage.__qualname__ = "torch_sparse.storage", "SparseStorage"
+    sub.SparseTensor, sub2.SparseStorage = SparseTensor, SparseStorage
+    st = SparseStorage()
+    st.__dict__.update({"_row": None, "_rowptr": torch.from_numpy(want_ptr), "_col": torch.from_numpy(want_col), "_value": None,
+                        "_sparse_sizes": (n, n)})
+    adj = SparseTensor()
+    adj.__dict__["storage"] = st
+    proc = tmp_path / "ogbn-arxiv" / "ogbn_arxiv" / "processed"
+    proc.mkdir(parents=True)
+    mods = {"torch_sparse": mod, "torch_sparse.tensor": sub, "torch_sparse.storage": sub2}
+    sys.modules.update(mods)
+    try:
+        torch.save(({"adj_t": adj, "num_nodes": n}, None, None), str(proc / "geometric_data_processed.pt"))
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    rowptr, col, nn = datasets.load_adjacency(str(tmp_path), "ogbn-arxiv")
+    assert nn == n and np.array_equal(rowptr, want_ptr) and np.array_equal(col, want_col)
+
+
+def test_processed_pt_refuses_foreign_code(tmp_path):
+    """the reader is not a general unpickler: a file that names anything but tensors, containers and PyG objects is refused"""
+    import torch
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    path = tmp_path / "data.pt"
+    torch.save((Evil(), None), str(path))
+    with pytest.raises(pickle.UnpicklingError):
+        datasets.load_processed(str(path))
