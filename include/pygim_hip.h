@@ -210,12 +210,12 @@ int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
- * "split_unit_pattern", "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
+ * "split_unit_pattern", "narrow_vals" (INT64 / DBL64 values that all fit int32 / float exactly are streamed in 4 bytes), "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
  * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),
  * "lds_round_tiles", "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
- * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, merge_parts at creation) are read when a group is created; the others per product.  */
+ * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, narrow_vals, merge_parts at creation) are read when a group is created; the others per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);
 
 #ifdef __cplusplus

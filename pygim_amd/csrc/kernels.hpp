@@ -626,7 +626,16 @@ __device__ __forceinline__ u32x4_t gather_raw(const char *__restrict__ xbase, ui
 //   DEQ = true (the conv layers' fused quantise -> aggregate -> dequantise, models/quantize.py:20-42): an item that is
 //   the LAST of its row (bit 30 of its length word: no later panel holds entries of the row) stores
 //   float(sum) * scale to the float matrix Cf instead of the running sum to C.
-template <typename T, int VEC, int AMODE, bool HAS_VALS, bool COOP, bool DEQ>
+// Stored values of the sweep: HAS_VALS 0 = none (all ones), 1 = values of the element type, 2 = NARROW values -- an 8-byte
+// element type whose values are all exactly representable in 4 bytes (double <- float, int64 <- int32: checked at group
+// creation, k_narrow_vals) streams half the value bytes per slice; the widening conversion is exact, so results do not change.
+template <typename T> struct NarrowOf { typedef T type; };
+template <> struct NarrowOf<double> { typedef float type; };
+template <> struct NarrowOf<int64_t> { typedef int32_t type; };
+template <typename T, int HV> struct SweepVal { typedef T type; };
+template <typename T> struct SweepVal<T, 2> { typedef typename NarrowOf<T>::type type; };
+
+template <typename T, int VEC, int AMODE, int HAS_VALS, bool COOP, bool DEQ>
 __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__restrict__ item_row,
                                             const uint32_t *__restrict__ item_begin,
                                             const uint32_t *__restrict__ item_len, uint32_t nitems,
@@ -717,8 +726,10 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     // chunk: one 128-byte request per group instead of four 32-byte ones), then consumed in four
     // batches of 8 gathers.  The next chunk is requested before the current one is gathered.
     uint32_t c4[4], c4n[4];
-    T v4[4], v4n[4];
-    auto load_chunk = [&](uint32_t cbase, uint32_t (&cc)[4], T (&vv)[4]) {
+    using VT = typename SweepVal<T, HAS_VALS>::type;
+    const VT *valsv = reinterpret_cast<const VT *>(vals);
+    VT v4[4], v4n[4];
+    auto load_chunk = [&](uint32_t cbase, uint32_t (&cc)[4], VT (&vv)[4]) {
         const uint32_t base = cbase + 4u * (uint32_t)li;
         if constexpr (AMODE == 3) {
             // 16-bit ids relative to the first column of this launch's panel (same entry order as colind):
@@ -741,12 +752,12 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
         }
         if constexpr (HAS_VALS) {
             if (base + 4u <= len) {
-                using V4 = typename Vec4U<T>::type;
-                const V4 q = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(vals + s + base));
+                using V4 = typename Vec4U<VT>::type;
+                const V4 q = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(valsv + s + base));
                 vv[0] = q[0]; vv[1] = q[1]; vv[2] = q[2]; vv[3] = q[3];
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(vals + s + base + k) : T(0);
+                for (int k = 0; k < 4; k++) vv[k] = (base + k < len) ? __builtin_nontemporal_load(valsv + s + base + k) : VT(0);
             }
         }
     };
@@ -776,10 +787,10 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
                 x[j] = gather_raw<AMODE>(xbase, lane_off, cj[j], row_bytes64, row_bytes);                  \
             if constexpr (HAS_VALS) {                                                                      \
                 T vj[LPR];                                                                                 \
-                vj[0] = bcast8_t<T, 2 * B>(v4[0]); vj[1] = bcast8_t<T, 2 * B>(v4[1]);                      \
-                vj[2] = bcast8_t<T, 2 * B>(v4[2]); vj[3] = bcast8_t<T, 2 * B>(v4[3]);                      \
-                vj[4] = bcast8_t<T, 2 * B + 1>(v4[0]); vj[5] = bcast8_t<T, 2 * B + 1>(v4[1]);              \
-                vj[6] = bcast8_t<T, 2 * B + 1>(v4[2]); vj[7] = bcast8_t<T, 2 * B + 1>(v4[3]);              \
+                vj[0] = (T)bcast8_t<VT, 2 * B>(v4[0]); vj[1] = (T)bcast8_t<VT, 2 * B>(v4[1]);              \
+                vj[2] = (T)bcast8_t<VT, 2 * B>(v4[2]); vj[3] = (T)bcast8_t<VT, 2 * B>(v4[3]);              \
+                vj[4] = (T)bcast8_t<VT, 2 * B + 1>(v4[0]); vj[5] = (T)bcast8_t<VT, 2 * B + 1>(v4[1]);      \
+                vj[6] = (T)bcast8_t<VT, 2 * B + 1>(v4[2]); vj[7] = (T)bcast8_t<VT, 2 * B + 1>(v4[3]);      \
                 _Pragma("unroll") for (int j = 0; j < LPR; j++) {                                          \
                     if (full || eb + j < len) acc.fma(vj[j], x[j]);                                       \
                 }                                                                                          \
@@ -850,9 +861,24 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     }
 }
 
+// narrow[i] = vals[i] in the 4-byte type; *flag |= 1 when some value does not survive the round trip (NaNs included)
+template <typename T>
+__global__ void k_narrow_vals(const T *__restrict__ vals, uint64_t n, typename NarrowOf<T>::type *__restrict__ narrow, int *flag) {
+    using NT = typename NarrowOf<T>::type;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T v = vals[i];
+    const NT q = (NT)v;
+    bool same;
+    if constexpr (std::is_same<T, double>::value) same = __double_as_longlong((double)q) == __double_as_longlong(v);
+    else same = (T)q == v;
+    narrow[i] = q;
+    if (!same) atomicOr(flag, 1);
+}
+
 // One launch per column panel: the first coop_grid blocks take the panel's LONG items (one wave each,
 // dispatched first), the rest the ordinary items (one lane group each).
-template <typename T, int VEC, int LOG_LPR, int AMODE, bool HAS_VALS, bool DEQ = false>
+template <typename T, int VEC, int LOG_LPR, int AMODE, int HAS_VALS, bool DEQ = false>
 __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ item_row,
                                                    const uint32_t *__restrict__ item_begin,
                                                    const uint32_t *__restrict__ item_len, uint32_t nitems,

@@ -76,6 +76,7 @@ struct Tunables {
     int64_t vec_lds = 1;                // 1 = ... and, when a column panel of X fits, the LDS-staged form of it (k_spmv_lds)
     int64_t vec_lds_min_seg = 14;       // ... from this many entries per (row, panel) on average
     int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
+    int64_t narrow_vals = 1;            // 1 = INT64 / DBL64 values that are all exactly 4-byte representable are streamed as int32 / float by the sweep
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
@@ -102,6 +103,7 @@ struct Part {
     uint32_t *rowind = nullptr;  // COO only
     uint32_t *colind = nullptr;
     void *vals = nullptr;        // nullptr when all ones
+    void *vals_narrow = nullptr; // 8-byte element types whose values all fit 4 bytes exactly: the sweep streams these (narrow_values)
     bool own_rowptr = false, own_rowind = false, own_colind = false, own_vals = false;
     // long-row plans (rows cut into segments over many waves).  lp_base: used by the row-per-wave kernels; lp_panel: used with the panel sweep, where a row is
     // only "long" when its share of ONE panel would be (threshold x npanels): segment kernels gather
@@ -311,6 +313,8 @@ void free_part(Part &p) {
     if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
     if (p.own_colind && p.colind) (void)hipFree(p.colind);
     if (p.own_vals && p.vals) (void)hipFree(p.vals);
+    if (p.vals_narrow) (void)hipFree(p.vals_narrow);
+    p.vals_narrow = nullptr;
     for (LongPlan *lp : {&p.lp_base, &p.lp_panel}) {
         if (lp->d_tasks) (void)hipFree(lp->d_tasks);
         if (lp->d_desc) (void)hipFree(lp->d_desc);
@@ -580,20 +584,30 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
                 if (amode == 2 && p.col16 && g_tune.panel_col16) amode = 3;
                 if constexpr (DeqType<T>::ok) {
                     if (g->deq_out && amode >= 2 && !vals) {
-                        if (amode == 3) PYGIM_LAUNCH_PANEL_D(3, false, true);
-                        else PYGIM_LAUNCH_PANEL_D(2, false, true);
+                        if (amode == 3) PYGIM_LAUNCH_PANEL_D(3, 0, true);
+                        else PYGIM_LAUNCH_PANEL_D(2, 0, true);
                         continue;
                     }
                 }
                 if (g->deq_out) return fail(PYGIM_ERR_INVALID, "internal: fused dequantisation on an unsupported sweep");
-                if (amode == 3 && vals) PYGIM_LAUNCH_PANEL(3, true);
-                else if (amode == 3) PYGIM_LAUNCH_PANEL(3, false);
-                else if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, true);
-                else if (amode == 2) PYGIM_LAUNCH_PANEL(2, false);
-                else if (amode == 1 && vals) PYGIM_LAUNCH_PANEL(1, true);
-                else if (amode == 1) PYGIM_LAUNCH_PANEL(1, false);
-                else if (vals) PYGIM_LAUNCH_PANEL(0, true);
-                else PYGIM_LAUNCH_PANEL(0, false);
+                if constexpr (sizeof(T) == 8) {
+                    if (vals && p.vals_narrow && g_tune.narrow_vals) {  // the 4-byte copy of the values (narrow_values)
+                        const T *vals = (const T *)p.vals_narrow;       // (the kernel reads it as NarrowOf<T>)
+                        if (amode == 3) PYGIM_LAUNCH_PANEL(3, 2);
+                        else if (amode == 2) PYGIM_LAUNCH_PANEL(2, 2);
+                        else if (amode == 1) PYGIM_LAUNCH_PANEL(1, 2);
+                        else PYGIM_LAUNCH_PANEL(0, 2);
+                        continue;
+                    }
+                }
+                if (amode == 3 && vals) PYGIM_LAUNCH_PANEL(3, 1);
+                else if (amode == 3) PYGIM_LAUNCH_PANEL(3, 0);
+                else if (amode == 2 && vals) PYGIM_LAUNCH_PANEL(2, 1);
+                else if (amode == 2) PYGIM_LAUNCH_PANEL(2, 0);
+                else if (amode == 1 && vals) PYGIM_LAUNCH_PANEL(1, 1);
+                else if (amode == 1) PYGIM_LAUNCH_PANEL(1, 0);
+                else if (vals) PYGIM_LAUNCH_PANEL(0, 1);
+                else PYGIM_LAUNCH_PANEL(0, 0);
 #undef PYGIM_LAUNCH_PANEL
 #undef PYGIM_LAUNCH_PANEL_D
             }
@@ -1320,6 +1334,35 @@ int split_unit_pattern_t(Part &p, size_t es, int *d_flag_sorted, uint32_t *d_cou
     return 0;
 }
 
+// One-time: a 4-byte copy of the values of an 8-byte element type for the sweep (kernels.hpp SweepVal), when every value
+// survives the round trip bit for bit.  The weights of a normalised adjacency are float32 numbers widened by the caller's
+// DBL64 choice, integer weights are small counts: both halve the value bytes every 128-byte slice re-reads.
+template <typename T> int narrow_values_t(Part &p, int *d_flag, hipStream_t st) {
+    using NT = typename NarrowOf<T>::type;
+    void *buf = nullptr;
+    if (hipMalloc(&buf, (size_t)p.nnz * sizeof(NT)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;  // (an optimisation only)
+    }
+    int bad = 0;
+    if (hipMemsetAsync(d_flag, 0, sizeof(int), st) != hipSuccess) { (void)hipFree(buf); return fail(PYGIM_ERR_HIP, "flag reset"); }
+    hipLaunchKernelGGL((k_narrow_vals<T>), dim3((unsigned)(((uint64_t)p.nnz + 255) / 256)), dim3(256), 0, st, (const T *)p.vals, (uint64_t)p.nnz,
+                       (NT *)buf, d_flag);
+    if (hipMemcpyAsync(&bad, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFree(buf);
+        return fail(PYGIM_ERR_HIP, "narrow values");
+    }
+    if (bad) (void)hipFree(buf);
+    else p.vals_narrow = buf;
+    return 0;
+}
+int narrow_values(Part &p, int dtype, int *d_flag, hipStream_t st) {
+    if (!g_tune.narrow_vals || !p.vals || p.nnz == 0 || p.is_extra || !p.d_items) return 0;  // (d_items: the part has a sweep plan)
+    if (dtype == PYGIM_INT64) return narrow_values_t<int64_t>(p, d_flag, st);
+    if (dtype == PYGIM_DBL64) return narrow_values_t<double>(p, d_flag, st);
+    return 0;
+}
+
 int split_unit_pattern(Part &p, int dtype, size_t es, int *d_flag_sorted, uint32_t *d_counter, hipStream_t st) {
     if (!p.vals || p.nnz == 0 || !g_tune.split_unit_pattern) return 0;
     switch (dtype) {
@@ -1382,6 +1425,7 @@ int build_merged_t(Group *g, size_t es, hipStream_t st) {
     int rc = 0;
     if (!g->all_ones) rc = split_unit_pattern(*m, g->dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st);
     if (!rc) rc = build_plans(*m, es, g->d_flags + 4, st, g->h);
+    if (!rc) rc = narrow_values(*m, g->dtype, g->d_flags + 6, st);
     if (rc) {
         free_part(*m);
         return rc;
@@ -1885,6 +1929,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
     else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
+    else if (n == "narrow_vals") slot = &g_tune.narrow_vals;
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
     else if (n == "vec_kernel") slot = &g_tune.vec_kernel;
     else if (n == "vec_lds") slot = &g_tune.vec_lds;
@@ -2019,6 +2064,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         }
         if (!g->all_ones && (rc = split_unit_pattern(p, dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st))) return bail(rc);
         if ((rc = build_plans(p, es, g->d_flags + 4, st, g->h, /*allow_lds=*/!(g->merged && g_tune.merge_parts)))) return bail(rc);
+        if (!(g->merged && g_tune.merge_parts) && (rc = narrow_values(p, dtype, g->d_flags + 6, st))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;

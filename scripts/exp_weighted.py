@@ -11,10 +11,11 @@ n, nnz, dmax = synth.SHAPES["reddit"]
 h = 256
 rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-for dt, code in ((torch.float32, _lib.FLT32), (torch.float64, _lib.DBL64), (torch.int32, _lib.INT32)):
+for dt, code in ((torch.float32, _lib.FLT32), (torch.float64, _lib.DBL64), (torch.int32, _lib.INT32), (torch.int64, _lib.INT64)):
     x = synth.features(n, h, dt, seed=0, device=dev)
     out = torch.empty((n, h), dtype=dt, device=dev)
-    for weighted in (False, True):
+    for weighted, narrow in ((False, 1), (True, 1)) + (((True, 0),) if dt in (torch.float64, torch.int64) else ()):
+        _lib.set_tunable("narrow_vals", narrow)   # (8-byte types: values that fit 4 bytes exactly are streamed as such)
         vals = None
         if weighted:
             vals = (torch.rand(nnz, device=dev) * 2 - 1).to(dt) if dt.is_floating_point else torch.randint(-3, 4, (nnz,), device=dev, dtype=dt)
@@ -24,5 +25,5 @@ for dt, code in ((torch.float32, _lib.FLT32), (torch.float64, _lib.DBL64), (torc
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); ts = []
         for _ in range(5):
             a.record(); _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st); b.record(); b.synchronize(); ts.append(a.elapsed_time(b))
-        print(f"{str(dt):14s} weighted={weighted}: {min(ts):7.3f} ms", flush=True)
+        print(f"{str(dt):14s} weighted={weighted}{'' if narrow else ' (narrow_vals=0)'}: {min(ts):7.3f} ms", flush=True)
         _lib.group_free(hd)

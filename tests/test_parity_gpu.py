@@ -731,3 +731,53 @@ def test_degenerate_shapes(dt):
                 vals = np.ones(len(entries), dtype=npdt)
                 out, _ = run_group_host("COO", [rows], [cols], [vals], [nrows], [ncols], [x], h)
                 assert np.array_equal(out, oracle.spmm_coo(rows, cols, vals, x, nrows)), (dt, nrows, ncols, h, "coo")
+
+
+@pytest.mark.parametrize("dt", ["DBL64", "INT64"])
+@pytest.mark.parametrize("kind", ["exact", "inexact", "one_wide", "specials"])
+def test_eight_byte_values_streamed_in_four_bytes_when_exact(rng, dt, kind):
+    """INT64 / DBL64 values that all survive the round trip through int32 / float are streamed narrow by the sweep
+    (kernels.hpp SweepVal, narrow_values at group creation); one value that does not, and the group keeps the 8-byte stream.
+    Either way the product is bit for bit the one with the knob off, and the oracle's (integers: exactly)."""
+    npdt = NP_DTYPES[dt]
+    nrows, ncols, h = 400, 700, 80
+    rowptr, col = random_csr(rng, nrows, ncols, 30, empty_frac=0.1, long_rows=[(5, 2000)])
+    if dt == "DBL64":
+        vals = (rng.random(len(col)) * 2 - 1).astype(np.float32).astype(np.float64)
+        x = (rng.random((ncols, h)) * 2 - 1).astype(np.float64)
+        if kind == "inexact":
+            vals = rng.random(len(col)) * 2 - 1
+        elif kind == "one_wide":
+            vals[len(vals) // 2] = 0.1
+        elif kind == "specials":
+            vals[:4] = [-0.0, np.inf, 2.0 ** -140, 3.0e38]   # (a float32 denormal and a near-max value: both exact)
+            x[col[1]] = np.abs(x[col[1]]) + 0.5             # inf * positive: no NaN from 0 * inf
+    else:
+        vals = rng.integers(-1000, 1000, size=len(col)).astype(np.int64)
+        x = driver_features(rng, ncols, h, npdt)
+        if kind == "inexact":
+            vals = rng.integers(-2 ** 40, 2 ** 40, size=len(col)).astype(np.int64)
+        elif kind == "one_wide":
+            vals[len(vals) // 2] = 2 ** 31
+        elif kind == "specials":
+            vals[:4] = [-2 ** 31, 2 ** 31 - 1, 0, -1]
+    ref = oracle.spmm_csr(rowptr, col, vals, x)
+    outs = {}
+    for narrow in (1, 0):
+        old = {"narrow_vals": _lib.set_tunable("narrow_vals", narrow), "panel_mode": _lib.set_tunable("panel_mode", 1)}
+        try:
+            outs[narrow], info = run_group_host("CSR", [rowptr], [col], [vals], [nrows], [ncols], [x], h)
+        finally:
+            for k, v in old.items():
+                _lib.set_tunable(k, v)
+        assert info["all_ones"] == 0
+        if dt == "INT64":
+            assert np.array_equal(outs[narrow], ref), (dt, kind, narrow)
+    # the widening conversion is exact: the narrow stream changes no bit of the result (floats: same kernel, same order)
+    assert np.array_equal(outs[1].view(np.int64), outs[0].view(np.int64)), (dt, kind)
+    if dt == "DBL64":
+        # (the 2 000-entry row is summed in segments: not the oracle's order, so a bound instead of bits)
+        scale = oracle.spmm_csr(rowptr, col, np.abs(vals), np.abs(x))
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(outs[1]), fin) and np.array_equal(outs[1][~fin], ref[~fin])
+        assert np.all(np.abs(outs[1][fin] - ref[fin]) <= 1e-13 * scale[fin] + 1e-300), (dt, kind)

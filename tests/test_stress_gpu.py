@@ -111,7 +111,7 @@ def test_random_groups(seed):
              "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20])),
              "panel_col16": int(rng.choice([0, 1])), "merge_parts": int(rng.choice([0, 1])),
              "split_unit_pattern": int(rng.choice([0, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
-             "lds_long_slots": int(rng.choice([0, 1, 128]))}
+             "lds_long_slots": int(rng.choice([0, 1, 128])), "narrow_vals": int(rng.choice([0, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
