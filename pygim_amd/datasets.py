@@ -225,8 +225,9 @@ def load_processed(path):
 
 
 def _processed(root, name):
-    sub = {True: [os.path.join(root, name.replace("-", "_")), root]}.get(name.startswith("ogbn-"), [os.path.join(root, name), root])
-    for d in sub:
+    # Planetoid(root, name) keeps <root>/<name>/processed, OGB <root>/<name_with_underscores>/processed, Reddit <root>/processed
+    inner = name.replace("-", "_") if name.startswith("ogbn-") else name
+    for d in (os.path.join(root, inner), root):
         for fname in ("geometric_data_processed.pt", "data.pt"):
             path = os.path.join(d, "processed", fname)
             if os.path.isfile(path):
