@@ -708,6 +708,9 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.wdelta = p.lds_wdelta;
     a.deq_amax = deq_amax;
     a.deq_log2 = deq_log2;
+    a.post_mul = deq_amax ? g->post_mul : nullptr;   // (the per-column epilogue rides the dequantising store only)
+    a.post_add = deq_amax ? g->post_add : nullptr;
+    a.post_relu = deq_amax ? g->post_relu : 0;
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);
@@ -1689,11 +1692,11 @@ static Part *fusable_part(Group *g) {
 }
 
 // the part whose LDS-staged plan can carry the conv layers' quantised aggregation with the dequantisation in its store
-// (INT32 / FLT32 adjacency types; no per-column epilogue: that one stays with the sweep's store)
+// (INT32 / FLT32 adjacency types; the per-column epilogue, if any, is applied in the same store)
 template <typename T>
 static Part *lds_fusable_part(Group *g) {
     if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return nullptr;
-    if (!g->all_ones || g->post_mul || g_tune.lds_mode == 2 || (int64_t)g->h < g_tune.lds_min_width) return nullptr;
+    if (!g->all_ones || g_tune.lds_mode == 2 || (int64_t)g->h < g_tune.lds_min_width) return nullptr;
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode != 0 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0 || !g_tune.fuse_windows)) return nullptr;
     Part *p = nullptr;
     if (g->parts.size() == 1) p = &g->parts[0];

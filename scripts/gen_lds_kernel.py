@@ -291,6 +291,14 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a("s_and_b64 exec, exec, vcc")
     a(f"s_mov_b64 {NP}, %[rowmap]")
     a(f"s_mov_b32 {KREG}, 0")
+    if deq:
+        # per-column epilogue factors of this slice's 64 features, one per lane (the x registers are free by now)
+        a("s_cmp_eq_u64 %[pmul], 0")
+        a("s_cbranch_scc1 L_nopost_%=")
+        a(f"global_load_dword v{XS[0]}, {VL4}, %[pmul]")
+        a(f"global_load_dword v{XS[0] + 1}, {VL4}, %[padd]")
+        a("s_waitcnt vmcnt(0)")
+        a("L_nopost_%=:")
     a("L_orow_%=:")                                # eight rows per scalar load of the row map
     a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
     a("s_waitcnt lgkmcnt(0)")
@@ -311,6 +319,14 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
             if deq == "i32":
                 a(f"v_cvt_f32_i32 {VT0}, {VT0}")
             a(f"v_mul_f32 {VT0}, %[scale], {VT0}")
+            a("s_cmp_eq_u64 %[pmul], 0")
+            a(f"s_cbranch_scc1 L_np{i}_%=")
+            a(f"v_mul_f32 {VT0}, v{XS[0]}, {VT0}")         # product and sum rounded separately, as k_post_affine / torch's a * y + b
+            a(f"v_add_f32 {VT0}, v{XS[0] + 1}, {VT0}")
+            a("s_cmp_eq_u32 %[relu], 0")
+            a(f"s_cbranch_scc1 L_np{i}_%=")
+            a(f"v_max_f32 {VT0}, 0, {VT0}")
+            a(f"L_np{i}_%=:")
         else:
             a("s_cmp_eq_u32 %[accum], 0")
             a(f"s_cbranch_scc1 L_ost{i}_%=")
@@ -357,6 +373,8 @@ struct LdsArgs {
     uint32_t wdelta;          // weighted kernels: bytes from a token to its value (the value stream follows the token stream)
     const uint32_t *deq_amax; // dequantising kernels: bits of max|x| (device), and the quantiser's log2 range
     int deq_log2;
+    const float *post_mul, *post_add;  // dequantising kernels: per-column epilogue of the store, y = post_mul[f] * y + post_add[f]
+    int post_relu;                     // (nullptr = none; then max(y, 0) when set) -- the sweep's fused store does the same
 };
 """
 
@@ -388,18 +406,21 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * PIECE);
     const uint32_t scale = %(scale_expr)s;
-#define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
+%(post_decl)s#define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
+#define PYGIM_SU2(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))   /* (the builtin returns int: no sign extension into the high word) */
     const uint32_t tok_lo = PYGIM_SU(tok), tok_hi = PYGIM_SU(tok >> 32), xs_lo = PYGIM_SU(xs), xs_hi = PYGIM_SU(xs >> 32);
     const uint32_t rm_lo = PYGIM_SU(rowmap), rm_hi = PYGIM_SU(rowmap >> 32), c_lo = PYGIM_SU(cb), c_hi = PYGIM_SU(cb >> 32);
 #undef PYGIM_SU
     const uint64_t tok_s = ((uint64_t)tok_hi << 32) | tok_lo, rm_s = ((uint64_t)rm_hi << 32) | rm_lo;
+%(post_decl2)s
     asm volatile(
 %(asm)s
         :
         : [lane] "v"(lane), [tok] "s"(tok_s), [cid0] "s"(cid0), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
-          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale), [wave] "s"(wave)
+          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale), [wave] "s"(wave)%(post_ops)s
         : %(clobbers)s, "vcc", "scc", "memory");
+#undef PYGIM_SU2
 }
 """
 
@@ -437,7 +458,12 @@ def main():
         text += KERNEL % dict(name=name, doc=doc, asm=asm, clobbers=clob, threads=g.threads, NW=g.NW, KA=g.KA, BATCH=g.BATCH,
                               piece=g.pieces * 1024,
                               scale_expr=("__builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(*a.deq_amax) * 2.0f / (float)(1u << a.deq_log2)))"
-                                          if deq else "0u"))
+                                          if deq else "0u"),
+                              post_decl=("    const uint64_t pmul = a.post_mul ? (uint64_t)(a.post_mul + slice * 64u) : 0ull, "
+                                         "padd = a.post_mul ? (uint64_t)(a.post_add + slice * 64u) : 0ull;\n" if deq else ""),
+                              post_decl2=("    const uint64_t pmul_s = ((uint64_t)PYGIM_SU2(pmul >> 32) << 32) | PYGIM_SU2(pmul), "
+                                          "padd_s = ((uint64_t)PYGIM_SU2(padd >> 32) << 32) | PYGIM_SU2(padd);" if deq else ""),
+                              post_ops=(',\n          [pmul] "s"(pmul_s), [padd] "s"(padd_s), [relu] "s"(a.post_relu)' if deq else ""))
         if guard:
             text += "#endif  // PYGIM_LDS_ABLATE\n"
     text += "\n}  // namespace pygim\n"

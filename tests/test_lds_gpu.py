@@ -302,6 +302,16 @@ def test_quantised_aggregation_with_the_dequantising_store(rng, lds_forced, dt, 
         scale = torch.empty(1, dtype=torch.float32, device="cuda")
         _lib.quant_spmm_run(hd, xd.data_ptr(), h, out.data_ptr(), scale.data_ptr())
         torch.cuda.synchronize()
+        # the per-column epilogue of a GCN layer (bias + eval-mode BatchNorm as one affine map, then ReLU) rides the same store:
+        # product and sum rounded separately, bit-identical to torch's a * out + b.  Widths that end inside a slice too.
+        for hh, relu in ((h, True), (h, False)):
+            a = torch.rand(hh, device="cuda") + 0.5
+            b = torch.randn(hh, device="cuda")
+            out2 = torch.full((n, hh), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.quant_spmm_run(hd, xd.data_ptr(), h, out2.data_ptr(), 0, 0, a.data_ptr(), b.data_ptr(), relu)
+            torch.cuda.synchronize()
+            want2 = a * out + b
+            assert torch.equal(out2, torch.relu(want2) if relu else want2), (code, hh, relu)
     finally:
         _lib.group_free(hd)
     s_ref, xq = oracle.symmetric_quantize(xf, dt)
