@@ -159,7 +159,7 @@ int pygim_block_run_x(int64_t handle, int part, const void *X, int64_t ldx, void
  * X: float32 [total_cols, h] (row stride ldx), out: float32 [nrows, h]; device pointers.
  * scale_out (device float, may be NULL) receives the scale.                     */
 int pygim_quant_spmm_run(int64_t handle, const float *X, int64_t ldx, float *out, float *scale_out, void *stream);
-/* the same with a per-column epilogue applied in the sweep's last store of every row:
+/* the same with a per-column epilogue applied in the last store of every row (the sweep's, or the LDS-staged kernel's):
  *   out[r, f] = col_mul[f] * out[r, f] + col_add[f], then max(., 0) when relu != 0
  * (what follows the aggregation in a GCN layer -- + bias, eval-mode BatchNorm, ReLU, models/models.py:30-38 -- folded into
  * one affine map per feature; col_mul / col_add: device float[h]; both NULL = no epilogue).                              */
