@@ -54,6 +54,39 @@ KERNEL(kA, RD_A)
 KERNEL(kB, RD_B)
 KERNEL(kC, RD_C)
 
+// ---- structure variants of form A (same instructions per token, different order) ----
+#define RDX(s, v) "v_bfi_b32 " v ", v110, " s ", v111\n ds_read_b32 " v ", " v "\n"
+#define READS_X "" RDX("s40","v12") RDX("s41","v13") RDX("s42","v14") RDX("s43","v15") RDX("s44","v16") RDX("s45","v17") RDX("s46","v18") RDX("s47","v19")
+#define READS_Y "" RDX("s40","v20") RDX("s41","v21") RDX("s42","v22") RDX("s43","v23") RDX("s44","v24") RDX("s45","v25") RDX("s46","v26") RDX("s47","v27")
+#define ADDS_X "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADD("s40","v12") ADD("s41","v13") ADD("s42","v14") ADD("s43","v15") ADD("s44","v16") ADD("s45","v17") ADD("s46","v18") ADD("s47","v19") "s_set_gpr_idx_off\n"
+#define ADDS_Y "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADD("s40","v20") ADD("s41","v21") ADD("s42","v22") ADD("s43","v23") ADD("s44","v24") ADD("s45","v25") ADD("s46","v26") ADD("s47","v27") "s_set_gpr_idx_off\n"
+// P: software-pipelined as the product kernel: wait, reads of the next batch, adds of the current one (two batches per iteration)
+#define BODY_P "s_waitcnt lgkmcnt(0)\n" READS_Y ADDS_X "s_waitcnt lgkmcnt(0)\n" READS_X ADDS_Y
+// Q: adds start as soon as the first read is back (in-order LDS returns: lgkmcnt(7), (6), ...) -- not available to the product
+//    kernel as it is (its scalar token loads share the counter and return out of order)
+#define ADDW(n, s, v) "s_waitcnt lgkmcnt(" #n ")\n" ADD(s, v)
+#define BODY_Q READS_X "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADDW(7,"s40","v12") ADDW(6,"s41","v13") ADDW(5,"s42","v14") ADDW(4,"s43","v15") ADDW(3,"s44","v16") ADDW(2,"s45","v17") ADDW(1,"s46","v18") ADDW(0,"s47","v19") "s_set_gpr_idx_off\n" \
+               READS_Y "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADDW(7,"s40","v20") ADDW(6,"s41","v21") ADDW(5,"s42","v22") ADDW(4,"s43","v23") ADDW(3,"s44","v24") ADDW(2,"s45","v25") ADDW(1,"s46","v26") ADDW(0,"s47","v27") "s_set_gpr_idx_off\n"
+// R: pipelined AND partial waits: reads of the next batch in flight while the current one's adds wait read by read
+#define BODY_R READS_Y "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADDW(15,"s40","v12") ADDW(14,"s41","v13") ADDW(13,"s42","v14") ADDW(12,"s43","v15") ADDW(11,"s44","v16") ADDW(10,"s45","v17") ADDW(9,"s46","v18") ADDW(8,"s47","v19") "s_set_gpr_idx_off\n" \
+               READS_X "s_set_gpr_idx_on s40, gpr_idx(SRC1,DST)\n" ADDW(15,"s40","v20") ADDW(14,"s41","v21") ADDW(13,"s42","v22") ADDW(12,"s43","v23") ADDW(11,"s44","v24") ADDW(10,"s45","v25") ADDW(9,"s46","v26") ADDW(8,"s47","v27") "s_set_gpr_idx_off\n"
+// S: the index mode left ON across the whole loop (the address v_bfi then runs under it too: src1 = s-register, not indexed)
+#define ADDS_X_NOON ADD("s40","v12") ADD("s41","v13") ADD("s42","v14") ADD("s43","v15") ADD("s44","v16") ADD("s45","v17") ADD("s46","v18") ADD("s47","v19")
+#define KERNEL2(NAME, PRO, BODY, TOKENS_PER_IT) \
+__global__ __launch_bounds__(1024) void NAME(int it, float *out) { \
+  extern __shared__ uint32_t lds[]; \
+  for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = 0; \
+  __syncthreads(); \
+  const uint32_t lane = threadIdx.x & 63; \
+  asm volatile(SETUP PRO "L_loop_%=:\n" BODY \
+    "s_sub_u32 s60, s60, 1\n s_cmp_lg_u32 s60, 0\n s_cbranch_scc1 L_loop_%=\n s_waitcnt lgkmcnt(0)\n" \
+    : : [it] "s"(it), [lane] "v"(lane) : CLOB); \
+  if (it < 0) out[threadIdx.x] = 1.f; \
+}
+KERNEL2(kP, READS_X, BODY_P, 16)
+KERNEL2(kQ, "", BODY_Q, 16)
+KERNEL2(kR, READS_X, BODY_R, 16)
+
 int main() {
   uint32_t *out;
   CHECK(hipMalloc(&out, 4096));
@@ -74,7 +107,8 @@ int main() {
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const int it = 20000;
-  struct V { const char *name; void (*fn)(int, float *); } vs[] = {{"A v_bfi + ds_read_b32", kA}, {"B s_and m0 + s_nop + ds_read_addtid", kB}, {"C s_and m0 + ds_read_addtid (no nop)", kC}};
+  struct V { const char *name; void (*fn)(int, float *); int tok; } vs[] = {{"A v_bfi + ds_read_b32", kA, 8}, {"B s_and m0 + s_nop + ds_read_addtid", kB, 8}, {"C s_and m0 + ds_read_addtid (no nop)", kC, 8},
+    {"P form A software-pipelined (as the kernel)", kP, 16}, {"Q form A, adds wait read by read", kQ, 16}, {"R pipelined + read-by-read waits", kR, 16}};
   for (auto &v : vs) {
     CHECK(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     hipLaunchKernelGGL(v.fn, dim3(256), dim3(1024), 131072, 0, 100, (float *)out);
@@ -90,7 +124,7 @@ int main() {
       if (ms < best) best = ms;
     }
     const double cyc = best * 1e-3 * 2.4e9;
-    printf("%-40s %8.3f ms  %6.2f CU cycles per token (16 waves, 8 tokens per batch)\n", v.name, best, cyc / ((double)it * 8 * 16));
+    printf("%-40s %8.3f ms  %6.2f CU cycles per token (16 waves, 8 tokens per batch)\n", v.name, best, cyc / ((double)it * v.tok * 16));
   }
   return 0;
 }
