@@ -693,7 +693,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
                                    (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)rows_pad);
         }
     }
-    LdsArgs a;
+    LdsArgs a{};
     a.tok = p.lds_tok;
     a.tiles = p.lds_tiles;
     a.rowmap = p.lds_rowmap;
