@@ -54,7 +54,7 @@ def lds_rows_per_tile(nrows, nslices, rmax=LDS_ROWS_MAX, cus=CUS):
     rounds = -(-wgs // cus)
     if rounds > 8 or wgs % cus == 0:
         return rmax
-    tiles2 = -(-rounds * cus // nslices)
+    tiles2 = rounds * cus // nslices
     if tiles2 <= tiles:
         return rmax
     return min(rmax, max(16, -(-nrows // tiles2)))

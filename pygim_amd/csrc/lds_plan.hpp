@@ -240,7 +240,8 @@ inline uint32_t lds_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32_t nslice
     if (rounds > 8 || wgs % cus == 0) return rmax;
     // as many tiles as fit the same number of rounds (less than one round: enough tiles to give every CU a workgroup --
     // the caller's reuse rule then decides whether such light tiles are still worth staging X for)
-    const uint64_t tiles2 = (rounds * cus + nslices - 1) / nslices;
+    // (rounded DOWN: 171 tiles x 3 slices = 513 workgroups would start a third round for one workgroup; 170 x 3 = 510 do not)
+    const uint64_t tiles2 = rounds * cus / nslices;
     if (tiles2 <= tiles) return rmax;
     return (uint32_t)std::min<uint64_t>(rmax, std::max<uint64_t>(16, (nrows + tiles2 - 1) / tiles2));
 }

@@ -711,6 +711,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.post_mul = deq_amax ? g->post_mul : nullptr;   // (the per-column epilogue rides the dequantising store only)
     a.post_add = deq_amax ? g->post_add : nullptr;
     a.post_relu = deq_amax ? g->post_relu : 0;
+    // (slice counts that do not divide 8 interleave the slices over the XCDs; a slice-major order measured the same: 2.86 vs 2.80 ms at h = 192)
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
     const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);

@@ -131,3 +131,11 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
     assert emul.lds_emul_rows_per_tile(232965, 1536, 4, 256) == 1214      # Reddit h = 256: 192 tiles x 4 slices = 3 full rounds
     assert emul.lds_emul_rows_per_tile(232965, 1536, 2, 256) == 911       # h = 128: 256 tiles x 2 slices = 2 rounds
     assert emul.lds_emul_rows_per_tile(29471, 1536, 4, 256) == 461        # a 1/8 row share: 64 tiles, one workgroup per CU
+    # slice counts that do not divide the CU count: the tile count is rounded DOWN so that no workgroup starts another round
+    # (h = 192: 170 tiles x 3 = 510 <= 512; rounding up gave 171 x 3 = 513 and a third round for one workgroup: 4.12 vs 2.80 ms)
+    for nsl in (3, 5, 6, 7, 10):
+        rpt = emul.lds_emul_rows_per_tile(232965, 1536, nsl, 256)
+        tiles = -(-232965 // rpt)
+        base_rounds = -(-(152 * nsl) // 256)
+        assert rpt <= 1536 and -(-(tiles * nsl) // 256) == base_rounds, (nsl, rpt, tiles)
+    assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
