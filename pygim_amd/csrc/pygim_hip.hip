@@ -739,6 +739,9 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
                 case 12: fn = k_lds_spmm_f32_w16_ab12; break;
                 case 15: fn = k_lds_spmm_f32_w16_ab15; break;
                 case 16: fn = k_lds_spmm_f32_w16_ab16; break;
+                case 17: fn = k_lds_spmm_f32_w16_ab17; break;
+                case 18: fn = k_lds_spmm_f32_w16_ab18; break;
+                case 19: fn = k_lds_spmm_f32_w16_ab19; break;
                 default: break;
             }
         }

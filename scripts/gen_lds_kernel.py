@@ -61,7 +61,9 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
     6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
     # codes 10..12: the bare batch loop (no scalar token loads, barrier, DMA or touches), whole / LDS side only / accumulate side only
-    AB = {0: set(), 10: {5, 6, 7, 8}, 11: {5, 6, 7, 8, 4}, 12: {5, 6, 7, 8, 3}}.get(ablate, {ablate})
+    TNT = " nt" if ablate in (17, 19) else ""     # experiment (results stay right): the token-line touches bypass the L1
+    DNT = " nt" if ablate in (18, 19) else ""     # experiment: the chunk DMA bypasses the L1
+    AB = {0: set(), 17: set(), 18: set(), 19: set(), 10: {5, 6, 7, 8}, 11: {5, 6, 7, 8, 4}, 12: {5, 6, 7, 8, 3}}.get(ablate, {ablate})
     KA, BATCH, NW, ACC0 = g.KA, g.BATCH, g.NW, g.ACC0
     VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = (f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
     XS = [g.X0, g.X0 + BATCH]
@@ -130,7 +132,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
                 a(f"s_mov_b32 m0, {DLDS}")
                 a("s_nop 0")
             if 7 not in AB:
-                a(f"global_load_lds_dwordx4 {VL16}, {PA} offset:{(i % 4) * 1024}")
+                a(f"global_load_lds_dwordx4 {VL16}, {PA} offset:{(i % 4) * 1024}{DNT}")
 
     if 15 in AB:   # experiment: static priority for the later-dispatched half of the workgroup (waves NW/2 ..)
         a("s_cmp_ge_u32 %[wave], " + str(NW // 2))
@@ -162,7 +164,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a(f"s_min_u32 {TMP}, {TMP}, 17")
     a(f"s_bfm_b64 exec, {TMP}, 0")
     if 8 not in AB:
-        a(f"global_load_dword {VT1}, {VL128}, {PA}")
+        a(f"global_load_dword {VT1}, {VL128}, {PA}{TNT}")
     if g.weighted:   # the same lines of the value stream (it sits wdelta bytes behind the tokens)
         a(f"s_add_u32 {PA_LO}, {PA_LO}, %[wdelta]")
         a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
@@ -192,7 +194,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
         a(f"s_cbranch_scc0 L_nt{next_id[0]}_%=")
         a(f"v_mov_b32 {VT0}, {TOFF}")
         if 8 not in AB:
-            a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
+            a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048{TNT}")
         if g.weighted:
             a(f"v_add_u32 {VT0}, %[wdelta], {VT0}")
             a(f"global_load_dword {VT1}, {VT0}, {TP} offset:2048")
@@ -432,7 +434,7 @@ def main():
     for nw in (8, 16):
         variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
         variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
-    for ab in (6, 7, 10, 11, 12, 15, 16):
+    for ab in (6, 7, 10, 11, 12, 15, 16, 17, 18, 19):
         variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
