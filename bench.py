@@ -377,7 +377,7 @@ def main():
         kname = (f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16{'b' if long_slots else ''} (ONE launch per product: {lds_info['tiles']} row tiles x "
                  f"{nsl} slices)")
         launches = 1
-        staged = lds_info["chunk_fills"] * 65536 * nsl
+        staged = lds_info["chunk_fills"] * 81920 * nsl     # 80 KiB chunks: 320 columns x 256 bytes
         on_chip = {"level": "LDS (ds_read_b32, one 256-byte row slice per stored entry and slice)", "gather_bytes": gather,
                    "achieved_TBs": round(gather / (k_ms * 1e-3) / 1e12, 2) if k_ms else None, "peak_TBs": round(LDS_READ_B32_TBS, 1),
                    "frac": round(gather / (k_ms * 1e-3) / 1e12 / LDS_READ_B32_TBS, 4) if k_ms else None,

@@ -205,7 +205,7 @@ int pygim_group_kernel_events(int64_t handle, int on);
 int pygim_group_plan(int64_t handle, int64_t out[8]);
 /* schedule of the LDS-staged product (k_lds_spmm; the reference's scratchpad loop spmm_default/dpu_kernels/
  * spmm_mul_csr_dpu.c:108-126 with X chunks in LDS and the running sums of a tile of rows in registers) of the same matrix:
- * row tiles (0 = no such plan), 64 KiB chunk fills per 64-feature slice and product, tokens incl. padding, stored entries */
+ * row tiles (0 = no such plan), 80 KiB (320-column) chunk fills per 64-feature slice and product, tokens incl. padding, stored entries */
 int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",

@@ -31,8 +31,9 @@ CUS = 256
 LDS_CLOCK = 2.3e9           # Hz held under this kernel (GRBM_GUI_ACTIVE / 8 / time)
 LDS_ROWS_MAX = 16 * 96      # rows of a tile (waves x accumulators per wave)
 LDS_CYC_PER_TOKEN = 3.9     # CU cycles per stored entry and slice (measured: clustered columns, nothing else in the way)
-LDS_CYC_PER_SLOT = 650      # CU cycles per 64 KiB chunk of X beside the tokens (barrier skew, DMA issue, touches)
-LDS_CYC_FILL = 2300         # CU cycles to land 64 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
+LDS_KC = 320                # columns of a chunk (80 KiB of one 64-feature slice; lds_plan.hpp)
+LDS_CYC_PER_SLOT = 650      # CU cycles per chunk of X beside the tokens (barrier skew, DMA issue, touches)
+LDS_CYC_FILL = 2875         # CU cycles to land 80 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
 LDS_PAD = 1.085             # tokens incl. batch padding per stored entry (uniform columns)
 LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
@@ -70,7 +71,7 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    slots = -(-int(ncols) // 256)
+    slots = -(-int(ncols) // LDS_KC)
     per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * LDS_CYC_PER_SLOT, slots * LDS_CYC_FILL)
     rounds = -(-tiles * nsl // CUS)
     return rounds * per_wg / LDS_CLOCK + ncols * h * es * 2 / RATE_STREAM + LAUNCH

@@ -10,17 +10,17 @@
 //     KA accumulator registers per wave: one register holds a row's 64-feature slice, one feature
 //     per lane).  Inside a tile the rows are dealt to the waves longest first, serpentine, so that
 //     every wave carries the same number of stored entries.
-//   * columns are cut into chunks of KC = 256 columns; a chunk of one 64-feature slice of X is
-//     64 KiB of LDS.  A tile lists the chunks in which it has entries (uniform graphs: all of them;
+//   * columns are cut into chunks of KC = 320 columns; a chunk of one 64-feature slice of X is
+//     80 KiB of LDS (two of them are the whole 160 KiB of a CU: fewer, longer slots than 2 x 64 KiB).  A tile lists the chunks in which it has entries (uniform graphs: all of them;
 //     community-structured graphs: a few) -- the workgroup streams exactly those through a
 //     double-buffered LDS ring.
 //   * per (tile, wave) a token stream: chunk after chunk, inside a chunk row after row (the order
 //     of the wave's accumulator index), inside a row in stored order.  A token is
-//     (column inside the chunk) << 8 | accumulator index, so that one stored entry costs the wave
+//     (LDS row: column inside the chunk, + KC in odd slots = the second buffer) << 8 | accumulator index, so that one stored entry costs the wave
 //     one ds_read_b32 and one indexed v_add.  Every row is summed by one wave in stored order:
 //     float results are bit-identical to the sequential CPU loop.
 //   * every (slot, wave) list is padded to whole batches of BATCH tokens -- at least one batch -- with tokens that add
-//     a row of the chunk into a dummy accumulator.  The first batch of a list is also the slot's HEADER: the upper halves
+//     a row of the chunk into a dummy accumulator.  The first batch of a list is also the slot's HEADER: bits 18..31
 //     of its tokens 0, 1, 2 carry the list's batch count, the NEXT slot's batch count and the NEXT slot's chunk id (what
 //     the wave needs to size its loop, its token prefetch and its share of the next chunk's DMA) -- the token stream is
 //     the only array the kernel's scalar unit follows.
@@ -49,10 +49,13 @@ struct LdsTile {            // 96 bytes, read by the kernel with scalar loads
 
 constexpr uint32_t LDS_TOK_SLACK = 4096 + 64;  // tokens readable past the last one (next batch; touched lines)
 
+// token = (LDS row of the entry's column: 10 bits, both buffers) << 8 | accumulator index; the 14 bits above carry the slot headers
+constexpr uint32_t LDS_HDR_SHIFT = 18, LDS_HDR_MAX = 0x3FFFu;
+
 struct LdsGeometry {
     uint32_t NW = 8;      // consumer waves per workgroup
     uint32_t KA = 208;    // accumulators (rows) per wave; accumulator KA is the dummy
-    uint32_t KC = 256;    // columns per chunk
+    uint32_t KC = 320;    // columns per chunk: two chunks of 64-feature rows (2 x 80 KiB) fill the 160 KiB of a CU's LDS
     uint32_t BATCH = 16;  // tokens per batch (one scalar load)
     uint32_t rows_per_tile = 0;  // 0 = NW * KA; fewer rows per tile = more, lighter tiles (to fill whole rounds of workgroups)
 };
@@ -198,7 +201,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
                     const uint32_t c = col[e];
                     const uint32_t j = slot_of[c / KC];
                     const uint64_t at = cursor[(size_t)j * NW + w]++;
-                    out.tok[at] = ((c % KC) << 8) | k;
+                    out.tok[at] = (((c % KC) + (j & 1) * KC) << 8) | k;   // odd slots read the second LDS buffer: row KC + (c % KC)
                     if (vals) out.wts[at] = vals[e];
                 }
             }
@@ -207,10 +210,10 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             uint64_t at = (uint64_t)d.tokstart[w] * B;
             for (uint32_t j = 0; j < nch; j++) {
                 const uint32_t nbj = batches_of(j, w), nbn = batches_of(j + 1, w), cidn = j + 1 < nch ? tt.chunk_ids[j + 1] : 0;
-                if (nbj > 0xFFFFu || nbn > 0xFFFFu || cidn > 0xFFFFu) out.header_overflow = true;
-                out.tok[at] |= nbj << 16;
-                out.tok[at + 1] |= nbn << 16;
-                out.tok[at + 2] |= cidn << 16;
+                if (nbj > LDS_HDR_MAX || nbn > LDS_HDR_MAX || cidn > LDS_HDR_MAX) out.header_overflow = true;
+                out.tok[at] |= nbj << LDS_HDR_SHIFT;
+                out.tok[at + 1] |= nbn << LDS_HDR_SHIFT;
+                out.tok[at + 2] |= cidn << LDS_HDR_SHIFT;
                 at += (uint64_t)nbj * B;
             }
         }

@@ -132,7 +132,7 @@ struct Part {
     LdsTile *lds_tiles = nullptr;
     int cols_sorted = -1;   // stored order inside every row is column order: -1 = not checked yet, 0 / 1
     uint32_t lds_ntiles = 0, lds_nw = 8, lds_batch = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
-    uint64_t lds_slots = 0, lds_tokens = 0;   // 64 KiB chunk fills per slice and product; tokens incl. padding
+    uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
 
@@ -641,7 +641,7 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
 
 // LDS-staged product (lds_kernel_gen.hpp / lds_plan.hpp): X is copied slice-major in 256-byte slices (64 features, rows padded to
 // whole 256-column chunks), then ONE launch: a 512-thread workgroup per (tile of rows, slice) streams the tile's chunks of X
-// through a double-buffered 128 KiB LDS ring and keeps the tile's running sums in registers; C is written once.
+// through a double-buffered 160 KiB LDS ring (two chunks of 320 columns) and keeps the tile's running sums in registers; C is written once.
 // lds_xs: a slice-major copy the caller already made on this stream (the fused quantiser); deq_amax != nullptr: the store
 // dequantises, C is then the FLOAT result (row stride ldc elements of 4 bytes)
 template <typename T>

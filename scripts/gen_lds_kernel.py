@@ -7,7 +7,7 @@ registers (one 64-feature slice per register, one feature per lane) and picks th
 with the wave-uniform VGPR index (s_set_gpr_idx_*), which HIP C++ cannot express for 200 registers.
 
 Per stored entry (token) the wave issues
-    v_bfi_b32   addr = (token & 0xff00) | (lane * 4 + buffer)      -- row of the X chunk in LDS
+    v_bfi_b32   addr = (token & 0x3ff00) | (lane * 4)              -- row of the X chunk in LDS (the token names the buffer too)
     ds_read_b32 x    = LDS[addr]                                   -- 64 lanes x 4 B, conflict-free
     s_set_gpr_idx_idx token                                        -- M0[7:0] = accumulator index
     v_add       acc[idx] += x
@@ -15,7 +15,7 @@ which is the reference's scratchpad loop (spmm_default/dpu_kernels/spmm_mul_csr_
 accumulators of ~1 500 rows resident per compute unit.  Schedule format: lds_plan.hpp.
 
 Structure of a workgroup (NW waves, one per (tile of rows, 64-feature slice)):
-    for every chunk (slot) of the tile:       -- 64 KiB of one slice of X, double-buffered in LDS
+    for every chunk (slot) of the tile:       -- 80 KiB (320 columns) of one slice of X, double-buffered in LDS
         touch the NEXT slot's token lines (vector load, result unused -> the scalar token loads hit L2)
         LDS-DMA this wave's share of the NEXT chunk (global_load_lds_dwordx4)
         batches of BATCH tokens, software-pipelined: the LDS reads of batch i + 1 are issued before the
@@ -44,7 +44,7 @@ class Geo:
         self.ACC0 = self.X0 + 2 * BATCH
         self.vmax = 512 // (NW // 4)          # VGPRs per lane at NW / 4 waves per SIMD
         assert self.ACC0 + KA + 1 <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
-        self.pieces = 64 // NW                # 1 KiB DMA pieces of a 64 KiB chunk per wave
+        self.pieces = 80 // NW                # 1 KiB DMA pieces of an 80 KiB chunk (320 columns x 256 bytes) per wave
         self.threads = NW * 64
         self.CTL0 = 88                        # control registers s88..s100; token sets below them (s32 is reserved: start at s36)
         self.TOK0 = self.CTL0 - (6 if weighted else 3) * BATCH   # weighted: three more sets for the entries' values
@@ -74,7 +74,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     # control SGPRs
     NBL, NLEFT, CIDN, TMP = (f"s{c + i}" for i in range(4))              # batches left, slots left, next chunk id, temporary
     PA_LO, PA_HI, PA = f"s{c + 4}", f"s{c + 5}", f"s[{c + 4}:{c + 5}]"   # 64-bit temporary (touch / DMA source address); even
-    DLDS, BUF = f"s{c + 6}", f"s{c + 7}"                                   # DMA LDS base (also a temporary), buffer select (0 / 0x10000)
+    DLDS, BUF = f"s{c + 6}", f"s{c + 7}"                                   # DMA LDS base (also a temporary), buffer select (0 / 0x14000: the DMA destination; the reads take the buffer from the token)
     TMP2 = DLDS
     TP_LO, TP_HI, TP = f"s{c + 8}", f"s{c + 9}", f"s[{c + 8}:{c + 9}]"      # token stream of this wave (fixed)
     NBN, TOFF, ROT = (f"s{c + 10 + i}" for i in range(3))                  # batches of the next slot, token offset (newest loaded batch), token-set rotation
@@ -89,15 +89,16 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
 
     def header(r):
         # slot header (lds_plan.hpp): upper halves of tokens 0..2 of the slot's first batch, here in token set r
-        a(f"s_lshr_b32 {NBL}, s{TOK[r]}, 16")         # batches of the slot
-        a(f"s_lshr_b32 {NBN}, s{TOK[r] + 1}, 16")     # batches of the slot after it (token prefetch)
-        a(f"s_lshr_b32 {CIDN}, s{TOK[r] + 2}, 16")    # chunk id of the slot after it (DMA)
+        a(f"s_lshr_b32 {NBL}, s{TOK[r]}, 18")         # batches of the slot
+        a(f"s_lshr_b32 {NBN}, s{TOK[r] + 1}, 18")     # batches of the slot after it (token prefetch)
+        a(f"s_lshr_b32 {CIDN}, s{TOK[r] + 2}, 18")    # chunk id of the slot after it (DMA)
 
     # ---- set-up
     a(f"v_lshlrev_b32 {VL4}, 2, %[lane]")
     a(f"v_lshlrev_b32 {VL16}, 4, %[lane]")
     a(f"v_lshlrev_b32 {VL128}, 7, %[lane]")
-    a(f"v_mov_b32 {VM}, 0xff00")
+    a(f"v_mov_b32 {VM}, 0x3ff00")
+    a(f"v_lshlrev_b32 {VB}, 2, %[lane]")       # (the token carries the LDS row of both buffers: the lane offset is all that is added)
     a(f"v_mov_b32 {VZ}, 0")
     for i in range(KA + 1):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
@@ -116,8 +117,8 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     next_id = [0]
 
     def dma(cid, bufsel_reg):
-        # this wave's 1 KiB pieces of the 64 KiB chunk `cid` -> LDS buffer `bufsel`
-        a(f"s_lshl_b32 {TMP}, {cid}, 16")
+        # this wave's 1 KiB pieces of the 80 KiB chunk `cid` -> LDS buffer `bufsel`
+        a(f"s_mul_i32 {TMP}, {cid}, 0x14000")           # 80 KiB per chunk (chunk ids are 14-bit: no overflow)
         a(f"s_add_u32 {PA_LO}, %[xs_lo], {TMP}")
         a(f"s_addc_u32 {PA_HI}, %[xs_hi], 0")
         a(f"s_add_u32 {DLDS}, {bufsel_reg}, %[ldsw]")
@@ -152,7 +153,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     # the NT youngest) covers the DMA without waiting for the touch.  TP + TOFF = this slot's first batch.
     a(f"s_cmp_gt_u32 {NLEFT}, 1")
     a("s_cbranch_scc0 L_nodma_%=")
-    a(f"s_xor_b32 {TMP2}, {BUF}, 0x10000")
+    a(f"s_xor_b32 {TMP2}, {BUF}, 0x14000")
     dma(CIDN, TMP2)
     a("L_nodma_%=:")
     a(f"s_mul_i32 {TMP}, {NBL}, {BATCH * 4}")
@@ -170,7 +171,6 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
         a(f"s_addc_u32 {PA_HI}, {PA_HI}, 0")
         a(f"global_load_dword {VT1}, {VL128}, {PA}")
     a("s_mov_b64 exec, -1")
-    a(f"v_add_u32 {VB}, {BUF}, {VL4}")
     a(f"s_sub_u32 {NBL}, {NBL}, 1")               # batches left after the one in hand (every list has at least its header batch)
     a(f"s_cmp_eq_u32 {ROT}, 0")
     a("s_cbranch_scc1 L_E0_%=")
@@ -282,7 +282,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a(f"s_waitcnt vmcnt({nt}) lgkmcnt(0)")        # my pieces of the next chunk have landed (the touch behind them may not have)
     if 6 not in AB:
         a("s_barrier")                           # ... and everybody is done reading the current one
-    a(f"s_xor_b32 {BUF}, {BUF}, 0x10000")
+    a(f"s_xor_b32 {BUF}, {BUF}, 0x14000")
     a(f"s_sub_u32 {NLEFT}, {NLEFT}, 1")
     a(f"s_cmp_gt_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_slot_%=")
@@ -357,7 +357,7 @@ HEADER = """// GENERATED by scripts/gen_lds_kernel.py -- do not edit; edit the g
 
 namespace pygim {
 
-constexpr uint32_t LDS_KC = 256, LDS_BYTES = 131072;
+constexpr uint32_t LDS_KC = 320, LDS_BYTES = 163840;   // two 80 KiB chunk buffers = the whole LDS of a CU
 // kernel variants: waves per workgroup -> accumulators per wave, tokens per batch
 constexpr uint32_t lds_ka(uint32_t nw) { return nw == 16 ? %(KA16)du : %(KA8)du; }
 constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du; }

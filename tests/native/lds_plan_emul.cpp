@@ -40,15 +40,20 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
                     // the kernel's scalar side reads nothing but the token stream: batch count / next count / next chunk id
                     // sit in the upper halves of the first three tokens of the slot's first batch
                     if (at + 2 >= plan.tok.size()) return 2;
-                    const uint32_t nb = plan.tok[at] >> 16, nb_next = plan.tok[at + 1] >> 16;
-                    chunk_next = plan.tok[at + 2] >> 16;
+                    const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT, nb_next = plan.tok[at + 1] >> LDS_HDR_SHIFT;
+                    chunk_next = plan.tok[at + 2] >> LDS_HDR_SHIFT;
                     if (nb == 0 || nb != plan.nb[t.nb_off + (size_t)j * NW + w] || chunk != plan.chunks[t.chunk_off + j]) return 11;
                     if (nb_next != (j + 1 < t.nch ? plan.nb[t.nb_off + (size_t)(j + 1) * NW + w] : 0u)) return 12;
                     for (uint32_t b = 0; b < nb * batch; b++, at++) {
                         if (at >= plan.tok.size()) return 2;
                         const uint32_t tk = plan.tok[at];
-                        const uint32_t k = tk & 0xFF, c = (tk >> 8) & 0xFF;
-                        if ((tk >> 16) && b > 2) return 3;   // upper halves are header space in tokens 0..2 of the first batch only
+                        const uint32_t k = tk & 0xFF, ldsrow = (tk >> 8) & 0x3FF;
+                        if ((tk >> LDS_HDR_SHIFT) && b > 2) return 3;   // bits 18.. are header space in tokens 0..2 of the first batch only
+                        // the kernel's LDS ring: slot j streams its chunk into buffer j & 1 = rows [KC * (j & 1), KC * (j & 1) + KC);
+                        // a real token must point into THAT buffer (padding reads row 0 of buffer 0 into the dummy accumulator)
+                        if (k < KA && ldsrow / KC != (j & 1)) return 15;
+                        if (ldsrow >= 2 * KC) return 16;
+                        const uint32_t c = ldsrow % KC;
                         if (k > KA) return 4;
                         const uint64_t xr = (uint64_t)chunk * KC + c;
                         if (k < KA && xr >= ncols) return 5;
