@@ -110,7 +110,22 @@ def self_launch(n_gpus):
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_gpus, 1))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "--max-restarts", "0", os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the children run in a process group of their own: a hung rank (a collective that never completes) is ended -- that group,
+    # by its id, nothing else -- when the launch outlives PYGIM_LAUNCH_TIMEOUT seconds, instead of hanging the caller for good
+    limit = float(os.environ.get("PYGIM_LAUNCH_TIMEOUT", "2400"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        print(f"[bench] the {n_gpus}-rank launch did not finish within {limit:.0f} s: ending its process group", file=sys.stderr)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return 124
 
 
 def main():
