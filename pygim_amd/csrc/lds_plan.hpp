@@ -258,4 +258,199 @@ inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncol
     return (double)nnz / ((double)ntiles * (double)ncols);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same schedule compiled into gfx950 MACHINE CODE ("code stream", round 3): per (tile, wave) one straight-line instruction
+// stream that the kernel jumps into once.  A stored entry is then
+//     ds_read2st64_b32 x[2i : 2i+1], base offset0:row_a offset1:row_b     -- ONE LDS instruction for TWO entries (its two 8-bit
+//                                                                            offsets count 256-byte rows: a chunk's row stride)
+//     v_add_f32 acc[k], x, acc[k]                                         -- the accumulator is the instruction's register field
+// i.e. 1.5 instructions and 8.5 bytes of code per entry, no address arithmetic, no index register, no token loads, no batch
+// bookkeeping and no padding (measured in isolation, scripts/micro/codestream.hip: 2.56 CU cycles per entry streamed from memory
+// once against 3.1-3.3 for the four-instruction token of the token kernels).  The slot boundary (DMA of the next chunk, wait,
+// barrier) is inlined with the chunk ids as literals; every ~6 KB the stream touches its own lines 8 KiB ahead into the L2.
+// Register contract with the kernel (scripts/gen_lds_kernel.py body_code): see LdsCodeRegs.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LdsCodeRegs {
+    // VGPRs
+    uint32_t vbase[3] = {4, 5, 10};   // lane * 4 + 0 / 65536 / 131072 (LDS rows 0..255, 256..511, 512..639)
+    uint32_t vl16 = 6;       // lane * 16 (DMA)
+    uint32_t vl128 = 11;     // lane * 128 (touch)
+    uint32_t vjunk = 9;
+    uint32_t x0 = 12;        // x registers: two sets of 8 (v12..19, v20..27)
+    uint32_t acc0 = 28;      // accumulators v28 .. v28 + KA - 1
+    // SGPRs
+    uint32_t s_xs = 80;      // s[80:81]: this slice of X + wave * PIECE (bytes)
+    uint32_t s_ldsw = 82;    // LDS byte address of this wave's DMA piece inside a chunk buffer
+    uint32_t s_cb = 84;      // s[84:85]: code touch pointer
+    uint32_t s_ret = 86;     // s[86:87]: return address
+    uint32_t s_pa = 92;      // s[92:93]: DMA source
+};
+
+struct LdsCodeHost {
+    std::vector<uint32_t> code;          // all streams, each 256-byte aligned, + slack behind the last (the touches read ahead)
+    std::vector<uint64_t> start;         // [ntiles][NW]: byte offset of a (tile, wave) stream
+    uint64_t entries = 0;                // stored entries compiled (no padding)
+    uint64_t pairs = 0;                  // of which read two to an LDS instruction
+};
+
+// opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000)
+inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0) {
+    const LdsGeometry &geo = plan.geo;
+    const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
+    const LdsCodeRegs R;
+    const uint32_t pieces = (KC * 256 / 1024) / NW;   // 1 KiB DMA pieces of a chunk per wave
+    const uint32_t chunk_bytes = KC * 256;
+    const uint32_t ntiles = plan.ntiles;
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = std::min<unsigned>(threads, std::max(1u, ntiles * NW));
+    constexpr uint32_t TOUCH_EVERY_DW = 1536;         // a touch per 6 KB of code: 64 lines (8 KB) from 8 KiB ahead
+
+    struct Emit {
+        std::vector<uint32_t> w;
+        uint32_t since_touch = 0;
+        void op(uint32_t a) { w.push_back(a); since_touch++; }
+        void op(uint32_t a, uint32_t b) { w.push_back(a); w.push_back(b); since_touch += 2; }
+    };
+    const LdsCodeRegs Rr = R;
+    auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs) {
+        const LdsTile &t = plan.tiles[ti];
+        auto s_add_lit = [&](uint32_t sdst, uint32_t ssrc, uint32_t lit) { e.op(0x80000000u | (sdst << 16) | (0xFFu << 8) | ssrc, lit); };
+        auto s_addc0 = [&](uint32_t sdst, uint32_t ssrc) { e.op(0x82000000u | (sdst << 16) | (0x80u << 8) | ssrc); };
+        auto touch = [&]() {
+            s_add_lit(Rr.s_cb, Rr.s_cb, (e.since_touch + 5) * 4);   // (+ the five dwords of this touch itself)
+            s_addc0(Rr.s_cb + 1, Rr.s_cb + 1);
+            e.op(0xDC508000u, (Rr.vjunk << 24) | (Rr.s_cb << 16) | Rr.vl128);   // global_load_dword vjunk, vl128, s[cb:cb+1]
+            e.since_touch = 0;
+        };
+        auto dma = [&](uint32_t cid, uint32_t buf) {
+            s_add_lit(Rr.s_pa, Rr.s_xs, cid * chunk_bytes);
+            s_addc0(Rr.s_pa + 1, Rr.s_xs + 1);
+            for (uint32_t i = 0; i < pieces; i++) {
+                if (i % 4 == 0) {
+                    if (i) {
+                        s_add_lit(Rr.s_pa, Rr.s_pa, 0x1000);
+                        s_addc0(Rr.s_pa + 1, Rr.s_pa + 1);
+                    }
+                    s_add_lit(124 /* m0 */, Rr.s_ldsw, buf * chunk_bytes + (i / 4) * 0x1000);
+                    e.op(0xBF800000u);                              // s_nop 0 (M0 write -> LDS-DMA)
+                }
+                e.op(0xDDF48000u | ((i % 4) * 1024), (Rr.s_pa << 16) | Rr.vl16);   // global_load_lds_dwordx4 vl16, s[pa:pa+1] offset
+            }
+        };
+        uint64_t at = (uint64_t)t.tokstart[wv] * B;
+        // the first chunk, then the slots
+        if (t.nch) {
+            dma(t.chunk0, 0);
+            e.op(0xBF8C0070u);                                      // s_waitcnt vmcnt(0) lgkmcnt(0)
+            e.op(0xBF8A0000u);                                      // s_barrier
+        }
+        std::vector<uint32_t> toks;
+        for (uint32_t j = 0; j < t.nch; j++) {
+            if (j + 1 < t.nch) dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);
+            const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT;
+            toks.clear();
+            for (uint32_t b = 0; b < nb * B; b++) {
+                const uint32_t tk = plan.tok[at + b] & ((1u << LDS_HDR_SHIFT) - 1);
+                if ((tk & 0xFF) < KA) toks.push_back(tk);
+            }
+            at += (uint64_t)nb * B;
+            // entries of the low LDS block first (stable: a row's entries are in column order, so its order is kept), then pairs
+            std::stable_sort(toks.begin(), toks.end(), [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });   // block = ldsrow >> 8 = token >> 16
+            n_entries += toks.size();
+            // groups of up to 8 entries: reads of group g, wait for group g - 1, adds of group g - 1
+            size_t i = 0;
+            uint32_t gsel = 0, prev_n = 0, prev_x = 0;
+            uint32_t prev_k[8];
+            auto adds_prev = [&]() {
+                for (uint32_t q = 0; q < prev_n; q++) {
+                    const uint32_t vk = Rr.acc0 + prev_k[q];
+                    e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + prev_x + q));
+                }
+            };
+            while (i < toks.size()) {
+                const uint32_t xb = Rr.x0 + 8 * gsel;
+                uint32_t n = 0, nlds = 0, ks[8];
+                while (n < 8 && i < toks.size()) {
+                    const uint32_t r0 = toks[i] >> 8, blk = r0 >> 8;
+                    if (n + 2 <= 8 && (n & 1) == 0 && i + 1 < toks.size() && ((toks[i + 1] >> 8) >> 8) == blk) {
+                        const uint32_t r1 = toks[i + 1] >> 8;
+                        e.op(0xD8700000u | ((r1 & 255) << 8) | (r0 & 255), ((xb + n) << 24) | Rr.vbase[blk]);   // ds_read2st64_b32
+                        ks[n] = toks[i] & 0xFF;
+                        ks[n + 1] = toks[i + 1] & 0xFF;
+                        n += 2;
+                        i += 2;
+                        n_pairs += 2;
+                    } else {
+                        e.op(0xD86C0000u | ((r0 & 255) << 8), ((xb + n) << 24) | Rr.vbase[blk]);             // ds_read_b32
+                        ks[n] = toks[i] & 0xFF;
+                        n += 1;
+                        i += 1;
+                    }
+                    nlds++;
+                }
+                if (prev_n) {
+                    e.op(0xBF8CC07Fu | (nlds << 8));                // s_waitcnt lgkmcnt(nlds): everything older than this group's reads
+                    adds_prev();
+                }
+                prev_n = n;
+                prev_x = xb;
+                for (uint32_t q = 0; q < n; q++) prev_k[q] = ks[q];
+                gsel ^= 1;
+                if (e.since_touch >= TOUCH_EVERY_DW) touch();
+            }
+            e.op(0xBF8CC07Fu);                                      // s_waitcnt lgkmcnt(0): the last group's reads are in
+            adds_prev();
+            e.op(0xBF8C0F70u);                                      // s_waitcnt vmcnt(0): my pieces of the next chunk have landed
+            e.op(0xBF8A0000u);                                      // s_barrier: everybody is done with this chunk and has landed the next
+        }
+        e.op(0xBE801D00u | Rr.s_ret);                               // s_setpc_b64 s[ret:ret+1]
+        while (e.w.size() % 64) e.w.push_back(0xBF800000u);         // streams start on 256-byte lines
+    };
+
+    const uint32_t nstreams = ntiles * NW;
+    std::vector<std::vector<uint32_t>> blobs(nstreams);
+    std::vector<uint64_t> ne(nstreams, 0), np(nstreams, 0);
+    {
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> pool;
+        auto body = [&]() {
+            for (;;) {
+                const uint32_t s = next.fetch_add(1);
+                if (s >= nstreams) return;
+                Emit e;
+                emit_stream(s / NW, s % NW, e, ne[s], np[s]);
+                blobs[s].swap(e.w);
+            }
+        };
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
+        body();
+        for (auto &th : pool) th.join();
+    }
+    out.start.assign(nstreams, 0);
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < nstreams; s++) {
+        out.start[s] = total * 4;
+        total += blobs[s].size();
+        out.entries += ne[s];
+        out.pairs += np[s];
+    }
+    out.code.assign((size_t)total + 8192, 0xBF800000u);             // (+ 32 KB of s_nop behind the last stream: touches read ahead)
+    {
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> pool;
+        auto body = [&]() {
+            for (;;) {
+                const uint32_t s = next.fetch_add(1);
+                if (s >= nstreams) return;
+                std::copy(blobs[s].begin(), blobs[s].end(), out.code.begin() + out.start[s] / 4);
+                std::vector<uint32_t>().swap(blobs[s]);
+            }
+        };
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
+        body();
+        for (auto &th : pool) th.join();
+    }
+}
+
 }  // namespace pygim

@@ -14,6 +14,8 @@
 #include "../../include/pygim_hip.h"
 #include "kernels.hpp"
 #include "lds_kernel_gen.hpp"
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -87,6 +89,7 @@ struct Tunables {
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
     int64_t lds_long_slots = 128;       // tokens per (wave, chunk) from which the 16-token-batch geometry is planned (0 = never)
+    int64_t lds_code = 1;               // 1 = FLT32 / INT32 unit-weight plans are also compiled into machine code (lds_plan.hpp lds_code_from_plan) and run by k_lds_code_*; 0 = the token kernels
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
@@ -132,6 +135,9 @@ struct Part {
     LdsTile *lds_tiles = nullptr;
     int cols_sorted = -1;   // stored order inside every row is column order: -1 = not checked yet, 0 / 1
     uint32_t lds_ntiles = 0, lds_nw = 8, lds_batch = 8, lds_wdelta = 0;   // lds_wdelta != 0: the plan carries the entries' values
+    char *lds_code = nullptr;              // the schedule as gfx950 machine code (EXECUTABLE device memory from the HSA pool), or nullptr
+    uint64_t *lds_code_start = nullptr;    // [ntiles][16]: byte offset of a (tile, wave) stream
+    uint64_t lds_code_bytes = 0, lds_code_pairs = 0;
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
@@ -308,6 +314,68 @@ template <typename P> int to_device(const void *src, size_t bytes, P **dst, bool
     return 0;
 }
 
+// Executable device memory for the code-stream kernels: hipMalloc memory is not executable (an instruction fetch from it faults),
+// the HSA runtime's coarse-grained GPU pool with HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG is (it is what the loader puts kernels in).
+struct ExecPool {
+    bool tried = false, ok = false;
+    hsa_agent_t agent{};
+    hsa_amd_memory_pool_t pool{};
+};
+static std::map<int, ExecPool> g_exec_pools;   // per HIP device ordinal (guarded by g_ctx.mu)
+static ExecPool *exec_pool_locked(int dev) {
+    ExecPool &ep = g_exec_pools[dev];
+    if (ep.tried) return ep.ok ? &ep : nullptr;
+    ep.tried = true;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;   // (reference-counted: HIP holds the runtime open already)
+    struct Find { int want, seen; hsa_agent_t agent; bool found; } f{dev, 0, {}, false};
+    hsa_iterate_agents([](hsa_agent_t a, void *d) -> hsa_status_t {
+        Find *f = (Find *)d;
+        hsa_device_type_t t;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+        if (f->seen++ == f->want) { f->agent = a; f->found = true; return HSA_STATUS_INFO_BREAK; }
+        return HSA_STATUS_SUCCESS;
+    }, &f);
+    if (!f.found) return nullptr;
+    struct FindPool { hsa_amd_memory_pool_t pool; bool found; } fp{{}, false};
+    hsa_amd_agent_iterate_memory_pools(f.agent, [](hsa_amd_memory_pool_t p, void *d) -> hsa_status_t {
+        FindPool *fp = (FindPool *)d;
+        hsa_amd_segment_t seg;
+        uint32_t flags = 0;
+        bool alloc = false;
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+        if (seg == HSA_AMD_SEGMENT_GLOBAL && alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED)) {
+            fp->pool = p;
+            fp->found = true;
+            return HSA_STATUS_INFO_BREAK;
+        }
+        return HSA_STATUS_SUCCESS;
+    }, &fp);
+    if (!fp.found) return nullptr;
+    ep.agent = f.agent;
+    ep.pool = fp.pool;
+    ep.ok = true;
+    return &ep;
+}
+static void *exec_alloc_upload(const void *host, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    ExecPool *ep;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx.mu);
+        ep = exec_pool_locked(dev);
+    }
+    if (!ep) return nullptr;
+    void *ptr = nullptr;
+    if (hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) return nullptr;
+    if (hsa_amd_agents_allow_access(1, &ep->agent, nullptr, ptr) != HSA_STATUS_SUCCESS || hsa_memory_copy(ptr, host, bytes) != HSA_STATUS_SUCCESS) {
+        (void)hsa_amd_memory_pool_free(ptr);
+        return nullptr;
+    }
+    return ptr;
+}
+
 void free_part(Part &p) {
     if (p.own_rowptr && p.rowptr) (void)hipFree(p.rowptr);
     if (p.own_rowind && p.rowind) (void)hipFree(p.rowind);
@@ -326,6 +394,10 @@ void free_part(Part &p) {
         if (q) (void)hipFree(q);
     p.lds_tok = p.lds_nb = p.lds_chunks = p.lds_rowmap = nullptr;
     p.lds_tiles = nullptr;
+    if (p.lds_code) (void)hsa_amd_memory_pool_free(p.lds_code);
+    if (p.lds_code_start) (void)hipFree(p.lds_code_start);
+    p.lds_code = nullptr;
+    p.lds_code_start = nullptr;
     if (p.extra) free_part(*p.extra);
 }
 
@@ -752,6 +824,14 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }
     if (deq_amax && g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate is a timing experiment of the plain kernel");
+    if constexpr (sizeof(T) == 4) {
+        if (p.lds_code && g_tune.lds_code && p.lds_nw == 16 && !p.lds_wdelta && !long16 && !g_tune.lds_ablate) {   // the schedule compiled into machine code
+            if constexpr (std::is_same<T, float>::value) fn = deq_amax ? k_lds_code_f32_deq : k_lds_code_f32;
+            else fn = deq_amax ? k_lds_code_i32_deq : k_lds_code_i32;
+            a.code = p.lds_code;
+            a.code_start = p.lds_code_start;
+        }
+    }
     {
         static std::set<std::pair<int, KernelFn>> attr_done;   // (the attribute is per device)
         int dev = 0;
@@ -1003,6 +1083,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint);
+static thread_local int t_plan_dtype = -1;   // element type of the group being created (the plan builders see the element SIZE only)
 
 int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0, bool allow_lds = true) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
@@ -1202,7 +1283,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
                    p.vals ? h_val.data() : nullptr);
     // long slots (a community-structured graph: a tile streams few chunks, a wave gets hundreds of tokens per chunk): the per-batch
     // bookkeeping is what is left to save -- the 16-token-batch geometry, when the tiles fit its 80 accumulators per wave
-    if (geo.NW == 16 && !p.vals && g_tune.lds_long_slots && plan.slots > 0 &&
+    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals && es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32);
+    if (geo.NW == 16 && !p.vals && !want_code && g_tune.lds_long_slots && plan.slots > 0 &&
         (double)plan.ntokens / ((double)plan.slots * geo.NW) >= (double)g_tune.lds_long_slots) {
         LdsGeometry gl = geo;
         gl.KA = LDS_L16_KA;
@@ -1235,6 +1317,21 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     if (plan.header_overflow) return 0;  // a slot header field would not fit 16 bits (a wave with > 65 535 batches in one chunk)
     if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles))
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
+    if (want_code) {
+        // the same schedule as machine code (1.5 instructions per stored entry instead of 4 + bookkeeping): executable memory
+        LdsCodeHost ch;
+        lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : 0x68000000u, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+        void *code = exec_alloc_upload(ch.code.data(), ch.code.size() * 4);
+        if (code) {
+            if (!up(&p.lds_code_start, ch.start)) {
+                (void)hsa_amd_memory_pool_free(code);
+                return fail(PYGIM_ERR_HIP, "code-stream offsets upload");
+            }
+            p.lds_code = (char *)code;
+            p.lds_code_bytes = ch.code.size() * 4;
+            p.lds_code_pairs = ch.pairs;
+        }
+    }
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
     p.lds_batch = geo.BATCH;
@@ -1949,6 +2046,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_waves") slot = &g_tune.lds_waves;
     else if (n == "lds_ablate") slot = &g_tune.lds_ablate;
     else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
+    else if (n == "lds_code") slot = &g_tune.lds_code;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
@@ -1975,6 +2073,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
     Group *g = new Group;
     g->format = format;
     g->dtype = dtype;
+    t_plan_dtype = dtype;
     g->h = h_size;
     g->total_rows = nrows[0];
     g->parts.resize(n_parts);

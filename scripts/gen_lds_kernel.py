@@ -56,7 +56,7 @@ GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 GEO_L16 = Geo(16, 80, 16, 4)                 # long slots (community-structured graphs): 16-token batches halve the per-batch bookkeeping
 
 
-def body(op_add, g, ablate=0, op_mul=None, deq=None):
+def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
     3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
     6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
@@ -102,6 +102,23 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None):
     a(f"v_mov_b32 {VZ}, 0")
     for i in range(KA + 1):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
+    if code:
+        # CODE-STREAM form (lds_plan.hpp lds_code_from_plan): the whole slot loop -- DMA of the chunks, the entries' LDS reads and
+        # adds, waits and barriers -- is ONE straight-line instruction stream per (tile, wave), compiled from the schedule when the
+        # group is created; the kernel sets up its registers (LdsCodeRegs), jumps into it and comes back for the store stage
+        a(f"v_add_u32 {VM}, 0x10000, {VB}")        # LDS rows 256..511
+        a(f"v_add_u32 {VZ}, 0x20000, {VB}")        # LDS rows 512..639
+        a("s_icache_inv")                          # (the code of a freed group may have lived at these addresses)
+        a("s_cmp_eq_u32 %[nch], 0")
+        a("s_cbranch_scc1 L_out_%=")
+        a("s_mov_b32 s80, %[xs_lo]")
+        a("s_mov_b32 s81, %[xs_hi]")
+        a("s_mov_b32 s82, %[ldsw]")
+        a("s_mov_b64 s[84:85], %[code]")
+        a("s_add_u32 s84, s84, 0x2000")            # the stream touches its own lines 8 KiB ahead
+        a("s_addc_u32 s85, s85, 0")
+        a("s_swappc_b64 s[86:87], %[code]")
+        a("s_branch L_out_%=")                     # (the token loop below is not part of this form)
     a(f"s_mov_b64 {TP}, %[tok]")
     a(f"s_mov_b32 {NLEFT}, %[nch]")
     a(f"s_mov_b32 {BUF}, 0")
@@ -377,6 +394,8 @@ struct LdsArgs {
     int deq_log2;
     const float *post_mul, *post_add;  // dequantising kernels: per-column epilogue of the store, y = post_mul[f] * y + post_add[f]
     int post_relu;                     // (nullptr = none; then max(y, 0) when set) -- the sweep's fused store does the same
+    const char *code;                  // code-stream kernels: the compiled schedule (executable memory) and the byte offset of
+    const uint64_t *code_start;        // every (tile, wave) stream in it
 };
 """
 
@@ -415,12 +434,13 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
 #undef PYGIM_SU
     const uint64_t tok_s = ((uint64_t)tok_hi << 32) | tok_lo, rm_s = ((uint64_t)rm_hi << 32) | rm_lo;
 %(post_decl2)s
+%(code_decl)s
     asm volatile(
 %(asm)s
         :
         : [lane] "v"(lane), [tok] "s"(tok_s), [cid0] "s"(cid0), [nch] "s"(nch), [xs_lo] "s"(xs_lo),
           [xs_hi] "s"(xs_hi), [rowmap] "s"(rm_s), [c_lo] "s"(c_lo), [c_hi] "s"(c_hi), [ldc] "s"(a.ldc_bytes),
-          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale), [wave] "s"(wave)%(post_ops)s
+          [wvalid] "s"(wvalid), [accum] "s"(a.accumulate), [ldsw] "s"(ldsw), [wdelta] "s"(a.wdelta), [scale] "s"(scale), [wave] "s"(wave)%(post_ops)s%(code_ops)s
         : %(clobbers)s, "vcc", "scc", "memory");
 #undef PYGIM_SU2
 }
@@ -447,13 +467,19 @@ def main():
                           ("i16", "v_pk_add_u16", None)):
         variants.append((f"k_lds_spmm_{base}_w16b" + ("_deq" if deq else ""), op, "L16", 0,
                          "the same for plans with long slots: 16-token batches, 80 accumulators per wave", None, deq))
+    # the code-stream form (the schedule compiled into machine code, lds_plan.hpp lds_code_from_plan): 16 waves, unit weights
+    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32")):
+        variants.append((f"k_lds_code_{base}" + ("_deq" if deq else ""), op, 16, 0,
+                         "CODE-STREAM form: the slot loop is a straight-line instruction stream compiled from the schedule (1.5 instructions per stored entry)",
+                         None, deq))
     for v in variants:
         name, op, nw, ab, doc = v[:5]
         op_mul = v[5] if len(v) > 5 else None
         deq = v[6] if len(v) > 6 else None
         g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq))
+        is_code = "_code" in name
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code))
         guard = "_ab" in name   # ablation builds (timing experiments, wrong results) only with -DPYGIM_LDS_ABLATE (make ablate)
         if guard:
             text += "\n#ifdef PYGIM_LDS_ABLATE"
@@ -465,7 +491,11 @@ def main():
                                          "padd = a.post_mul ? (uint64_t)(a.post_add + slice * 64u) : 0ull;\n" if deq else ""),
                               post_decl2=("    const uint64_t pmul_s = ((uint64_t)PYGIM_SU2(pmul >> 32) << 32) | PYGIM_SU2(pmul), "
                                           "padd_s = ((uint64_t)PYGIM_SU2(padd >> 32) << 32) | PYGIM_SU2(padd);" if deq else ""),
-                              post_ops=(',\n          [pmul] "s"(pmul_s), [padd] "s"(padd_s), [relu] "s"(a.post_relu)' if deq else ""))
+                              post_ops=(',\n          [pmul] "s"(pmul_s), [padd] "s"(padd_s), [relu] "s"(a.post_relu)' if deq else ""),
+                              code_decl=("    const uint64_t code_a = (uint64_t)(a.code + a.code_start[(uint64_t)ti * NW + wave]);\n"
+                                         "    const uint64_t code_s = ((uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(code_a >> 32))) << 32) | "
+                                         "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)code_a);" if is_code else ""),
+                              code_ops=(',\n          [code] "s"(code_s)' if is_code else ""))
         if guard:
             text += "#endif  // PYGIM_LDS_ABLATE\n"
     text += "\n}  // namespace pygim\n"

@@ -106,3 +106,177 @@ int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, ui
 extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32_t nslices, uint32_t cus) {
     return lds_rows_per_tile(nrows, rmax, nslices, cus);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The code-stream form (lds_code_from_plan): a CPU interpreter of exactly the instructions the stream may contain.  It models
+// what the hardware would do with them -- the two 80 KiB chunk buffers in LDS filled by the DMA sequences (chunk id and
+// destination decoded from the literals), the x registers written by ds_read_b32 / ds_read2st64_b32 (base register + offsets),
+// the accumulators named by the add's register field, lgkmcnt waits (an add must not read an x register whose read is still
+// "in flight": in-order LDS returns, so a wait for N outstanding reads retires all but the N youngest) -- and rejects anything else.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
+                    uint32_t threads, uint64_t *stats) {
+    LdsGeometry geo;
+    geo.NW = 16;
+    geo.KA = 96;
+    geo.BATCH = 8;
+    LdsPlanHost plan;
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, nullptr);
+    if (plan.header_overflow) return 13;
+    const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
+    LdsCodeHost ch;
+    lds_code_from_plan(plan, opcode, ch, threads);
+    const LdsCodeRegs R;
+    const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, chunk_bytes = KC * 256;
+    const uint32_t nslices = (h + 63) / 64;
+    if (stats) {
+        stats[0] = plan.ntiles;
+        stats[1] = ch.code.size() * 4;
+        stats[2] = ch.entries;
+        stats[3] = ch.pairs;
+    }
+    uint64_t entries_seen = 0;
+    std::vector<char> written((size_t)nrows, 0);
+    for (uint32_t ti = 0; ti < plan.ntiles; ti++) {
+        for (uint32_t s = 0; s < nslices; s++) {
+            const uint32_t wvalid = std::min(64u, h - s * 64);
+            // LDS as the 16 waves of the workgroup see it: which chunk each buffer holds (the DMA of all waves lands the same chunk)
+            for (uint32_t w = 0; w < NW; w++) {
+                std::vector<T> acc((size_t)KA * 64, T(0));
+                int64_t buf_chunk[2] = {-1, -1};
+                int64_t pending_chunk[2] = {-1, -1};          // DMA issued, not yet waited for (vmcnt(0)) + barrier
+                struct XReg { bool valid = false, inflight = false; uint32_t ldsrow = 0; };
+                XReg x[16];
+                std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
+                uint64_t pc = ch.start[(size_t)ti * NW + w] / 4;
+                uint64_t pa = 0;                              // DMA source offset inside the slice (bytes), from the literal
+                int64_t dma_buf = -1, dma_cid = -1;
+                uint32_t pieces_seen = 0;
+                const uint32_t pieces = (KC * 256 / 1024) / NW;
+                bool done = false;
+                for (uint64_t guard = 0; !done; guard++) {
+                    if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
+                    const uint32_t i0 = ch.code[pc];
+                    if (i0 == 0xBF800000u) { pc++; continue; }                                  // s_nop 0
+                    if (i0 == 0xBF8A0000u) {                                                    // s_barrier: pending DMAs become visible
+                        for (int b = 0; b < 2; b++)
+                            if (pending_chunk[b] >= 0) { buf_chunk[b] = pending_chunk[b]; pending_chunk[b] = -1; }
+                        pc++;
+                        continue;
+                    }
+                    if ((i0 & 0xFFFFF0FFu) == 0xBF8CC07Fu) {                                    // s_waitcnt lgkmcnt(n)
+                        const uint32_t n = (i0 >> 8) & 0xF;
+                        while (fifo.size() > n) { x[fifo.front()].inflight = false; fifo.erase(fifo.begin()); }
+                        pc++;
+                        continue;
+                    }
+                    if (i0 == 0xBF8C0F70u || i0 == 0xBF8C0070u) {                               // s_waitcnt vmcnt(0) [lgkmcnt(0)]
+                        if (i0 == 0xBF8C0070u) { for (uint32_t r : fifo) x[r].inflight = false; fifo.clear(); }
+                        pc++;
+                        continue;
+                    }
+                    if (i0 == (0xBE801D00u | R.s_ret)) { done = true; continue; }                // s_setpc_b64: back to the kernel
+                    if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_xs) && ((i0 >> 16) & 0xFF) == R.s_pa) {   // s_add_u32 pa, xs, literal (chunk)
+                        pa = ch.code[pc + 1];
+                        if (pa % chunk_bytes) return 21;
+                        dma_cid = pa / chunk_bytes;
+                        pieces_seen = 0;
+                        pc += 2;
+                        continue;
+                    }
+                    if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_pa) && ((i0 >> 16) & 0xFF) == R.s_pa) {   // s_add_u32 pa, pa, 0x1000
+                        if (ch.code[pc + 1] != 0x1000) return 22;
+                        pc += 2;
+                        continue;
+                    }
+                    if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_cb) && ((i0 >> 16) & 0xFF) == R.s_cb) { pc += 2; continue; }   // touch pointer
+                    if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_ldsw) && ((i0 >> 16) & 0xFF) == 124) {    // s_add_u32 m0, ldsw, literal
+                        const uint32_t lit = ch.code[pc + 1];
+                        dma_buf = lit / chunk_bytes;
+                        if (dma_buf > 1 || (lit % chunk_bytes) != (pieces_seen / 4) * 0x1000) return 23;
+                        pc += 2;
+                        continue;
+                    }
+                    if ((i0 & 0xFF00FF00u) == 0x82008000u) { pc++; continue; }                  // s_addc_u32 x, x, 0
+                    if ((i0 & 0xFFFF8000u) == 0xDDF48000u) {                                    // global_load_lds_dwordx4 (one DMA piece)
+                        if (ch.code[pc + 1] != ((R.s_pa << 16) | R.vl16) || (i0 & 0x1FFF) != (pieces_seen % 4) * 1024 || dma_buf < 0) return 24;
+                        // the buffer being filled must not be the one this slot reads from: checked at the reads below
+                        if (++pieces_seen == pieces) pending_chunk[dma_buf] = dma_cid;
+                        pc += 2;
+                        continue;
+                    }
+                    if ((i0 & 0xFFFF8000u) == 0xDC508000u) { pc += 2; continue; }               // global_load_dword (touch)
+                    if ((i0 & 0xFFFF0000u) == 0xD8700000u || (i0 & 0xFFFF0000u) == 0xD86C0000u) {   // ds_read2st64_b32 / ds_read_b32
+                        const bool two = (i0 & 0xFFFF0000u) == 0xD8700000u;
+                        const uint32_t i1 = ch.code[pc + 1], vdst = i1 >> 24, vaddr = i1 & 0xFF;
+                        int blk = -1;
+                        for (int b = 0; b < 3; b++) if (vaddr == R.vbase[b]) blk = b;
+                        if (blk < 0 || vdst < R.x0 || vdst + (two ? 1 : 0) >= R.x0 + 16 || (two && (vdst & 1))) return 25;
+                        const uint32_t rows[2] = {two ? (i0 & 0xFF) : ((i0 & 0xFFFF) >> 8), two ? ((i0 >> 8) & 0xFF) : 0};
+                        if (!two && (i0 & 0xFF)) return 26;
+                        for (int q = 0; q < (two ? 2 : 1); q++) {
+                            XReg &xr = x[vdst - R.x0 + q];
+                            if (xr.inflight) return 27;                                         // overwritten before it was consumed
+                            xr.valid = true;
+                            xr.inflight = true;
+                            xr.ldsrow = blk * 256 + rows[q];
+                            if (xr.ldsrow >= 2 * KC) return 28;
+                            if (pending_chunk[xr.ldsrow / KC] >= 0) return 29;                  // reading a buffer whose DMA has not been fenced
+                        }
+                        fifo.push_back(vdst - R.x0);   // (a pair retires as one LDS instruction: both registers with the first index)
+                        if (two) x[vdst - R.x0 + 1].inflight = true;
+                        pc += 2;
+                        continue;
+                    }
+                    if ((i0 & 0xFE000000u) == opcode) {                                         // v_add acc[k], x, acc[k]
+                        const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, src0 = i0 & 0x1FF;
+                        if (vd != vs1 || vd < R.acc0 || vd >= R.acc0 + KA || src0 < 256 + R.x0 || src0 >= 256 + R.x0 + 16) return 30;
+                        XReg &xr = x[src0 - 256 - R.x0];
+                        // a pair's second register retires with the pair: find whether its instruction is still in the fifo
+                        bool infl = false;
+                        for (uint32_t r : fifo) if (r == src0 - 256 - R.x0 || (r + 1 == src0 - 256 - R.x0 && x[r + 1].inflight && x[r].inflight)) infl = true;
+                        if (!xr.valid || infl) return 31;                                       // the read has not been waited for
+                        xr.inflight = false;
+                        const int64_t chunk = buf_chunk[xr.ldsrow / KC];
+                        if (chunk < 0) return 32;
+                        const uint64_t xrow = (uint64_t)chunk * KC + xr.ldsrow % KC;
+                        const uint32_t k = vd - R.acc0;
+                        for (uint32_t l = 0; l < wvalid; l++) {
+                            const T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
+                            T &a = acc[(size_t)k * 64 + l];
+                            if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)xv);
+                            else a = a + xv;
+                        }
+                        if (s == 0) entries_seen++;
+                        pc++;
+                        continue;
+                    }
+                    return 40;   // an instruction the stream must not contain
+                }
+                for (uint32_t k = 0; k < KA; k++) {
+                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * KA + k];
+                    if (row == 0xFFFFFFFFu) continue;
+                    if (row >= nrows) return 7;
+                    if (s == 0) written[row]++;
+                    for (uint32_t l = 0; l < wvalid; l++) C[(size_t)row * h + s * 64 + l] = acc[(size_t)k * 64 + l];
+                }
+            }
+        }
+    }
+    for (uint32_t r = 0; r < nrows; r++)
+        if (written[r] != 1) return 8;
+    if (entries_seen != (uint64_t)rowptr[nrows]) return 41;   // every stored entry exactly once, no padding
+    return 0;
+}
+
+extern "C" {
+int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
+                 uint32_t threads, uint64_t *stats) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats);
+}
+int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
+                 uint32_t threads, uint64_t *stats) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats);
+}
+}

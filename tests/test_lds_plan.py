@@ -139,3 +139,38 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
         base_rounds = -(-(152 * nsl) // 256)
         assert rpt <= 1536 and -(-(tiles * nsl) // 256) == base_rounds, (nsl, rpt, tiles)
     assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
+
+
+def _run_code(emul, rowptr, col, ncols, x, threads=4):
+    nrows = len(rowptr) - 1
+    h = x.shape[1]
+    out = np.full((nrows, h), 77, dtype=x.dtype)
+    stats = (ctypes.c_uint64 * 4)()
+    fn = emul.lds_code_f32 if x.dtype == np.float32 else emul.lds_code_i32
+    rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
+    xx = np.ascontiguousarray(x)
+    rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
+            out.ctypes.data_as(ctypes.c_void_p), threads, stats)
+    assert rc == 0, f"the interpreter rejected the code stream (code {rc})"
+    return out, list(stats)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+@pytest.mark.parametrize("shape", [(1, 1, 3), (300, 700, 64), (3000, 2500, 100), (1700, 5000, 256), (5000, 300, 65)])
+def test_code_stream_interpreted_equals_oracle(emul, dtype, shape):
+    """the schedule compiled into gfx950 machine code (lds_plan.hpp lds_code_from_plan), run by a CPU interpreter of exactly the
+    instructions it may contain (DMA literals -> which chunk sits in which LDS buffer, reads -> x registers, adds -> accumulators,
+    waits -> which reads have landed): every stored entry exactly once, rows summed in stored order (floats bit-identical)"""
+    nrows, ncols, h = shape
+    rng = np.random.default_rng(nrows * 11 + h)
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=12, long_rows=[(0, min(3000, 4 * ncols))] if nrows > 100 else ())
+    if dtype == np.float32:
+        x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    else:
+        x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    got, stats = _run_code(emul, rowptr, col, ncols, x)
+    assert got.tobytes() == want.tobytes()
+    assert stats[2] == len(col) and stats[1] % 256 == 0          # no padding entries; streams on 256-byte lines (+ slack)
+    if len(col) > 1000:
+        assert stats[3] > 0.8 * len(col)                          # most entries are read two to an LDS instruction
