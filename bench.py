@@ -373,7 +373,7 @@ def main():
             tj = json.load(open(args.traffic_json))
             traffic = tj.get("hbm_bytes_per_product")
             lds_now = _lib.group_lds_plan(handles[0])["tiles"] > 0
-            if lds_now != ("k_lds_spmm" in str(tj.get("kernel"))):
+            if lds_now != ("k_lds_spmm" in str(tj.get("kernel")) or "k_lds_code" in str(tj.get("kernel"))):
                 traffic = None  # the committed counter run is of the other kernel family: nothing to replay
             traffic_source = {"replayed_from": os.path.relpath(args.traffic_json, ROOT), "collected": tj.get("collected"),
                               "box": tj.get("box"), "command": tj.get("command"), "kernel_ms_then": tj.get("kernel_ms")}
@@ -389,16 +389,22 @@ def main():
         nsl = (my_h + 63) // 64
         # (plans with long slots -- >= 128 tokens per wave and chunk -- take the 16-token-batch form of the kernel, pygim_hip.hip lds_long_slots)
         long_slots = lds_info["chunk_fills"] > 0 and lds_info["tokens"] / (lds_info["chunk_fills"] * 16) >= 128
-        kname = (f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16{'b' if long_slots else ''} (ONE launch per product: {lds_info['tiles']} row tiles x "
-                 f"{nsl} slices)")
+        code_info = _lib.group_lds_code(handles[0])
+        if code_info["active"]:   # the schedule compiled into machine code (k_lds_code_*: 1.5 instructions per stored entry)
+            kname = (f"k_slice_pack<float,4,4> + k_lds_code_f32 (ONE launch per product: {lds_info['tiles']} row tiles x {nsl} slices; "
+                     f"{code_info['code_bytes'] / 1e9:.2f} GB of generated gfx950 code per graph)")
+        else:
+            kname = (f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16{'b' if long_slots else ''} (ONE launch per product: {lds_info['tiles']} row tiles x "
+                     f"{nsl} slices)")
         launches = 1
         staged = lds_info["chunk_fills"] * 81920 * nsl     # 80 KiB chunks: 320 columns x 256 bytes
-        on_chip = {"level": "LDS (ds_read_b32, one 256-byte row slice per stored entry and slice)", "gather_bytes": gather,
+        on_chip = {"level": "LDS (one 256-byte row slice per stored entry and slice: ds_read_b32, or ds_read2st64_b32 for two entries)", "gather_bytes": gather,
                    "achieved_TBs": round(gather / (k_ms * 1e-3) / 1e12, 2) if k_ms else None, "peak_TBs": round(LDS_READ_B32_TBS, 1),
                    "frac": round(gather / (k_ms * 1e-3) / 1e12 / LDS_READ_B32_TBS, 4) if k_ms else None,
                    "staged_L2_to_LDS_bytes": staged,
                    "staged_TBs": round(staged / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
-                   "tokens_incl_padding": lds_info["tokens"]}
+                   "tokens_incl_padding": lds_info["tokens"],
+                   **({"code_stream": code_info, "instruction_fetch_bytes": code_info["code_bytes"] * nsl} if code_info["active"] else {})}
     else:
         # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
         amode = 3 if plan_info["col16"] else 2

@@ -207,13 +207,18 @@ int pygim_group_plan(int64_t handle, int64_t out[8]);
  * spmm_mul_csr_dpu.c:108-126 with X chunks in LDS and the running sums of a tile of rows in registers) of the same matrix:
  * row tiles (0 = no such plan), 80 KiB (320-column) chunk fills per 64-feature slice and product, tokens incl. padding, stored entries */
 int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
+/* the same schedule compiled into gfx950 machine code (the code-stream form of the product, k_lds_code_*: one straight-line
+ * instruction stream per (row tile, wave), 1.5 instructions per stored entry): bytes of code (0 = none), stored entries that share
+ * an LDS instruction with a neighbour, 1 when products take this form (tunable "lds_code"), 0 */
+int pygim_group_lds_code(int64_t handle, int64_t out[4]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
  * "split_unit_pattern", "narrow_vals" (INT64 / DBL64 values that all fit int32 / float exactly are streamed in 4 bytes), "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
  * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),
- * "lds_round_tiles", "lds_ablate" (timing experiments, wrong results)};
+ * "lds_round_tiles", "lds_code" (1 = FLT32 / INT32 unit-weight plans are compiled into machine code at creation and run by k_lds_code_*,
+ * 0 = the token kernels), "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, narrow_vals, merge_parts at creation) are read when a group is created; the others per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

@@ -347,7 +347,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         }
         std::vector<uint32_t> toks;
         for (uint32_t j = 0; j < t.nch; j++) {
-            if (j + 1 < t.nch) dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);
+            bool dma_due = j + 1 < t.nch;     // the next chunk's DMA goes behind the slot's FIRST group of reads (their LDS latency covers its issue)
             const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT;
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
@@ -389,6 +389,10 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     }
                     nlds++;
                 }
+                if (dma_due) {
+                    dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);
+                    dma_due = false;
+                }
                 if (prev_n) {
                     e.op(0xBF8CC07Fu | (nlds << 8));                // s_waitcnt lgkmcnt(nlds): everything older than this group's reads
                     adds_prev();
@@ -399,6 +403,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 gsel ^= 1;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }
+            if (dma_due) dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);   // (a slot without entries for this wave)
             e.op(0xBF8CC07Fu);                                      // s_waitcnt lgkmcnt(0): the last group's reads are in
             adds_prev();
             e.op(0xBF8C0F70u);                                      // s_waitcnt vmcnt(0): my pieces of the next chunk have landed

@@ -2360,6 +2360,17 @@ int pygim_group_lds_plan(int64_t handle, int64_t out[4]) {
     return 0;
 }
 
+int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    out[0] = p.lds_code ? (int64_t)p.lds_code_bytes : 0;
+    out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
+    out[2] = (p.lds_code && g_tune.lds_code) ? 1 : 0;
+    out[3] = 0;
+    return 0;
+}
+
 int pygim_group_info(int64_t handle, int64_t out[8]) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");

@@ -29,7 +29,7 @@ open(os.path.join(root, "summary.txt"), "w").write(txt + "\n")
 # FETCH_SIZE (KiB) reads 1/2 of the bytes of wide reads on gfx950 -> doubled; WRITE_SIZE (KiB) exact.
 dom = None
 for (k, c), (tot, n) in agg.items():
-    if c == "FETCH_SIZE" and ("k_lds_spmm" in k or "k_csr_panel" in k or "k_csr_wide" in k or "k_coo_wide" in k):
+    if c == "FETCH_SIZE" and ("k_lds_spmm" in k or "k_lds_code" in k or "k_csr_panel" in k or "k_csr_wide" in k or "k_coo_wide" in k):
         if dom is None or tot > agg[(dom, "FETCH_SIZE")][0]:
             dom = k
 if dom and (dom, "WRITE_SIZE") in agg:

@@ -34,6 +34,7 @@ def lds_forced():
     _lib.set_tunable("lds_waves", 16)
     _lib.set_tunable("lds_long_slots", 128)
     _lib.set_tunable("lds_round_tiles", 1)
+    _lib.set_tunable("lds_code", 1)
 
 
 def features(rng, n, h, dt):
@@ -63,12 +64,14 @@ def product(rowptr, col, x, ncols=None, fmt="CSR", row=None, vals=None, want_pla
     return out, plan
 
 
-@pytest.mark.parametrize("waves", [16, 8, "16-long"])
+@pytest.mark.parametrize("waves", ["16-code", 16, 8, "16-long"])
 @pytest.mark.parametrize("dt", [np.float32, np.int32])
 def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
-    # "16-long": the 16-token-batch geometry the plan picks for long slots, forced here for every shape
+    # "16-code": the schedule compiled into machine code (k_lds_code_*, the default form); 16 / 8 / "16-long": the token kernels
+    # ("16-long": the 16-token-batch geometry the plan picks for long slots, forced here for every shape)
     old_long = _lib.set_tunable("lds_long_slots", 1 if waves == "16-long" else 0)
-    _lib.set_tunable("lds_waves", 16 if waves == "16-long" else waves)
+    old_code = _lib.set_tunable("lds_code", 1 if waves == "16-code" else 0)
+    _lib.set_tunable("lds_waves", 16 if waves in ("16-long", "16-code") else waves)
     # (rows, cols, h, mean degree): widths around the 64-feature slice, ragged tiles, one and many chunks, a 5 000-entry row
     for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),
                              (4000, 4000, 33, 30), (2000, 9000, 300, 25), (1500, 300, 64, 250)):   # (the last: hundreds of entries per row and chunk)
@@ -79,6 +82,7 @@ def test_lds_product_is_bit_exact(rng, lds_forced, waves, dt):
         assert got.tobytes() == want.tobytes(), (waves, dt, n, ncols, h)
         assert plan["nnz"] == len(col) and plan["tokens"] >= len(col)
     _lib.set_tunable("lds_long_slots", old_long)
+    _lib.set_tunable("lds_code", old_code)
 
 
 def test_empty_rows_and_empty_matrix(rng, lds_forced):
@@ -210,6 +214,7 @@ def test_random_shapes(seed, lds_forced):
     _lib.set_tunable("lds_waves", int(rng.choice([8, 16])))
     _lib.set_tunable("lds_long_slots", int(rng.choice([0, 1, 128])))
     _lib.set_tunable("lds_round_tiles", int(rng.choice([0, 1])))
+    _lib.set_tunable("lds_code", int(rng.choice([0, 1, 1])))
     dt = [np.float32, np.int32][seed % 2]
     n, ncols = int(rng.integers(1, 6000)), int(rng.integers(1, 6000))
     h = int(rng.integers(33, 320))

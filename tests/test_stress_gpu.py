@@ -111,7 +111,8 @@ def test_random_groups(seed):
              "panel_bytes": int(rng.choice([128 * 64, 4 << 20])), "slice_group_bytes": int(rng.choice([1, 640 << 20])),
              "panel_col16": int(rng.choice([0, 1])), "merge_parts": int(rng.choice([0, 1])),
              "split_unit_pattern": int(rng.choice([0, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
-             "lds_long_slots": int(rng.choice([0, 1, 128])), "narrow_vals": int(rng.choice([0, 1]))}
+             "lds_long_slots": int(rng.choice([0, 1, 128])), "narrow_vals": int(rng.choice([0, 1])),
+             "lds_code": int(rng.choice([0, 1, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
@@ -290,7 +291,7 @@ def test_random_quantised_aggregations(seed):
              "panel_pack": int(rng.choice([0, 1, 1])), "panel_col16": int(rng.choice([0, 1])),
              "slice_group_bytes": int(rng.choice([0, 1, 640 << 20])), "merge_parts": int(rng.choice([0, 1, 1])),
              "fuse_windows": int(rng.choice([0, 1, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
-             "lds_long_slots": int(rng.choice([0, 1, 128]))}
+             "lds_long_slots": int(rng.choice([0, 1, 128])), "lds_code": int(rng.choice([0, 1, 1]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         parts = _col_split(rowptr, col, nrows, ncols, sp_parts)
