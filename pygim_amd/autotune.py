@@ -30,11 +30,11 @@ LAUNCH = 6e-6               # per kernel launch incl. ramp, back to back
 CUS = 256
 LDS_CLOCK = 2.3e9           # Hz held under this kernel (GRBM_GUI_ACTIVE / 8 / time)
 LDS_ROWS_MAX = 16 * 96      # rows of a tile (waves x accumulators per wave)
-LDS_CYC_PER_TOKEN = 3.9     # CU cycles per stored entry and slice (measured: clustered columns, nothing else in the way)
+LDS_CYC_PER_TOKEN = 2.9     # CU cycles per stored entry and slice in the code-stream form (k_lds_code_*; clustered columns: nothing else in the way; the token kernels: 3.9)
 LDS_KC = 320                # columns of a chunk (80 KiB of one 64-feature slice; lds_plan.hpp)
-LDS_CYC_PER_SLOT = 650      # CU cycles per chunk of X beside the tokens (barrier skew, DMA issue, touches)
+LDS_CYC_PER_SLOT = 1030     # CU cycles per chunk of X beside the entries (barrier, DMA issue, landing the chunk; fitted to h = 256 uniform)
 LDS_CYC_FILL = 2875         # CU cycles to land 80 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
-LDS_PAD = 1.085             # tokens incl. batch padding per stored entry (uniform columns)
+LDS_PAD = 1.0               # the code stream has no padding entries (the token kernels: 1.07-1.085)
 LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 

@@ -58,6 +58,9 @@ struct LdsGeometry {
     uint32_t KC = 320;    // columns per chunk: two chunks of 64-feature rows (2 x 80 KiB) fill the 160 KiB of a CU's LDS
     uint32_t BATCH = 16;  // tokens per batch (one scalar load)
     uint32_t rows_per_tile = 0;  // 0 = NW * KA; fewer rows per tile = more, lighter tiles (to fill whole rounds of workgroups)
+    uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
+                                 // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
+                                 // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
 };
 
 struct LdsPlanHost {
@@ -201,7 +204,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
                     const uint32_t c = col[e];
                     const uint32_t j = slot_of[c / KC];
                     const uint64_t at = cursor[(size_t)j * NW + w]++;
-                    out.tok[at] = (((c % KC) + (j & 1) * KC) << 8) | k;   // odd slots read the second LDS buffer: row KC + (c % KC)
+                    out.tok[at] = (((c % KC) + (j % geo.NBUF) * KC) << 8) | k;   // slot j reads LDS buffer j % NBUF: row KC * (j % NBUF) + (c % KC)
                     if (vals) out.wts[at] = vals[e];
                 }
             }
@@ -309,6 +312,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     struct Emit {
         std::vector<uint32_t> w;
         uint32_t since_touch = 0;
+        uint64_t vm_touch = 0;             // touches emitted (vector loads, counted into vmcnt)
         void op(uint32_t a) { w.push_back(a); since_touch++; }
         void op(uint32_t a, uint32_t b) { w.push_back(a); w.push_back(b); since_touch += 2; }
     };
@@ -322,6 +326,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             s_addc0(Rr.s_cb + 1, Rr.s_cb + 1);
             e.op(0xDC508000u, (Rr.vjunk << 24) | (Rr.s_cb << 16) | Rr.vl128);   // global_load_dword vjunk, vl128, s[cb:cb+1]
             e.since_touch = 0;
+            e.vm_touch++;
         };
         auto dma = [&](uint32_t cid, uint32_t buf) {
             s_add_lit(Rr.s_pa, Rr.s_xs, cid * chunk_bytes);
@@ -339,15 +344,32 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             }
         };
         uint64_t at = (uint64_t)t.tokstart[wv] * B;
-        // the first chunk, then the slots
+        const uint32_t NBUF = geo.NBUF;
+        // vector loads issued so far (DMA pieces and touches): the wait for "chunk j + 1 has landed" names how many YOUNGER loads may
+        // still be in flight -- known when the code is generated (vmcnt retires in issue order)
+        uint64_t dma_issued = 0;
+        auto vm_now = [&]() { return dma_issued + e.vm_touch; };    // vector loads issued so far: DMA pieces + touches
+        std::vector<uint64_t> landed_mark(t.nch + NBUF + 1, 0);     // vm_now() right after the last piece of chunk j
+        auto dma_chunk = [&](uint32_t j) {                          // chunk of slot j -> buffer j % NBUF
+            dma(plan.chunks[t.chunk_off + j], j % NBUF);
+            dma_issued += pieces;
+            landed_mark[j] = vm_now();
+        };
+        auto wait_landed = [&](uint32_t j) {                        // s_waitcnt vmcnt(N): everything up to chunk j's last piece has landed
+            const uint64_t younger = vm_now() - landed_mark[j];
+            const uint32_t nn = (uint32_t)std::min<uint64_t>(younger, 63);
+            e.op(0xBF8C0F70u | (nn & 15) | (((nn >> 4) & 3) << 14));
+        };
+        // the first NBUF - 1 chunks, then the slots
         if (t.nch) {
-            dma(t.chunk0, 0);
-            e.op(0xBF8C0070u);                                      // s_waitcnt vmcnt(0) lgkmcnt(0)
+            for (uint32_t j = 0; j + 1 < NBUF && j < t.nch; j++) dma_chunk(j);
+            wait_landed(0);
             e.op(0xBF8A0000u);                                      // s_barrier
         }
         std::vector<uint32_t> toks;
         for (uint32_t j = 0; j < t.nch; j++) {
-            bool dma_due = j + 1 < t.nch;     // the next chunk's DMA goes behind the slot's FIRST group of reads (their LDS latency covers its issue)
+            bool dma_due = j + NBUF - 1 < t.nch;   // the DMA of chunk j + NBUF - 1 (into the buffer the barrier just freed) goes behind the
+                                                   // slot's FIRST group of reads (their LDS latency covers its issue)
             const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT;
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
@@ -390,7 +412,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     nlds++;
                 }
                 if (dma_due) {
-                    dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);
+                    dma_chunk(j + NBUF - 1);
                     dma_due = false;
                 }
                 if (prev_n) {
@@ -403,12 +425,13 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 gsel ^= 1;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }
-            if (dma_due) dma(plan.chunks[t.chunk_off + j + 1], (j + 1) & 1);   // (a slot without entries for this wave)
+            if (dma_due) dma_chunk(j + NBUF - 1);                   // (a slot without entries for this wave)
             e.op(0xBF8CC07Fu);                                      // s_waitcnt lgkmcnt(0): the last group's reads are in
             adds_prev();
-            e.op(0xBF8C0F70u);                                      // s_waitcnt vmcnt(0): my pieces of the next chunk have landed
+            if (j + 1 < t.nch) wait_landed(j + 1);                  // my pieces of the NEXT chunk have landed (younger loads may still fly)
             e.op(0xBF8A0000u);                                      // s_barrier: everybody is done with this chunk and has landed the next
         }
+        e.op(0xBF8C0F70u);                                          // s_waitcnt vmcnt(0): no touch is left in flight
         e.op(0xBE801D00u | Rr.s_ret);                               // s_setpc_b64 s[ret:ret+1]
         while (e.w.size() % 64) e.w.push_back(0xBF800000u);         // streams start on 256-byte lines
     };

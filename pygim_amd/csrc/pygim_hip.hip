@@ -17,6 +17,10 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+// rows of a slice of the slice-major copy: whole chunks of either kernel family (320-column chunks of the token kernels, 192 of the
+// code-stream kernels), so that the DMA of a tile's last chunk stays inside the copy
+constexpr uint64_t LDS_ROWS_PAD = 960;
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -90,6 +94,7 @@ struct Tunables {
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
     int64_t lds_long_slots = 128;       // tokens per (wave, chunk) from which the 16-token-batch geometry is planned (0 = never)
     int64_t lds_code = 1;               // 1 = FLT32 / INT32 unit-weight plans are also compiled into machine code (lds_plan.hpp lds_code_from_plan) and run by k_lds_code_*; 0 = the token kernels
+    int64_t lds_code_nbuf = 0;          // chunk buffers of a code-stream plan: 0 = by the product's width (3 x 192 columns up to two slices, else 2 x 320), 2, 3
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
@@ -138,6 +143,8 @@ struct Part {
     char *lds_code = nullptr;              // the schedule as gfx950 machine code (EXECUTABLE device memory from the HSA pool), or nullptr
     uint64_t *lds_code_start = nullptr;    // [ntiles][16]: byte offset of a (tile, wave) stream
     uint64_t lds_code_bytes = 0, lds_code_pairs = 0;
+    uint32_t lds_code_piece = 0;           // bytes of a chunk one wave DMAs (the code plan's ring geometry)
+    bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
 };
@@ -398,6 +405,7 @@ void free_part(Part &p) {
     if (p.lds_code_start) (void)hipFree(p.lds_code_start);
     p.lds_code = nullptr;
     p.lds_code_start = nullptr;
+    p.lds_is_code = false;
     if (p.extra) free_part(*p.extra);
 }
 
@@ -724,7 +732,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     constexpr int PVEC = 16 / (int)sizeof(T);
     const uint32_t w_lanes = (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);
     const uint32_t nslices = (w + EPS - 1) / EPS;
-    const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
+    const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_ROWS_PAD - 1) / LDS_ROWS_PAD * LDS_ROWS_PAD;
     const size_t need = (size_t)rows_pad * nslices * 256;
     KernelTimer kt(g, st, !p.is_extra);
     XsPin pin;
@@ -825,11 +833,13 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     }
     if (deq_amax && g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate is a timing experiment of the plain kernel");
     if constexpr (sizeof(T) == 4) {
-        if (p.lds_code && g_tune.lds_code && p.lds_nw == 16 && !p.lds_wdelta && !long16 && !g_tune.lds_ablate) {   // the schedule compiled into machine code
+        if (p.lds_is_code) {   // the schedule compiled into machine code
+            if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
             if constexpr (std::is_same<T, float>::value) fn = deq_amax ? k_lds_code_f32_deq : k_lds_code_f32;
             else fn = deq_amax ? k_lds_code_i32_deq : k_lds_code_i32;
             a.code = p.lds_code;
             a.code_start = p.lds_code_start;
+            a.piece_bytes = p.lds_code_piece;
         }
     }
     {
@@ -854,6 +864,7 @@ template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, i
         if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || p.lds_nw != 16) return false;
     }
     if (!p.lds_tiles || g_tune.lds_mode == 2 || (p.vals != nullptr) != (p.lds_wdelta != 0) || g->deq_out || g->pre_xs) return false;
+    if (p.lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return false;   // (a code-stream plan serves no token kernel: the sweep instead)
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode == 1 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0)) return false;  // another kernel was asked for by name
     if ((int64_t)((size_t)w * sizeof(T) / 4) < g_tune.lds_min_width) return false;   // (lanes: 4-byte units of a row)
     if ((uint64_t)ldc * sizeof(T) >= (1ull << 32)) return false;
@@ -1278,12 +1289,24 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
             for (size_t i = 0; i < v16.size(); i++) h_val[i] = (uint32_t)v16[i] * 0x10001u;
         }
     }
+    // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its LDS ring is three
+    // buffers of 192 columns (two chunks in flight), so its plan is built in that geometry and serves no token kernel
+    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals && es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32);
+    if (want_code) {
+        // the ring: two buffers of 320 columns; for products of one or two slices (their workgroups do little but land chunks) three of
+        // 192, two chunks in flight (Reddit h = 64 / 128: 1.06 / 2.04 -> 1.01 / 1.83 ms; h = 256: 3.23 -> 3.39, h = 192: 2.30 -> 3.84)
+        const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + 255) / 256 : 4;
+        const bool three = g_tune.lds_code_nbuf == 3 || (g_tune.lds_code_nbuf == 0 && nsl_hint <= 2);
+        if (three) {
+            geo.KC = LDS_CODE_KC3;
+            geo.NBUF = 3;
+        }
+    }
     LdsPlanHost plan;
     lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
                    p.vals ? h_val.data() : nullptr);
     // long slots (a community-structured graph: a tile streams few chunks, a wave gets hundreds of tokens per chunk): the per-batch
     // bookkeeping is what is left to save -- the 16-token-batch geometry, when the tiles fit its 80 accumulators per wave
-    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals && es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32);
     if (geo.NW == 16 && !p.vals && !want_code && g_tune.lds_long_slots && plan.slots > 0 &&
         (double)plan.ntokens / ((double)plan.slots * geo.NW) >= (double)g_tune.lds_long_slots) {
         LdsGeometry gl = geo;
@@ -1314,23 +1337,26 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         if (hipMalloc((void **)dst, bytes) != hipSuccess) return false;
         return v.empty() || hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (plan.header_overflow) return 0;  // a slot header field would not fit 16 bits (a wave with > 65 535 batches in one chunk)
-    if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles))
-        return fail(PYGIM_ERR_HIP, "LDS plan upload");
+    if (plan.header_overflow) return 0;  // a slot header field would not fit its 14 bits (a wave with > 16 383 batches in one chunk, > 5 M columns)
     if (want_code) {
-        // the same schedule as machine code (1.5 instructions per stored entry instead of 4 + bookkeeping): executable memory
+        // the schedule as machine code (1.5 instructions per stored entry instead of 4 + bookkeeping) in EXECUTABLE memory; the token
+        // stream itself stays on the host (the kernel needs the tile table and the row map only)
         LdsCodeHost ch;
         lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : 0x68000000u, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+        std::vector<uint32_t>().swap(plan.tok);
         void *code = exec_alloc_upload(ch.code.data(), ch.code.size() * 4);
-        if (code) {
-            if (!up(&p.lds_code_start, ch.start)) {
-                (void)hsa_amd_memory_pool_free(code);
-                return fail(PYGIM_ERR_HIP, "code-stream offsets upload");
-            }
-            p.lds_code = (char *)code;
-            p.lds_code_bytes = ch.code.size() * 4;
-            p.lds_code_pairs = ch.pairs;
+        if (!code) return 0;             // (no executable pool on this runtime: the sweep serves the group)
+        if (!up(&p.lds_code_start, ch.start) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles)) {
+            (void)hsa_amd_memory_pool_free(code);
+            return fail(PYGIM_ERR_HIP, "code-stream plan upload");
         }
+        p.lds_code = (char *)code;
+        p.lds_code_bytes = ch.code.size() * 4;
+        p.lds_code_pairs = ch.pairs;
+        p.lds_is_code = true;
+        p.lds_code_piece = geo.KC * 256 / geo.NW;
+    } else if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles)) {
+        return fail(PYGIM_ERR_HIP, "LDS plan upload");
     }
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
@@ -1803,6 +1829,7 @@ static Part *lds_fusable_part(Group *g) {
     if (g->parts.size() == 1) p = &g->parts[0];
     else if (g->merged && g_tune.merge_parts) p = g->merged.get();
     if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || p->lds_nw != 16 || p->nrows == 0 || p->ncols == 0) return nullptr;
+    if (p->lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return nullptr;
     return p;
 }
 
@@ -1829,7 +1856,7 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
             // FUSED on the LDS-staged kernel: the 256-byte-slice copy is written quantised from the float features, the kernel's
             // store dequantises (no quantised matrix, no integer result)
             const uint32_t nslices = (h + 63) / 64;
-            const uint64_t rows_pad = ((uint64_t)p->ncols + LDS_KC - 1) / LDS_KC * LDS_KC;
+            const uint64_t rows_pad = ((uint64_t)p->ncols + LDS_ROWS_PAD - 1) / LDS_ROWS_PAD * LDS_ROWS_PAD;
             void *xs = nullptr;
             {
                 std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -2047,6 +2074,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_ablate") slot = &g_tune.lds_ablate;
     else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
     else if (n == "lds_code") slot = &g_tune.lds_code;
+    else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);
@@ -2366,7 +2394,7 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
     const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
     out[0] = p.lds_code ? (int64_t)p.lds_code_bytes : 0;
     out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
-    out[2] = (p.lds_code && g_tune.lds_code) ? 1 : 0;
+    out[2] = (p.lds_is_code && g_tune.lds_code) ? 1 : 0;
     out[3] = 0;
     return 0;
 }

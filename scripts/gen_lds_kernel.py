@@ -54,6 +54,8 @@ class Geo:
 GEOS = {8: Geo(8, 192, 16, 16), 16: Geo(16, 96, 8, 4)}
 GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 GEO_L16 = Geo(16, 80, 16, 4)                 # long slots (community-structured graphs): 16-token batches halve the per-batch bookkeeping
+GEO_CODE = Geo(16, 96, 8, 4)                 # the code-stream kernels: chunks of 192 columns (48 KiB, three buffers): 3 DMA pieces per wave
+GEO_CODE.pieces = 48 // 16
 
 
 def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
@@ -375,6 +377,9 @@ HEADER = """// GENERATED by scripts/gen_lds_kernel.py -- do not edit; edit the g
 namespace pygim {
 
 constexpr uint32_t LDS_KC = 320, LDS_BYTES = 163840;   // two 80 KiB chunk buffers = the whole LDS of a CU
+// the code-stream kernels take the ring geometry from the plan (LdsArgs.piece_bytes): two buffers of 320 columns, or -- products of
+// one or two slices, whose workgroups do little but land chunks -- three of 192 (two chunks in flight while one is read)
+constexpr uint32_t LDS_CODE_KC3 = 192;
 // kernel variants: waves per workgroup -> accumulators per wave, tokens per batch
 constexpr uint32_t lds_ka(uint32_t nw) { return nw == 16 ? %(KA16)du : %(KA8)du; }
 constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du; }
@@ -396,6 +401,7 @@ struct LdsArgs {
     int post_relu;                     // (nullptr = none; then max(y, 0) when set) -- the sweep's fused store does the same
     const char *code;                  // code-stream kernels: the compiled schedule (executable memory) and the byte offset of
     const uint64_t *code_start;        // every (tile, wave) stream in it
+    uint32_t piece_bytes;              // code-stream kernels: bytes of a chunk that one wave DMAs (chunk bytes / 16: the plan's ring geometry)
 };
 """
 
@@ -421,11 +427,11 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const uint32_t nch = __builtin_amdgcn_readfirstlane(t->nch);
     const uint64_t tok = (uint64_t)(a.tok + (uint64_t)t->tokstart[wave] * BATCH);
     const uint32_t cid0 = __builtin_amdgcn_readfirstlane(t->chunk0);
-    const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * PIECE);
+    const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * %(piece_expr)s);
     const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * KA);
     const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
-    const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * PIECE);
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * %(piece_expr)s);
     const uint32_t scale = %(scale_expr)s;
 %(post_decl)s#define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
 #define PYGIM_SU2(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))   /* (the builtin returns int: no sign extension into the high word) */
@@ -477,6 +483,8 @@ def main():
         op_mul = v[5] if len(v) > 5 else None
         deq = v[6] if len(v) > 6 else None
         g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
+        if "_code" in name:
+            g = GEO_CODE
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         is_code = "_code" in name
         asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code))
@@ -495,7 +503,8 @@ def main():
                               code_decl=("    const uint64_t code_a = (uint64_t)(a.code + a.code_start[(uint64_t)ti * NW + wave]);\n"
                                          "    const uint64_t code_s = ((uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(code_a >> 32))) << 32) | "
                                          "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)code_a);" if is_code else ""),
-                              code_ops=(',\n          [code] "s"(code_s)' if is_code else ""))
+                              code_ops=(',\n          [code] "s"(code_s)' if is_code else ""),
+                              piece_expr=("a.piece_bytes" if is_code else "PIECE"))
         if guard:
             text += "#endif  // PYGIM_LDS_ABLATE\n"
     text += "\n}  // namespace pygim\n"

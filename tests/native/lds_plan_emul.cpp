@@ -51,8 +51,8 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
                         if ((tk >> LDS_HDR_SHIFT) && b > 2) return 3;   // bits 18.. are header space in tokens 0..2 of the first batch only
                         // the kernel's LDS ring: slot j streams its chunk into buffer j & 1 = rows [KC * (j & 1), KC * (j & 1) + KC);
                         // a real token must point into THAT buffer (padding reads row 0 of buffer 0 into the dummy accumulator)
-                        if (k < KA && ldsrow / KC != (j & 1)) return 15;
-                        if (ldsrow >= 2 * KC) return 16;
+                        if (k < KA && ldsrow / KC != (j % geo.NBUF)) return 15;
+                        if (ldsrow >= geo.NBUF * KC) return 16;
                         const uint32_t c = ldsrow % KC;
                         if (k > KA) return 4;
                         const uint64_t xr = (uint64_t)chunk * KC + c;
@@ -116,14 +116,17 @@ extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                    uint32_t threads, uint64_t *stats) {
+                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
     LdsGeometry geo;
     geo.NW = 16;
     geo.KA = 96;
     geo.BATCH = 8;
+    geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
+    geo.NBUF = nbuf;
     LdsPlanHost plan;
     lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, nullptr);
     if (plan.header_overflow) return 13;
+    const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
     LdsCodeHost ch;
     lds_code_from_plan(plan, opcode, ch, threads);
@@ -144,8 +147,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
             // LDS as the 16 waves of the workgroup see it: which chunk each buffer holds (the DMA of all waves lands the same chunk)
             for (uint32_t w = 0; w < NW; w++) {
                 std::vector<T> acc((size_t)KA * 64, T(0));
-                int64_t buf_chunk[2] = {-1, -1};
-                int64_t pending_chunk[2] = {-1, -1};          // DMA issued, not yet waited for (vmcnt(0)) + barrier
+                int64_t buf_chunk[4] = {-1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
+                int64_t landed_chunk[4] = {-1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
+                bool dirty[4] = {false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
+                struct VLoad { int buf; int64_t cid; bool last; };
+                std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)
                 struct XReg { bool valid = false, inflight = false; uint32_t ldsrow = 0; };
                 XReg x[16];
                 std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
@@ -159,9 +165,9 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
                     const uint32_t i0 = ch.code[pc];
                     if (i0 == 0xBF800000u) { pc++; continue; }                                  // s_nop 0
-                    if (i0 == 0xBF8A0000u) {                                                    // s_barrier: pending DMAs become visible
-                        for (int b = 0; b < 2; b++)
-                            if (pending_chunk[b] >= 0) { buf_chunk[b] = pending_chunk[b]; pending_chunk[b] = -1; }
+                    if (i0 == 0xBF8A0000u) {                                                    // s_barrier: landed chunks become visible
+                        for (uint32_t b = 0; b < NBUF; b++)
+                            if (landed_chunk[b] >= 0) { buf_chunk[b] = landed_chunk[b]; landed_chunk[b] = -1; dirty[b] = false; }
                         pc++;
                         continue;
                     }
@@ -171,8 +177,12 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc++;
                         continue;
                     }
-                    if (i0 == 0xBF8C0F70u || i0 == 0xBF8C0070u) {                               // s_waitcnt vmcnt(0) [lgkmcnt(0)]
-                        if (i0 == 0xBF8C0070u) { for (uint32_t r : fifo) x[r].inflight = false; fifo.clear(); }
+                    if ((i0 & 0xFFFF3FF0u) == 0xBF8C0F70u) {                                    // s_waitcnt vmcnt(N): all but the N youngest loads
+                        const uint32_t n = (i0 & 15) | (((i0 >> 14) & 3) << 4);
+                        while (vfifo.size() > n) {
+                            if (vfifo.front().last) landed_chunk[vfifo.front().buf] = vfifo.front().cid;
+                            vfifo.erase(vfifo.begin());
+                        }
                         pc++;
                         continue;
                     }
@@ -194,19 +204,22 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_ldsw) && ((i0 >> 16) & 0xFF) == 124) {    // s_add_u32 m0, ldsw, literal
                         const uint32_t lit = ch.code[pc + 1];
                         dma_buf = lit / chunk_bytes;
-                        if (dma_buf > 1 || (lit % chunk_bytes) != (pieces_seen / 4) * 0x1000) return 23;
+                        if (dma_buf >= (int64_t)NBUF || (lit % chunk_bytes) != (pieces_seen / 4) * 0x1000) return 23;
                         pc += 2;
                         continue;
                     }
                     if ((i0 & 0xFF00FF00u) == 0x82008000u) { pc++; continue; }                  // s_addc_u32 x, x, 0
                     if ((i0 & 0xFFFF8000u) == 0xDDF48000u) {                                    // global_load_lds_dwordx4 (one DMA piece)
                         if (ch.code[pc + 1] != ((R.s_pa << 16) | R.vl16) || (i0 & 0x1FFF) != (pieces_seen % 4) * 1024 || dma_buf < 0) return 24;
-                        // the buffer being filled must not be the one this slot reads from: checked at the reads below
-                        if (++pieces_seen == pieces) pending_chunk[dma_buf] = dma_cid;
+                        // the buffer being filled must not be one that is read before the fence: checked at the reads below
+                        dirty[dma_buf] = true;
+                        buf_chunk[dma_buf] = -1;
+                        ++pieces_seen;
+                        vfifo.push_back({(int)dma_buf, dma_cid, pieces_seen == pieces});
                         pc += 2;
                         continue;
                     }
-                    if ((i0 & 0xFFFF8000u) == 0xDC508000u) { pc += 2; continue; }               // global_load_dword (touch)
+                    if ((i0 & 0xFFFF8000u) == 0xDC508000u) { vfifo.push_back({-1, -1, false}); pc += 2; continue; }   // global_load_dword (touch)
                     if ((i0 & 0xFFFF0000u) == 0xD8700000u || (i0 & 0xFFFF0000u) == 0xD86C0000u) {   // ds_read2st64_b32 / ds_read_b32
                         const bool two = (i0 & 0xFFFF0000u) == 0xD8700000u;
                         const uint32_t i1 = ch.code[pc + 1], vdst = i1 >> 24, vaddr = i1 & 0xFF;
@@ -221,8 +234,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             xr.valid = true;
                             xr.inflight = true;
                             xr.ldsrow = blk * 256 + rows[q];
-                            if (xr.ldsrow >= 2 * KC) return 28;
-                            if (pending_chunk[xr.ldsrow / KC] >= 0) return 29;                  // reading a buffer whose DMA has not been fenced
+                            if (xr.ldsrow >= NBUF * KC) return 28;
+                            if (dirty[xr.ldsrow / KC]) return 29;                               // reading a buffer whose DMA has not been fenced
                         }
                         fifo.push_back(vdst - R.x0);   // (a pair retires as one LDS instruction: both registers with the first index)
                         if (two) x[vdst - R.x0 + 1].inflight = true;
@@ -272,11 +285,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
 
 extern "C" {
 int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t threads, uint64_t *stats) {
-    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats);
+                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
-                 uint32_t threads, uint64_t *stats) {
-    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats);
+                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf);
 }
 }

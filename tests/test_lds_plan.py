@@ -141,7 +141,7 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
     assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
 
 
-def _run_code(emul, rowptr, col, ncols, x, threads=4):
+def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -150,7 +150,7 @@ def _run_code(emul, rowptr, col, ncols, x, threads=4):
     rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
     xx = np.ascontiguousarray(x)
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
-            out.ctypes.data_as(ctypes.c_void_p), threads, stats)
+            out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf)
     assert rc == 0, f"the interpreter rejected the code stream (code {rc})"
     return out, list(stats)
 
@@ -169,8 +169,9 @@ def test_code_stream_interpreted_equals_oracle(emul, dtype, shape):
     else:
         x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
     want = oracle.spmm_csr(rowptr, col, None, x)
-    got, stats = _run_code(emul, rowptr, col, ncols, x)
-    assert got.tobytes() == want.tobytes()
-    assert stats[2] == len(col) and stats[1] % 256 == 0          # no padding entries; streams on 256-byte lines (+ slack)
-    if len(col) > 1000:
-        assert stats[3] > 0.8 * len(col)                          # most entries are read two to an LDS instruction
+    for kc, nbuf in ((320, 2), (192, 3)):                         # the two ring geometries (pygim_hip.hip build_lds_plan)
+        got, stats = _run_code(emul, rowptr, col, ncols, x, kc=kc, nbuf=nbuf)
+        assert got.tobytes() == want.tobytes(), (kc, nbuf)
+        assert stats[2] == len(col) and stats[1] % 256 == 0      # no padding entries; streams on 256-byte lines (+ slack)
+        if len(col) > 1000:
+            assert stats[3] > 0.8 * len(col)                      # most entries are read two to an LDS instruction
