@@ -271,7 +271,7 @@ inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncol
 // i.e. 1.5 instructions and 8.5 bytes of code per entry, no address arithmetic, no index register, no token loads, no batch
 // bookkeeping and no padding (measured in isolation, scripts/micro/codestream.hip: 2.56 CU cycles per entry streamed from memory
 // once against 3.1-3.3 for the four-instruction token of the token kernels).  The slot boundary (DMA of the next chunk, wait,
-// barrier) is inlined with the chunk ids as literals; every ~6 KB the stream touches its own lines 8 KiB ahead into the L2.
+// barrier) is inlined with the chunk ids as literals; every 1 KB the stream touches its own lines 2 KiB ahead into the L2.
 // Register contract with the kernel (scripts/gen_lds_kernel.py body_code): see LdsCodeRegs.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct LdsCodeRegs {
@@ -307,7 +307,11 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     const uint32_t ntiles = plan.ntiles;
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = std::min<unsigned>(threads, std::max(1u, ntiles * NW));
-    constexpr uint32_t TOUCH_EVERY_DW = 1536;         // a touch per 6 KB of code: 64 lines (8 KB) from 8 KiB ahead
+    // a touch per 1 KB of code: the 8 lines (1 KB) that start 2 KiB ahead (the kernel's lane offsets repeat every 8 lanes).  A wave
+    // consumes ~0.2 bytes of code per cycle: 2 KiB is > 10 000 cycles of lead.  (First version: 64 lines from 8 KiB ahead every 6 KB --
+    // 512 waves per XCD x 8 KiB of lead is the whole 4 MiB L2: touched lines were evicted before they were fetched, fabric traffic
+    // 17.7 GB per product and an L2 hit rate of 80 %.)
+    constexpr uint32_t TOUCH_EVERY_DW = 256;
 
     struct Emit {
         std::vector<uint32_t> w;

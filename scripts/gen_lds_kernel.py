@@ -117,7 +117,9 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
         a("s_mov_b32 s81, %[xs_hi]")
         a("s_mov_b32 s82, %[ldsw]")
         a("s_mov_b64 s[84:85], %[code]")
-        a("s_add_u32 s84, s84, 0x2000")            # the stream touches its own lines 8 KiB ahead
+        a("s_add_u32 s84, s84, 0x800")             # the stream touches its own lines 2 KiB ahead, 8 lines (1 KB) per touch:
+        a(f"v_and_b32 {VL128}, 7, %[lane]")        # lane offsets (lane % 8) * 128
+        a(f"v_lshlrev_b32 {VL128}, 7, {VL128}")
         a("s_addc_u32 s85, s85, 0")
         a("s_swappc_b64 s[86:87], %[code]")
         a("s_branch L_out_%=")                     # (the token loop below is not part of this form)
