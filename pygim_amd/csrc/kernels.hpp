@@ -861,6 +861,12 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     }
 }
 
+// dst[i] = src[i], 16 bytes a thread (the upload of the code stream into its executable allocation)
+__global__ void k_copy16(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // narrow[i] = vals[i] in the 4-byte type; *flag |= 1 when some value does not survive the round trip (NaNs included)
 template <typename T>
 __global__ void k_narrow_vals(const T *__restrict__ vals, uint64_t n, typename NarrowOf<T>::type *__restrict__ narrow, int *flag) {

@@ -334,15 +334,33 @@ static ExecPool *exec_pool_locked(int dev) {
     if (ep.tried) return ep.ok ? &ep : nullptr;
     ep.tried = true;
     if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;   // (reference-counted: HIP holds the runtime open already)
-    struct Find { int want, seen; hsa_agent_t agent; bool found; } f{dev, 0, {}, false};
+    // the HSA agent of this HIP device: by PCI address (HIP_VISIBLE_DEVICES renumbers HIP's devices, not the runtime's agents);
+    // by ordinal only when the address cannot be had
+    struct Find { int want, seen; int bdf, domain; hsa_agent_t agent, nth; bool found, have_nth; } f{dev, 0, -1, -1, {}, {}, false, false};
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        f.bdf = (prop.pciBusID << 8) | (prop.pciDeviceID << 3);
+        f.domain = prop.pciDomainID;
+    }
     hsa_iterate_agents([](hsa_agent_t a, void *d) -> hsa_status_t {
         Find *f = (Find *)d;
         hsa_device_type_t t;
         if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
-        if (f->seen++ == f->want) { f->agent = a; f->found = true; return HSA_STATUS_INFO_BREAK; }
+        if (f->seen++ == f->want) { f->nth = a; f->have_nth = true; }
+        uint32_t bdf = 0, domain = 0;
+        if (f->bdf >= 0 && hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS &&
+            hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain) == HSA_STATUS_SUCCESS &&
+            (int)(bdf & ~7u) == f->bdf && (int)domain == f->domain) {
+            f->agent = a;
+            f->found = true;
+            return HSA_STATUS_INFO_BREAK;
+        }
         return HSA_STATUS_SUCCESS;
     }, &f);
-    if (!f.found) return nullptr;
+    if (!f.found) {
+        if (!f.have_nth) return nullptr;
+        f.agent = f.nth;
+    }
     struct FindPool { hsa_amd_memory_pool_t pool; bool found; } fp{{}, false};
     hsa_amd_agent_iterate_memory_pools(f.agent, [](hsa_amd_memory_pool_t p, void *d) -> hsa_status_t {
         FindPool *fp = (FindPool *)d;
@@ -374,9 +392,23 @@ static void *exec_alloc_upload(const void *host, size_t bytes) {
         ep = exec_pool_locked(dev);
     }
     if (!ep) return nullptr;
-    void *ptr = nullptr;
-    if (hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) return nullptr;
-    if (hsa_amd_agents_allow_access(1, &ep->agent, nullptr, ptr) != HSA_STATUS_SUCCESS || hsa_memory_copy(ptr, host, bytes) != HSA_STATUS_SUCCESS) {
+    // the code goes up through HIP (a staging buffer and a copy kernel: the executable allocation is a device address like any
+    // other inside a kernel); the HSA runtime is asked for the memory only
+    void *ptr = nullptr, *stage = nullptr;
+    if (hipMalloc(&stage, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipMemcpy(stage, host, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) {
+        (void)hipFree(stage);
+        return nullptr;
+    }
+    const uint64_t n16 = bytes / 16;   // (the code blob is a multiple of 256 bytes)
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (const u32x4_t *)stage, (u32x4_t *)ptr, n16);
+    const bool ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    (void)hipFree(stage);
+    if (!ok) {
         (void)hsa_amd_memory_pool_free(ptr);
         return nullptr;
     }
@@ -1342,7 +1374,11 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         // the schedule as machine code (1.5 instructions per stored entry instead of 4 + bookkeeping) in EXECUTABLE memory; the token
         // stream itself stays on the host (the kernel needs the tile table and the row map only)
         LdsCodeHost ch;
-        lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : 0x68000000u, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+        try {
+            lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : 0x68000000u, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+        } catch (const std::exception &) {
+            return 0;   // (out of host memory or threads: the sweep serves the group)
+        }
         std::vector<uint32_t>().swap(plan.tok);
         void *code = exec_alloc_upload(ch.code.data(), ch.code.size() * 4);
         if (!code) return 0;             // (no executable pool on this runtime: the sweep serves the group)
