@@ -1287,6 +1287,7 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint) {
     if (g_tune.lds_mode == 2 || (es != 4 && es != 2) || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
     if ((p.vals || es == 2) && g_tune.lds_waves != 16) return 0;  // the valued and the INT16 kernels exist for the 16-wave geometry
+    if (h_hint > 0 && (h_hint * (int64_t)es) / 4 < g_tune.lds_min_width) return 0;   // no product of this group is wide enough (want_lds): no plan, no code
     if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
     LdsGeometry geo;
     geo.NW = g_tune.lds_waves == 16 ? 16 : 8;
