@@ -404,7 +404,13 @@ def main():
                    "staged_L2_to_LDS_bytes": staged,
                    "staged_TBs": round(staged / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
                    "tokens_incl_padding": lds_info["tokens"],
-                   **({"code_stream": code_info, "instruction_fetch_bytes": code_info["code_bytes"] * nsl} if code_info["active"] else {})}
+                   **({"code_stream": code_info, "instruction_fetch_bytes": code_info["code_bytes"] * nsl,
+                       # what the kernel is bound by now: bytes the L2 hands to the CUs (chunks into LDS + the code, each fetched once
+                       # per slice) against the gather ceiling measured in round 2 (17.7 TB/s; 256 CUs x ~70 GB/s of LDS-DMA is the same number)
+                       "l2_read_TBs": round((staged + code_info["code_bytes"] * nsl) / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
+                       "l2_read_ceiling_measured_TBs": 17.7,
+                       "l2_read_frac": round((staged + code_info["code_bytes"] * nsl) / (k_ms * 1e-3) / 1e12 / 17.7, 3) if k_ms else None}
+                      if code_info["active"] else {})}
     else:
         # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids
         amode = 3 if plan_info["col16"] else 2
