@@ -297,7 +297,9 @@ struct LdsCodeHost {
     uint64_t pairs = 0;                  // of which read two to an LDS instruction
 };
 
-// opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000)
+// opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000), or LDS_CODE_PK_ADD_U16 for
+// INT16 (two features to a lane: v_pk_add_u16, a VOP3P instruction of 8 bytes)
+constexpr uint32_t LDS_CODE_PK_ADD_U16 = 0xFFFFFFFFu;
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0) {
     const LdsGeometry &geo = plan.geo;
     const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
@@ -391,7 +393,8 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             auto adds_prev = [&]() {
                 for (uint32_t q = 0; q < prev_n; q++) {
                     const uint32_t vk = Rr.acc0 + prev_k[q];
-                    e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + prev_x + q));
+                    if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + prev_x + q));   // v_pk_add_u16 acc, x, acc
+                    else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + prev_x + q));
                 }
             };
             while (i < toks.size()) {

@@ -836,6 +836,13 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     } else if constexpr (sizeof(T) == 2) {
         if (p.lds_nw != 16) return fail(PYGIM_ERR_INVALID, "internal: INT16 LDS-staged product needs the 16-wave plan");
         fn = long16 ? k_lds_spmm_i16_w16b : (p.lds_wdelta ? k_lds_spmm_i16_w16_val : k_lds_spmm_i16_w16);
+        if (p.lds_is_code) {   // the schedule compiled into machine code (two features to a lane: v_pk_add_u16)
+            if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
+            fn = k_lds_code_i16;
+            a.code = p.lds_code;
+            a.code_start = p.lds_code_start;
+            a.piece_bytes = p.lds_code_piece;
+        }
     } else if (long16) {
         if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16b;
         else fn = k_lds_spmm_i32_w16b;
@@ -1324,7 +1331,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     }
     // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its LDS ring is three
     // buffers of 192 columns (two chunks in flight), so its plan is built in that geometry and serves no token kernel
-    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals && es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32);
+    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals &&
+                           ((es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32)) || (es == 2 && t_plan_dtype == PYGIM_INT16));
     if (want_code) {
         // the ring: two buffers of 320 columns; for products of one or two slices (their workgroups do little but land chunks) three of
         // 192, two chunks in flight (Reddit h = 64 / 128: 1.06 / 2.04 -> 1.01 / 1.83 ms; h = 256: 3.23 -> 3.39, h = 192: 2.30 -> 3.84)
@@ -1376,7 +1384,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         // stream itself stays on the host (the kernel needs the tile table and the row map only)
         LdsCodeHost ch;
         try {
-            lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : 0x68000000u, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+            lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : (t_plan_dtype == PYGIM_INT32 ? 0x68000000u : LDS_CODE_PK_ADD_U16), ch,
+                               (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
         } catch (const std::exception &) {
             return 0;   // (out of host memory or threads: the sweep serves the group)
         }

@@ -22,7 +22,7 @@ dev = torch.device("cuda", 0)
 _lib.init_ranks(1)
 n, nnz, dmax = synth.SHAPES[args.shape]
 rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev, clustered=args.clustered)
-dt = torch.float32 if args.dtype == "f32" else torch.int32
+dt = {"f32": torch.float32, "i32": torch.int32, "i16": torch.int16}[args.dtype]
 x = synth.features(n, args.h, dt, seed=0, device=dev)
 _lib.set_tunable("lds_mode", args.mode)
 _lib.set_tunable("lds_waves", args.waves)
@@ -30,7 +30,7 @@ _lib.set_tunable("lds_ablate", args.ablate)
 for kv in filter(None, args.tune.split(",")):
     k, v = kv.split("=")
     _lib.set_tunable(k, int(v))
-hd = _lib.group_create(_lib.CSR, _lib.FLT32 if dt == torch.float32 else _lib.INT32, [rowptr.data_ptr()], [col.data_ptr()], None,
+hd = _lib.group_create(_lib.CSR, {torch.float32: _lib.FLT32, torch.int32: _lib.INT32, torch.int16: _lib.INT16}[dt], [rowptr.data_ptr()], [col.data_ptr()], None,
                        [n], [n], [nnz], [1], [args.h], args.h)
 out = torch.empty((n, args.h), dtype=dt, device=dev)
 for _ in range(2):

@@ -476,7 +476,8 @@ def main():
         variants.append((f"k_lds_spmm_{base}_w16b" + ("_deq" if deq else ""), op, "L16", 0,
                          "the same for plans with long slots: 16-token batches, 80 accumulators per wave", None, deq))
     # the code-stream form (the schedule compiled into machine code, lds_plan.hpp lds_code_from_plan): 16 waves, unit weights
-    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32")):
+    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32"),
+                          ("i16", "v_pk_add_u16", None)):
         variants.append((f"k_lds_code_{base}" + ("_deq" if deq else ""), op, 16, 0,
                          "CODE-STREAM form: the slot loop is a straight-line instruction stream compiled from the schedule (1.5 instructions per stored entry)",
                          None, deq))

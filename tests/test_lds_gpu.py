@@ -282,16 +282,19 @@ def test_int16_two_features_to_a_lane(rng, lds_forced):
         x = rng.integers(info.min, info.max, size=(ncols, h), endpoint=True).astype(np.int16)
         vals = rng.integers(info.min, info.max, size=len(col), endpoint=True).astype(np.int16)
         rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
-        for v in (None, vals):
+        for v, code in ((None, 1), (None, 0), (vals, 1)):   # unit weights: the code-stream form (v_pk_add_u16 in the stream) and the token kernel
+            old_code = _lib.set_tunable("lds_code", code)
             hd = _lib.group_create(_lib.CSR, _lib.INT16, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data],
                                    [n], [ncols], [len(ci)], [1], [h], h)
             try:
                 assert _lib.group_lds_plan(hd)["tiles"] > 0
+                assert _lib.group_lds_code(hd)["active"] == (1 if (v is None and code) else 0)
                 out = np.full((n, h), 77, dtype=np.int16)
                 _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
             finally:
                 _lib.group_free(hd)
-            assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (n, h, v is not None)
+                _lib.set_tunable("lds_code", old_code)
+            assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (n, h, v is not None, code)
 
 
 @pytest.mark.parametrize("dt,code", [(np.int32, "INT32"), (np.float32, "FLT32")])
