@@ -372,7 +372,8 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             wait_landed(0);
             e.op(0xBF8A0000u);                                      // s_barrier
         }
-        std::vector<uint32_t> toks;
+        std::vector<uint64_t> toks;   // token | value << 32 (valued FLT32 matrices: the entry's value rides as a literal of its v_mul_f32)
+        const bool valued = !plan.wts.empty();
         for (uint32_t j = 0; j < t.nch; j++) {
             bool dma_due = j + NBUF - 1 < t.nch;   // the DMA of chunk j + NBUF - 1 (into the buffer the barrier just freed) goes behind the
                                                    // slot's FIRST group of reads (their LDS latency covers its issue)
@@ -380,17 +381,22 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
                 const uint32_t tk = plan.tok[at + b] & ((1u << LDS_HDR_SHIFT) - 1);
-                if ((tk & 0xFF) < KA) toks.push_back(tk);
+                if ((tk & 0xFF) < KA) toks.push_back((uint64_t)tk | (valued ? (uint64_t)plan.wts[at + b] << 32 : 0));
             }
             at += (uint64_t)nb * B;
             // entries of the low LDS block first (stable: a row's entries are in column order, so its order is kept), then pairs
-            std::stable_sort(toks.begin(), toks.end(), [](uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); });   // block = ldsrow >> 8 = token >> 16
+            std::stable_sort(toks.begin(), toks.end(), [](uint64_t a, uint64_t b) { return ((uint32_t)a >> 16) < ((uint32_t)b >> 16); });   // block = ldsrow >> 8 = token >> 16
             n_entries += toks.size();
             // groups of up to 8 entries: reads of group g, wait for group g - 1, adds of group g - 1
             size_t i = 0;
             uint32_t gsel = 0, prev_n = 0, prev_x = 0;
-            uint32_t prev_k[8];
+            uint32_t prev_k[8], prev_v[8];
             auto adds_prev = [&]() {
+                if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the eight products first
+                    for (uint32_t q = 0; q < prev_n; q++) {
+                        const uint32_t vx = prev_x + q;
+                        e.op(0x0A0000FFu | (vx << 17) | (vx << 9), prev_v[q]);   // v_mul_f32 x, <literal value>, x
+                    }
                 for (uint32_t q = 0; q < prev_n; q++) {
                     const uint32_t vk = Rr.acc0 + prev_k[q];
                     if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + prev_x + q));   // v_pk_add_u16 acc, x, acc
@@ -399,20 +405,23 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             };
             while (i < toks.size()) {
                 const uint32_t xb = Rr.x0 + 8 * gsel;
-                uint32_t n = 0, nlds = 0, ks[8];
+                uint32_t n = 0, nlds = 0, ks[8], vs[8];
                 while (n < 8 && i < toks.size()) {
-                    const uint32_t r0 = toks[i] >> 8, blk = r0 >> 8;
-                    if (n + 2 <= 8 && (n & 1) == 0 && i + 1 < toks.size() && ((toks[i + 1] >> 8) >> 8) == blk) {
-                        const uint32_t r1 = toks[i + 1] >> 8;
+                    const uint32_t t0 = (uint32_t)toks[i], r0 = t0 >> 8, blk = r0 >> 8;
+                    if (n + 2 <= 8 && (n & 1) == 0 && i + 1 < toks.size() && (((uint32_t)toks[i + 1] >> 8) >> 8) == blk) {
+                        const uint32_t r1 = (uint32_t)toks[i + 1] >> 8;
                         e.op(0xD8700000u | ((r1 & 255) << 8) | (r0 & 255), ((xb + n) << 24) | Rr.vbase[blk]);   // ds_read2st64_b32
-                        ks[n] = toks[i] & 0xFF;
-                        ks[n + 1] = toks[i + 1] & 0xFF;
+                        ks[n] = t0 & 0xFF;
+                        ks[n + 1] = (uint32_t)toks[i + 1] & 0xFF;
+                        vs[n] = (uint32_t)(toks[i] >> 32);
+                        vs[n + 1] = (uint32_t)(toks[i + 1] >> 32);
                         n += 2;
                         i += 2;
                         n_pairs += 2;
                     } else {
                         e.op(0xD86C0000u | ((r0 & 255) << 8), ((xb + n) << 24) | Rr.vbase[blk]);             // ds_read_b32
-                        ks[n] = toks[i] & 0xFF;
+                        ks[n] = t0 & 0xFF;
+                        vs[n] = (uint32_t)(toks[i] >> 32);
                         n += 1;
                         i += 1;
                     }
@@ -428,7 +437,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 }
                 prev_n = n;
                 prev_x = xb;
-                for (uint32_t q = 0; q < n; q++) prev_k[q] = ks[q];
+                for (uint32_t q = 0; q < n; q++) { prev_k[q] = ks[q]; prev_v[q] = vs[q]; }
                 gsel ^= 1;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }

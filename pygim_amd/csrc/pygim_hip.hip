@@ -902,7 +902,7 @@ template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, i
     if constexpr (sizeof(T) == 2) {  // two features to a lane: whole lanes, dword-aligned rows of C, the 16-wave plan
         if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || p.lds_nw != 16) return false;
     }
-    if (!p.lds_tiles || g_tune.lds_mode == 2 || (p.vals != nullptr) != (p.lds_wdelta != 0) || g->deq_out || g->pre_xs) return false;
+    if (!p.lds_tiles || g_tune.lds_mode == 2 || (!p.lds_is_code && (p.vals != nullptr) != (p.lds_wdelta != 0)) || g->deq_out || g->pre_xs) return false;
     if (p.lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return false;   // (a code-stream plan serves no token kernel: the sweep instead)
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode == 1 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0)) return false;  // another kernel was asked for by name
     if ((int64_t)((size_t)w * sizeof(T) / 4) < g_tune.lds_min_width) return false;   // (lanes: 4-byte units of a row)
@@ -1331,8 +1331,10 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     }
     // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its LDS ring is three
     // buffers of 192 columns (two chunks in flight), so its plan is built in that geometry and serves no token kernel
-    const bool want_code = g_tune.lds_code && geo.NW == 16 && !p.vals &&
-                           ((es == 4 && (t_plan_dtype == PYGIM_FLT32 || t_plan_dtype == PYGIM_INT32)) || (es == 2 && t_plan_dtype == PYGIM_INT16));
+    // (valued matrices: FLT32 only -- the value is the literal of a v_mul_f32 in the stream; the integer multiplies have no literal form)
+    const bool want_code = g_tune.lds_code && geo.NW == 16 &&
+                           ((es == 4 && t_plan_dtype == PYGIM_FLT32) || (!p.vals && es == 4 && t_plan_dtype == PYGIM_INT32) ||
+                            (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16));
     if (want_code) {
         // the ring: two buffers of 320 columns; for products of one or two slices (their workgroups do little but land chunks) three of
         // 192, two chunks in flight (Reddit h = 64 / 128: 1.06 / 2.04 -> 1.01 / 1.83 ms; h = 256: 3.23 -> 3.39, h = 192: 2.30 -> 3.84)
@@ -1365,7 +1367,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     }
     std::vector<uint32_t>().swap(h_col);
     std::vector<uint32_t>().swap(h_val);
-    if (p.vals) {
+    if (p.vals && !want_code) {
         // one buffer: the token stream, then the value stream at the same positions (the kernel adds a 32-bit byte offset)
         if ((uint64_t)plan.tok.size() * 8 >= (1ull << 32)) return 0;
         p.lds_wdelta = (uint32_t)(plan.tok.size() * 4);

@@ -116,7 +116,7 @@ extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
+                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr) {
     LdsGeometry geo;
     geo.NW = 16;
     geo.KA = 96;
@@ -124,7 +124,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
     geo.NBUF = nbuf;
     LdsPlanHost plan;
-    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, nullptr);
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
     if (plan.header_overflow) return 13;
     const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
@@ -152,7 +152,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 bool dirty[4] = {false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
                 struct VLoad { int buf; int64_t cid; bool last; };
                 std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)
-                struct XReg { bool valid = false, inflight = false; uint32_t ldsrow = 0; };
+                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; };
                 XReg x[16];
                 std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
                 uint64_t pc = ch.start[(size_t)ti * NW + w] / 4;
@@ -233,12 +233,26 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             if (xr.inflight) return 27;                                         // overwritten before it was consumed
                             xr.valid = true;
                             xr.inflight = true;
+                            xr.has_mul = false;
                             xr.ldsrow = blk * 256 + rows[q];
                             if (xr.ldsrow >= NBUF * KC) return 28;
                             if (dirty[xr.ldsrow / KC]) return 29;                               // reading a buffer whose DMA has not been fenced
                         }
                         fifo.push_back(vdst - R.x0);   // (a pair retires as one LDS instruction: both registers with the first index)
                         if (two) x[vdst - R.x0 + 1].inflight = true;
+                        pc += 2;
+                        continue;
+                    }
+                    if (vals && (i0 & 0xFE0001FFu) == 0x0A0000FFu) {                            // v_mul_f32 x, <literal>, x (valued matrices)
+                        const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF;
+                        if (vd != vs1 || vd < R.x0 || vd >= R.x0 + 16) return 33;
+                        XReg &xr = x[vd - R.x0];
+                        bool infl = false;
+                        for (uint32_t r : fifo) if (r == vd - R.x0 || (r + 1 == vd - R.x0 && x[r + 1].inflight && x[r].inflight)) infl = true;
+                        if (!xr.valid || infl || xr.has_mul) return 34;                         // multiplied before its read landed, or twice
+                        xr.inflight = false;
+                        xr.has_mul = true;
+                        xr.mulbits = ch.code[pc + 1];
                         pc += 2;
                         continue;
                     }
@@ -255,11 +269,20 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         if (chunk < 0) return 32;
                         const uint64_t xrow = (uint64_t)chunk * KC + xr.ldsrow % KC;
                         const uint32_t k = vd - R.acc0;
+                        if ((vals != nullptr) != xr.has_mul) return 35;                         // every entry of a valued matrix is multiplied once
                         for (uint32_t l = 0; l < wvalid; l++) {
-                            const T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
+                            T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
                             T &a = acc[(size_t)k * 64 + l];
                             if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)xv);
-                            else a = a + xv;
+                            else {
+                                if (xr.has_mul) {
+                                    float mv;
+                                    std::memcpy(&mv, &xr.mulbits, 4);
+                                    volatile float prod = mv * xv;   // product and sum round separately (no FMA)
+                                    xv = prod;
+                                }
+                                a = a + xv;
+                            }
                         }
                         if (s == 0) entries_seen++;
                         pc++;
@@ -285,8 +308,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
 
 extern "C" {
 int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
-    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf);
+                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {

@@ -163,8 +163,11 @@ def test_valued_entries_are_bit_exact(rng, lds_forced, dt):
         rowptr, col = random_csr(rng, n, ncols, 25, long_rows=[(1, 4000)])
         x = features(rng, ncols, h, dt)
         vals = features(rng, len(col), 1, dt)[:, 0]
-        got, plan = product(rowptr, col, x, vals=vals)
-        assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (dt, n, h)
+        for code in (1, 0):   # FLT32: the code-stream form (the value is the literal of a v_mul_f32 in the stream), then the token kernel
+            old_code = _lib.set_tunable("lds_code", code)
+            got, plan = product(rowptr, col, x, vals=vals)
+            _lib.set_tunable("lds_code", old_code)
+            assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (dt, n, h, code)
     _lib.set_tunable("lds_waves", 8)   # no valued kernel in the 8-wave geometry: the sweep answers (floats within the bound)
     got, plan = product(rowptr, col, x, vals=vals, want_plan=False)
     want = oracle.spmm_csr(rowptr, col, vals, x)

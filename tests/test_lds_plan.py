@@ -141,7 +141,7 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
     assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
 
 
-def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2):
+def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2, vals=None):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -150,7 +150,8 @@ def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2):
     rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
     xx = np.ascontiguousarray(x)
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
-            out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf)
+            out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf,
+            *(() if x.dtype != np.float32 else (None if vals is None else np.ascontiguousarray(vals, np.float32).ctypes.data_as(ctypes.c_void_p),)))
     assert rc == 0, f"the interpreter rejected the code stream (code {rc})"
     return out, list(stats)
 
@@ -175,3 +176,17 @@ def test_code_stream_interpreted_equals_oracle(emul, dtype, shape):
         assert stats[2] == len(col) and stats[1] % 256 == 0      # no padding entries; streams on 256-byte lines (+ slack)
         if len(col) > 1000:
             assert stats[3] > 0.8 * len(col)                      # most entries are read two to an LDS instruction
+
+
+def test_code_stream_with_values(emul):
+    """a valued FLT32 matrix in the code-stream form: every entry's value is the literal of a v_mul_f32 in front of its add
+    (product and sum rounded separately, stored order: bit-identical to the CPU loop)"""
+    rng = np.random.default_rng(31)
+    nrows, ncols, h = 2000, 1500, 96
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=14, long_rows=[(3, 2500)])
+    x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    vals = (rng.random(len(col), dtype=np.float32) * 2 - 1).astype(np.float32)
+    want = oracle.spmm_csr(rowptr, col, vals, x)
+    for kc, nbuf in ((320, 2), (192, 3)):
+        got, stats = _run_code(emul, rowptr, col, ncols, x, kc=kc, nbuf=nbuf, vals=vals)
+        assert got.tobytes() == want.tobytes(), (kc, nbuf)
