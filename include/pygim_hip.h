@@ -217,7 +217,7 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]);
  * "split_unit_pattern", "narrow_vals" (INT64 / DBL64 values that all fit int32 / float exactly are streamed in 4 bytes), "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
  * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),
- * "lds_round_tiles", "lds_code" (1 = FLT32 / INT32 / INT16 unit-weight plans are compiled into machine code at creation and run by k_lds_code_*,
+ * "lds_round_tiles", "lds_code" (1 = FLT32 (valued too) / INT32 / INT16 unit-weight plans are compiled into machine code at creation and run by k_lds_code_*,
  * 0 = the token kernels), "lds_code_nbuf" (its LDS ring: 0 = by width, 2 = 2 x 320 columns, 3 = 3 x 192), "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, narrow_vals, merge_parts at creation) are read when a group is created; the others per product.  */
