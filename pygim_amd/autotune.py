@@ -31,9 +31,11 @@ CUS = 256
 LDS_CLOCK = 2.3e9           # Hz held under this kernel (GRBM_GUI_ACTIVE / 8 / time)
 LDS_ROWS_MAX = 16 * 96      # rows of a tile (waves x accumulators per wave)
 LDS_CYC_PER_TOKEN = 2.9     # CU cycles per stored entry and slice in the code-stream form (k_lds_code_*; clustered columns: nothing else in the way; the token kernels: 3.9)
-LDS_KC = 320                # columns of a chunk (80 KiB of one 64-feature slice; lds_plan.hpp)
-LDS_CYC_PER_SLOT = 1030     # CU cycles per chunk of X beside the entries (barrier, DMA issue, landing the chunk; fitted to h = 256 uniform)
-LDS_CYC_FILL = 2875         # CU cycles to land 80 KiB in LDS at ~65 GB/s per CU: a slot cannot be shorter
+LDS_KC = 320                # columns of a chunk, products of three or more slices: 2 x 80 KiB ring (lds_plan.hpp, pygim_hip.hip build_lds_plan)
+LDS_KC3 = 192               # ... of one or two slices: 3 x 48 KiB ring, two chunks in flight
+LDS_CYC_PER_SLOT = 1030     # CU cycles per chunk of X beside the entries (barrier, DMA issue; fitted to h = 256 uniform)
+LDS_CYC_FILL = 3300         # CU cycles to land an 80 KiB chunk with every CU streaming (~56 GB/s per CU: the L2's gather ceiling shared by 256): a slot cannot be shorter
+LDS_CYC_FILL3 = 1750        # ... a 48 KiB chunk of the three-buffer ring
 LDS_PAD = 1.0               # the code stream has no padding entries (the token kernels: 1.07-1.085)
 LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
@@ -71,8 +73,10 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    slots = -(-int(ncols) // LDS_KC)
-    per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * LDS_CYC_PER_SLOT, slots * LDS_CYC_FILL)
+    three = nsl <= 2
+    slots = -(-int(ncols) // (LDS_KC3 if three else LDS_KC))
+    per_slot = LDS_CYC_PER_SLOT * (0.6 if three else 1.0)
+    per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * per_slot, slots * (LDS_CYC_FILL3 if three else LDS_CYC_FILL))
     rounds = -(-tiles * nsl // CUS)
     return rounds * per_wg / LDS_CLOCK + ncols * h * es * 2 / RATE_STREAM + LAUNCH
 
