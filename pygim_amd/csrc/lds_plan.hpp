@@ -58,6 +58,9 @@ struct LdsGeometry {
     uint32_t KC = 320;    // columns per chunk: two chunks of 64-feature rows (2 x 80 KiB) fill the 160 KiB of a CU's LDS
     uint32_t BATCH = 16;  // tokens per batch (one scalar load)
     uint32_t rows_per_tile = 0;  // 0 = NW * KA; fewer rows per tile = more, lighter tiles (to fill whole rounds of workgroups)
+    uint32_t col_splits = 1;     // S > 1: every row tile becomes S workgroup tiles, each with 1/S of the chunk range; tile (t, c) writes its
+                                 // partial sums to row r + c * nrows (the row map says so): the caller sums the S row blocks afterwards.
+                                 // For row shares too short to fill the chip with whole-X workgroups (a rank's share on N GPUs)
     uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
                                  // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
                                  // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
@@ -82,7 +85,8 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, B = geo.BATCH;
     const uint32_t RS = NW * KA;                                                       // row-map stride of a tile
     const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, RS) : RS;     // rows of a tile
-    const uint32_t ntiles = (nrows + R - 1) / R;
+    const uint32_t S = std::max(1u, geo.col_splits);
+    const uint32_t ntiles = ((nrows + R - 1) / R) * S;                                // workgroup tiles: (row tile, column range)
     const uint32_t nchunks = (ncols + KC - 1) / KC;
     out.geo = geo;
     out.ntiles = ntiles;
@@ -117,7 +121,9 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     };
     run([&](uint32_t t) {
         TileTmp &tt = tmp[t];
-        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0;
+        const uint32_t rt = t / S, cs = t % S;
+        const uint32_t ch_lo = (uint32_t)((uint64_t)nchunks * cs / S), ch_hi = (uint32_t)((uint64_t)nchunks * (cs + 1) / S);   // this tile's chunk range
+        const uint32_t r0 = rt * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0;
         // longest rows first (stable), dealt serpentine over the waves
         std::vector<uint32_t> order(nr);
         for (uint32_t i = 0; i < nr; i++) order[i] = i;
@@ -131,14 +137,18 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             const uint32_t w = (round & 1) ? NW - 1 - pos : pos;
             tt.wave_of[order[i]] = (uint8_t)w;
             tt.k_of[order[i]] = (uint16_t)round;
-            out.rowmap[((size_t)t * NW + w) * KA + round] = r0 + order[i];
+            out.rowmap[((size_t)t * NW + w) * KA + round] = r0 + order[i] + cs * nrows;   // (row of the partial-sum block of column range cs)
         }
         // token counts per (chunk, wave)
         std::vector<uint32_t> cnt((size_t)nchunks * NW, 0);
         for (uint32_t i = 0; i < nr; i++) {
             const uint32_t w = tt.wave_of[i];
-            for (uint32_t e = rowptr[r0 + i]; e < rowptr[r0 + i + 1]; e++) cnt[(size_t)(col[e] / KC) * NW + w]++;
+            for (uint32_t e = rowptr[r0 + i]; e < rowptr[r0 + i + 1]; e++) {
+                const uint32_t ch = col[e] / KC;
+                if (ch >= ch_lo && ch < ch_hi) cnt[(size_t)ch * NW + w]++;
+            }
         }
+        uint32_t nnz_range = 0;
         for (uint32_t c = 0; c < nchunks; c++) {
             uint32_t any = 0;
             for (uint32_t w = 0; w < NW; w++) any |= cnt[(size_t)c * NW + w];
@@ -146,6 +156,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             tt.chunk_ids.push_back(c);
             for (uint32_t w = 0; w < NW; w++) {
                 const uint32_t n = cnt[(size_t)c * NW + w];
+                nnz_range += n;
                 tt.cnt.push_back(n);
                 tt.batches[w] += std::max<uint32_t>(1, (n + B - 1) / B);   // at least the header batch
             }
@@ -153,7 +164,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         out.tiles[t].nch = (uint32_t)tt.chunk_ids.size();
         out.tiles[t].chunk0 = tt.chunk_ids.empty() ? 0 : tt.chunk_ids[0];
         out.tiles[t].row0 = r0;
-        out.tiles[t].nnz = rowptr[r1] - rowptr[r0];
+        out.tiles[t].nnz = nnz_range;
     });
     // offsets
     uint64_t tokb = 0, nbo = 0, cho = 0, slots = 0;
@@ -179,7 +190,8 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     run([&](uint32_t t) {
         TileTmp &tt = tmp[t];
         const LdsTile &d = out.tiles[t];
-        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0, nch = d.nch;
+        const uint32_t rt = t / S, cs = t % S;
+        const uint32_t r0 = rt * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0, nch = d.nch;
         for (uint32_t j = 0; j < nch + 2; j++) out.chunks[(size_t)d.chunk_off + j] = nch ? tt.chunk_ids[std::min(j, nch - 1)] : 0;
         // where each (slot, wave) list starts inside the wave's stream
         std::vector<uint32_t> slot_of(nchunks, 0xFFFFFFFFu);
@@ -198,11 +210,13 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         // rows in accumulator order per wave == any order that visits a wave's rows k = 0, 1, ...: walk k-major
         for (uint32_t k = 0; k < KA; k++)
             for (uint32_t w = 0; w < NW; w++) {
-                const uint32_t row = out.rowmap[((size_t)t * NW + w) * KA + k];
-                if (row == 0xFFFFFFFFu) continue;
+                const uint32_t rowm = out.rowmap[((size_t)t * NW + w) * KA + k];
+                if (rowm == 0xFFFFFFFFu) continue;
+                const uint32_t row = rowm - cs * nrows;
                 for (uint32_t e = rowptr[row]; e < rowptr[row + 1]; e++) {
                     const uint32_t c = col[e];
                     const uint32_t j = slot_of[c / KC];
+                    if (j == 0xFFFFFFFFu) continue;   // (an entry of another column range)
                     const uint64_t at = cursor[(size_t)j * NW + w]++;
                     out.tok[at] = (((c % KC) + (j % geo.NBUF) * KC) << 8) | k;   // slot j reads LDS buffer j % NBUF: row KC * (j % NBUF) + (c % KC)
                     if (vals) out.wts[at] = vals[e];

@@ -8,9 +8,18 @@
 using namespace pygim;
 
 template <typename T>
-static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const T *vals) {
+static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *Cout,
+                   uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const T *vals, uint32_t col_splits = 1) {
+    // column-split plans: tile (t, c) writes the partial sums of column range c to row r + c * nrows; summed in range order at the end
+    const uint32_t nrows_real = nrows, S = col_splits ? col_splits : 1;
+    std::vector<T> part;
+    T *C = Cout;
+    if (S > 1) {
+        part.assign((size_t)S * nrows * h, T(0));
+        C = part.data();
+    }
     LdsGeometry geo;
+    geo.col_splits = S;
     geo.NW = nw;
     geo.KA = KA;
     geo.BATCH = batch;
@@ -19,6 +28,7 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
     lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
     if (plan.header_overflow) return 13;
     if ((vals != nullptr) != !plan.wts.empty() || (vals && plan.wts.size() != plan.tok.size())) return 9;
+    nrows = S * nrows_real;   // rows of the (partial-sum) result the plan writes
     const uint32_t NW = geo.NW, KC = geo.KC;
     const uint32_t nslices = (h + 63) / 64;
     if (stats) {
@@ -89,17 +99,28 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
     }
     for (uint32_t r = 0; r < nrows; r++)
         if (written[r] != 1) return 8;
+    if (S > 1)
+        for (uint32_t r = 0; r < nrows_real; r++)
+            for (uint32_t f = 0; f < h; f++) {
+                T acc = part[(size_t)r * h + f];
+                for (uint32_t c = 1; c < S; c++) {
+                    const T v = part[((size_t)c * nrows_real + r) * h + f];
+                    if constexpr (std::is_integral<T>::value) acc = (T)((uint32_t)acc + (uint32_t)v);
+                    else acc = acc + v;
+                }
+                Cout[(size_t)r * h + f] = acc;
+            }
     return 0;
 }
 
 extern "C" {
 int lds_emul_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const float *vals) {
-    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const float *vals, uint32_t col_splits) {
+    return emulate<float>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals, col_splits);
 }
 int lds_emul_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
-                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const int32_t *vals) {
-    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals);
+                 uint32_t KA, uint32_t batch, uint32_t threads, uint64_t *stats, uint32_t nw, const int32_t *vals, uint32_t col_splits) {
+    return emulate<int32_t>(rowptr, col, nrows, ncols, X, h, C, KA, batch, threads, stats, nw, vals, col_splits);
 }
 }
 
@@ -115,9 +136,17 @@ extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32
 // "in flight": in-order LDS returns, so a wait for N outstanding reads retires all but the N youngest) -- and rejects anything else.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T>
-static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *C,
-                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr) {
+static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *Cout,
+                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr, uint32_t col_splits = 1) {
+    const uint32_t nrows_real = nrows, S = col_splits ? col_splits : 1;
+    std::vector<T> part;
+    T *C = Cout;
+    if (S > 1) {
+        part.assign((size_t)S * nrows * h, T(0));
+        C = part.data();
+    }
     LdsGeometry geo;
+    geo.col_splits = S;
     geo.NW = 16;
     geo.KA = 96;
     geo.BATCH = 8;
@@ -126,6 +155,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     LdsPlanHost plan;
     lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
     if (plan.header_overflow) return 13;
+    nrows = S * nrows_real;   // rows of the (partial-sum) result the plan writes
     const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
     LdsCodeHost ch;
@@ -302,17 +332,28 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     }
     for (uint32_t r = 0; r < nrows; r++)
         if (written[r] != 1) return 8;
-    if (entries_seen != (uint64_t)rowptr[nrows]) return 41;   // every stored entry exactly once, no padding
+    if (entries_seen != (uint64_t)rowptr[nrows_real]) return 41;   // every stored entry exactly once, no padding
+    if (S > 1)
+        for (uint32_t r = 0; r < nrows_real; r++)
+            for (uint32_t f = 0; f < h; f++) {
+                T acc = part[(size_t)r * h + f];
+                for (uint32_t c = 1; c < S; c++) {
+                    const T v = part[((size_t)c * nrows_real + r) * h + f];
+                    if constexpr (std::is_integral<T>::value) acc = (T)((uint32_t)acc + (uint32_t)v);
+                    else acc = acc + v;
+                }
+                Cout[(size_t)r * h + f] = acc;
+            }
     return 0;
 }
 
 extern "C" {
 int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
-                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals) {
-    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals);
+                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals, uint32_t col_splits) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
-                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf) {
-    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf);
+                 uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits);
 }
 }

@@ -26,7 +26,7 @@ def emul():
     return ctypes.CDLL(_SO)
 
 
-def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8, vals=None):
+def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8, vals=None, splits=1):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -36,7 +36,7 @@ def _run(emul, rowptr, col, ncols, x, ka=192, batch=16, threads=4, nw=8, vals=No
     xx = np.ascontiguousarray(x)
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols,
             xx.ctypes.data_as(ctypes.c_void_p), h, out.ctypes.data_as(ctypes.c_void_p), ka, batch, threads, stats, nw,
-            None if vals is None else np.ascontiguousarray(vals, x.dtype).ctypes.data_as(ctypes.c_void_p))
+            None if vals is None else np.ascontiguousarray(vals, x.dtype).ctypes.data_as(ctypes.c_void_p), splits)
     assert rc == 0, f"emulator rejected the plan (code {rc})"
     return out, list(stats)
 
@@ -141,7 +141,7 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
     assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
 
 
-def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2, vals=None):
+def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2, vals=None, splits=1):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -151,7 +151,7 @@ def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2, vals=None)
     xx = np.ascontiguousarray(x)
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
             out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf,
-            *(() if x.dtype != np.float32 else (None if vals is None else np.ascontiguousarray(vals, np.float32).ctypes.data_as(ctypes.c_void_p),)))
+            *(() if x.dtype != np.float32 else (None if vals is None else np.ascontiguousarray(vals, np.float32).ctypes.data_as(ctypes.c_void_p),)), splits)
     assert rc == 0, f"the interpreter rejected the code stream (code {rc})"
     return out, list(stats)
 
@@ -190,3 +190,34 @@ def test_code_stream_with_values(emul):
     for kc, nbuf in ((320, 2), (192, 3)):
         got, stats = _run_code(emul, rowptr, col, ncols, x, kc=kc, nbuf=nbuf, vals=vals)
         assert got.tobytes() == want.tobytes(), (kc, nbuf)
+
+
+@pytest.mark.parametrize("splits", [2, 3, 5])
+def test_column_split_tiles(emul, splits):
+    """row shares too short to fill the chip with workgroups that each stream all of X (a rank's share on N GPUs): every row tile
+    becomes S workgroup tiles with 1/S of the chunk range each, partial sums land in row r + c * nrows and are added in range order.
+    Integers: exact.  Floats: every partial sum is the CPU loop over its column range; their sum in range order is what is compared."""
+    rng = np.random.default_rng(70 + splits)
+    nrows, ncols, h = 900, 4000, 100
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=60, long_rows=[(7, 3000)])
+    xi = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+    want = oracle.spmm_csr(rowptr, col, None, xi)
+    got, _ = _run(emul, rowptr, col, ncols, xi, ka=96, batch=8, nw=16, splits=splits)
+    assert got.tobytes() == want.tobytes()
+    for kc, nbuf in ((320, 2), (192, 3)):
+        got, stats = _run_code(emul, rowptr, col, ncols, xi, kc=kc, nbuf=nbuf, splits=splits)
+        assert got.tobytes() == want.tobytes(), (kc, nbuf)
+    # floats: the reference for a split plan is the sum over column ranges (in range order) of the sequential loop over each range
+    xf = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    for kc in (320, 192):
+        nchunks = -(-ncols // kc)
+        ref = None
+        for c in range(splits):
+            lo, hi = (nchunks * c // splits) * kc, (nchunks * (c + 1) // splits) * kc
+            keep = (col >= lo) & (col < hi)
+            rows_of = np.repeat(np.arange(nrows), np.diff(rowptr))[keep]
+            rp = np.concatenate([[0], np.cumsum(np.bincount(rows_of, minlength=nrows))])
+            part = oracle.spmm_csr(rp, col[keep], None, xf)
+            ref = part if ref is None else (ref + part).astype(np.float32)
+        got, _ = _run_code(emul, rowptr, col, ncols, xf, kc=kc, nbuf=2 if kc == 320 else 3, splits=splits)
+        assert got.tobytes() == ref.tobytes(), kc
