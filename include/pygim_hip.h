@@ -218,7 +218,8 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]);
  * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),
  * "lds_round_tiles", "lds_code" (1 = FLT32 (valued too) / INT32 / INT16 unit-weight plans are compiled into machine code at creation and run by k_lds_code_*,
- * 0 = the token kernels), "lds_code_nbuf" (its LDS ring: 0 = by width, 2 = 2 x 320 columns, 3 = 3 x 192), "lds_ablate" (timing experiments, wrong results)};
+ * 0 = the token kernels), "lds_col_split" (short row shares: tiles split into column ranges, partial sums reduced in range order; 0 = automatic,
+ * 1 = never, S), "lds_col_split_f32" (1 = FLT32 shares too: their sums are then sums of per-range sums), "lds_code_nbuf" (its LDS ring: 0 = by width, 2 = 2 x 320 columns, 3 = 3 x 192), "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, narrow_vals, merge_parts at creation) are read when a group is created; the others per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

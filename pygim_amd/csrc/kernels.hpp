@@ -861,6 +861,22 @@ __device__ __forceinline__ void panel_sweep(uint32_t blk, const uint32_t *__rest
     }
 }
 
+// column-split LDS plans: C[r][f] = (accumulate ? C[r][f] : 0) + part[0][r][f] + part[1][r][f] + ... in range order (deterministic;
+// integers exact, floats: the sum of the column ranges' sequential sums)
+template <typename T>
+__global__ void k_lds_reduce(const T *__restrict__ part, uint32_t splits, uint64_t nrows, uint32_t w, uint64_t ldp, T *__restrict__ C,
+                             int64_t ldc, int accumulate) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * w) return;
+    const uint64_t r = i / w;
+    const uint32_t f = (uint32_t)(i % w);
+    using A = typename AccOf<T>::type;
+    A acc = (A)part[r * ldp + f];
+    for (uint32_t c = 1; c < splits; c++) acc = (A)(acc + (A)part[((uint64_t)c * nrows + r) * ldp + f]);
+    if (accumulate) acc = (A)((A)C[r * ldc + f] + acc);   // (as the kernels' own store: what was there + the product)
+    C[r * ldc + f] = (T)acc;
+}
+
 // dst[i] = src[i], 16 bytes a thread (the upload of the code stream into its executable allocation)
 __global__ void k_copy16(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

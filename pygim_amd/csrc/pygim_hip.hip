@@ -94,6 +94,8 @@ struct Tunables {
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
     int64_t lds_long_slots = 128;       // tokens per (wave, chunk) from which the 16-token-batch geometry is planned (0 = never)
     int64_t lds_code = 1;               // 1 = FLT32 / INT32 unit-weight plans are also compiled into machine code (lds_plan.hpp lds_code_from_plan) and run by k_lds_code_*; 0 = the token kernels
+    int64_t lds_col_split = 0;          // column-split workgroup tiles for short row shares: 0 = automatic (integers; FLT32 with lds_col_split_f32), 1 = never, S > 1 = S ranges
+    int64_t lds_col_split_f32 = 0;      // 1 = FLT32 shares may be split too (a row's sum is then the sum of its column ranges' sums: the norm-wise contract, not the bit-identical one)
     int64_t lds_code_nbuf = 0;          // chunk buffers of a code-stream plan: 0 = by the product's width (3 x 192 columns up to two slices, else 2 x 320), 2, 3
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
@@ -143,6 +145,7 @@ struct Part {
     char *lds_code = nullptr;              // the schedule as gfx950 machine code (EXECUTABLE device memory from the HSA pool), or nullptr
     uint64_t *lds_code_start = nullptr;    // [ntiles][16]: byte offset of a (tile, wave) stream
     uint64_t lds_code_bytes = 0, lds_code_pairs = 0;
+    uint32_t lds_col_splits = 1;           // > 1: the plan's tiles are (row tile, column range) pairs writing partial sums (launch_lds reduces them)
     uint32_t lds_code_piece = 0;           // bytes of a chunk one wave DMAs (the code plan's ring geometry)
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
@@ -438,6 +441,7 @@ void free_part(Part &p) {
     p.lds_code = nullptr;
     p.lds_code_start = nullptr;
     p.lds_is_code = false;
+    p.lds_col_splits = 1;
     if (p.extra) free_part(*p.extra);
 }
 
@@ -817,6 +821,18 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.nslices = nslices;
     a.ntiles = p.lds_ntiles;
     a.accumulate = accumulate ? 1 : 0;
+    // column-split plans: the tiles write the partial sums of column range c to row r + c * nrows of a scratch block (compact rows of
+    // w_lanes dwords); k_lds_reduce adds the S blocks in range order into C afterwards
+    const uint32_t S = p.lds_col_splits;
+    const uint64_t ldp = (uint64_t)w_lanes * 4 / sizeof(T);   // elements of a partial row
+    if (S > 1) {
+        if (deq_amax) return fail(PYGIM_ERR_INVALID, "internal: dequantising store on a column-split LDS plan");
+        const size_t need = (size_t)S * (size_t)p.nrows * ldp * sizeof(T);
+        if (int rc = ensure(&g->scratch, &g->scratch_bytes, std::max<size_t>(need, 256))) return rc;
+        a.c = (char *)g->scratch;
+        a.ldc_bytes = (uint32_t)(ldp * sizeof(T));
+        a.accumulate = 0;
+    }
     a.wdelta = p.lds_wdelta;
     a.deq_amax = deq_amax;
     a.deq_log2 = deq_log2;
@@ -892,6 +908,11 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
         }
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(p.lds_nw * 64), LDS_BYTES, st, a);
+    if (S > 1 && p.nrows > 0 && w > 0) {
+        const uint64_t total = (uint64_t)p.nrows * w;
+        hipLaunchKernelGGL((k_lds_reduce<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const T *)g->scratch, S, (uint64_t)p.nrows, w, ldp, C,
+                           ldc, accumulate ? 1 : 0);
+    }
     kt.stop();
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1304,6 +1325,21 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     // tiles sized so that one product of the group's width runs as whole rounds of workgroups (lds_plan.hpp)
     if (g_tune.lds_round_tiles && h_hint > 0)
         geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1));
+    // a row share too short to fill the chip with workgroups that each stream a whole slice of X (a rank's share on N GPUs: 24 tiles x
+    // 4 slices on 256 CUs): full-height row tiles, each split into S column ranges -- S x as many workgroups, each landing 1/S of X;
+    // partial sums per range, reduced in range order (launch_lds).  Integers stay exact; FLT32 only when asked (lds_col_split_f32)
+    if (g_tune.lds_col_split != 1 && geo.NW == 16 && (t_plan_dtype != PYGIM_FLT32 || g_tune.lds_col_split_f32) && !p.vals) {
+        const uint32_t cus = (uint32_t)std::max(g_ctx.cu_count, 1);
+        const uint64_t nsl = h_hint > 0 ? (uint64_t)((h_hint * (int64_t)es + 255) / 256) : 1;
+        const uint64_t tall = ((uint64_t)p.nrows + geo.NW * geo.KA - 1) / (geo.NW * geo.KA), wgs = tall * nsl;
+        uint32_t S = 1;
+        if (g_tune.lds_col_split > 1) S = (uint32_t)std::min<int64_t>(g_tune.lds_col_split, 16);
+        else if (wgs * 2 <= cus) S = (uint32_t)std::min<uint64_t>(8, cus / wgs);
+        if (S > 1 && (uint64_t)p.nrows * S < (1ull << 31)) {
+            geo.col_splits = S;
+            geo.rows_per_tile = 0;   // full-height tiles: the column ranges fill the chip
+        }
+    }
     if (g_tune.lds_mode == 0 &&
         lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
         return 0;
@@ -1355,7 +1391,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         LdsGeometry gl = geo;
         gl.KA = LDS_L16_KA;
         gl.BATCH = LDS_L16_BATCH;
-        gl.rows_per_tile = g_tune.lds_round_tiles && h_hint > 0
+        gl.rows_per_tile = geo.col_splits > 1 ? 0 : g_tune.lds_round_tiles && h_hint > 0
                                ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1))
                                : 0;
         const uint32_t r_now = geo.rows_per_tile ? geo.rows_per_tile : geo.NW * geo.KA, r_new = gl.rows_per_tile ? gl.rows_per_tile : gl.NW * gl.KA;
@@ -1406,6 +1442,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     } else if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles)) {
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
     }
+    p.lds_col_splits = geo.col_splits;
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
     p.lds_batch = geo.BATCH;
@@ -1878,6 +1915,7 @@ static Part *lds_fusable_part(Group *g) {
     else if (g->merged && g_tune.merge_parts) p = g->merged.get();
     if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || p->lds_nw != 16 || p->nrows == 0 || p->ncols == 0) return nullptr;
     if (p->lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return nullptr;
+    if (p->lds_col_splits > 1) return nullptr;   // (partial sums per column range cannot be dequantised in the store)
     return p;
 }
 
@@ -2123,6 +2161,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
     else if (n == "lds_code") slot = &g_tune.lds_code;
     else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
+    else if (n == "lds_col_split") slot = &g_tune.lds_col_split;
+    else if (n == "lds_col_split_f32") slot = &g_tune.lds_col_split_f32;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);

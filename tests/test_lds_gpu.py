@@ -335,3 +335,47 @@ def test_quantised_aggregation_with_the_dequantising_store(rng, lds_forced, dt, 
     want = oracle.symmetric_dequantize(oracle.spmm_csr(rowptr, col, None, xq), 1.0, s_ref)
     assert np.float32(scale.item()) == s_ref
     assert out.cpu().numpy().tobytes() == want.tobytes(), code
+
+
+@pytest.mark.parametrize("code", [1, 0])
+def test_short_row_shares_split_their_tiles_into_column_ranges(rng, lds_forced, code):
+    """a rank's row share on N GPUs is a few tall tiles: too few workgroups to fill the chip when each streams a whole slice of X.
+    The plan then splits every row tile into S column ranges (S x the workgroups, 1/S of X each), partial sums land in a scratch
+    block and are added in range order.  INT32 / INT16: exact, automatic.  FLT32: only with lds_col_split_f32 = 1, and then a row's
+    sum is the sum of its ranges' sequential sums (compared here on integer-valued features, where every order is exact, and
+    on real ones against the norm-wise bound)."""
+    old_code = _lib.set_tunable("lds_code", code)
+    try:
+        n, ncols, h = 2500, 30000, 256
+        rowptr, col = random_csr(rng, n, ncols, 150, empty_frac=0.1, long_rows=[(3, 9000)])
+        xi = features(rng, ncols, h, np.int32)
+        got, plan = product(rowptr, col, xi)
+        assert plan["tiles"] >= 4 * 2 and plan["tiles"] % 2 == 0          # 2 tall row tiles x S >= 4 column ranges
+        assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xi).tobytes()
+        # FLT32: not split unless asked
+        xf = features(rng, ncols, h, np.float32)
+        got, plan1 = product(rowptr, col, xf)
+        assert plan1["tiles"] < plan["tiles"] and got.tobytes() == oracle.spmm_csr(rowptr, col, None, xf).tobytes()
+        old = _lib.set_tunable("lds_col_split_f32", 1)
+        try:
+            got, plan2 = product(rowptr, col, xf)
+            xint = rng.integers(-8, 8, size=(ncols, h)).astype(np.float32)
+            got_i, _ = product(rowptr, col, xint)
+        finally:
+            _lib.set_tunable("lds_col_split_f32", old)
+        assert plan2["tiles"] == plan["tiles"]
+        assert np.array_equal(got_i, oracle.spmm_csr(rowptr, col, None, xint))
+        want = oracle.spmm_csr(rowptr, col, None, xf)
+        scale = oracle.spmm_csr(rowptr, col, None, np.abs(xf))
+        assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * scale + 1e-30)
+        # a forced split count, and never
+        for s, tiles in ((3, 2 * 3), (1, None)):
+            o = _lib.set_tunable("lds_col_split", s)
+            try:
+                got, pl = product(rowptr, col, xi)
+            finally:
+                _lib.set_tunable("lds_col_split", o)
+            assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xi).tobytes()
+            assert tiles is None or pl["tiles"] == tiles
+    finally:
+        _lib.set_tunable("lds_code", old_code)
