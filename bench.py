@@ -215,6 +215,13 @@ def main():
     feat_ok = h % world == 0 and (h // world) * 4 >= 32
     from pygim_amd import autotune
 
+    if world > 1:
+        # a rank's row share is a few tall tiles: let the LDS-staged plan split them into column ranges (S x the workgroups, each
+        # landing 1 / S of X; a 1/8 share of this graph: 1.08 -> 0.52 ms, profiles/r03_exp_colsplit.txt).  For FLT32 a row's sum is
+        # then the sum of its ranges' sums (the norm-wise contract); the N = 1 line never splits.
+        _lib.set_tunable("lds_col_split_f32", 1)
+        autotune.LDS_COL_SPLIT = True
+
     prior, table = autotune.choose(n, n, nnz, h, 4, max(world, 1))
     cands = []
     if args.partition == "pipelined":

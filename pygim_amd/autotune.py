@@ -37,6 +37,7 @@ LDS_CYC_PER_SLOT = 1030     # CU cycles per chunk of X beside the entries (barri
 LDS_CYC_FILL = 3300         # CU cycles to land an 80 KiB chunk with every CU streaming (~56 GB/s per CU: the L2's gather ceiling shared by 256): a slot cannot be shorter
 LDS_CYC_FILL3 = 1750        # ... a 48 KiB chunk of the three-buffer ring
 LDS_PAD = 1.0               # the code stream has no padding entries (the token kernels: 1.07-1.085)
+LDS_COL_SPLIT = False       # True when the caller lets FLT32 shares be split into column ranges (tunable lds_col_split_f32; bench.py at N > 1)
 LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
@@ -69,11 +70,22 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
     if es != 4 or h < 33 or nrows == 0 or nnz == 0:
         return None
     nsl = -(-h // 64)
+    three = nsl <= 2
+    # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
+    tall = -(-int(nrows) // LDS_ROWS_MAX)
+    if LDS_COL_SPLIT and tall * nsl * 2 <= CUS:
+        split = min(8, CUS // (tall * nsl))
+        if nnz / (tall * ncols) < LDS_MIN_REUSE:
+            return None
+        slots = -(-int(ncols) // (LDS_KC3 if three else LDS_KC)) / split
+        per_slot = LDS_CYC_PER_SLOT * (0.6 if three else 1.0)
+        per_wg = max(nnz * LDS_PAD / tall / split * LDS_CYC_PER_TOKEN + slots * per_slot, slots * (LDS_CYC_FILL3 if three else LDS_CYC_FILL))
+        reduce_s = (split + 1) * nrows * h * es / RATE_STREAM
+        return per_wg / LDS_CLOCK + reduce_s + ncols * h * es * 2 / RATE_STREAM + 2 * LAUNCH
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    three = nsl <= 2
     slots = -(-int(ncols) // (LDS_KC3 if three else LDS_KC))
     per_slot = LDS_CYC_PER_SLOT * (0.6 if three else 1.0)
     per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * per_slot, slots * (LDS_CYC_FILL3 if three else LDS_CYC_FILL))
