@@ -151,6 +151,11 @@ def main():
     from pygim_amd import _lib, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # a rank that hangs (a collective that never completes, a teardown that blocks) says where and ends instead of waiting for ever
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ.get("PYGIM_RANK_TIMEOUT", "1800")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:

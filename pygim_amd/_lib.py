@@ -97,9 +97,18 @@ def ptr_array(ptrs):
     return (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(int(p) if p else None) for p in ptrs])
 
 
+def _env_tunables():
+    """PYGIM_TUNE="name=value,name=value": kernel tunables for a whole run without touching the driver scripts (A/B runs)"""
+    for kv in filter(None, os.environ.get("PYGIM_TUNE", "").split(",")):
+        name, _, value = kv.partition("=")
+        if set_tunable(name.strip(), int(value)) == -1:
+            raise ValueError(f"PYGIM_TUNE: unknown tunable {name!r}")
+
+
 def init_ranks(nr_ranks, want_units=False):
     out = (ctypes.c_int64 * max(int(nr_ranks), 1))()
     check(lib().pygim_init_ranks(int(nr_ranks), out))
+    _env_tunables()
     return list(out)[: int(nr_ranks)] if want_units else None
 
 
