@@ -145,18 +145,32 @@ def _bag_class(module, name):
     return _bag_classes[key]
 
 
+# exact names of torch that a tensor pickle may name -- rebuilders, storages, dtypes, Size; nothing is matched by prefix or suffix
+_TORCH_GLOBALS = {
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._utils", "_rebuild_sparse_tensor"),
+    ("torch._utils", "_rebuild_sparse_csr_tensor"), ("torch._utils", "_rebuild_qtensor"),
+    ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "Tensor"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("torch.serialization", "_get_layout"),
+}
+_TORCH_STORAGES = {"DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+                   "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage", "TypedStorage"}
+
+
 class _PygUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        # protocol 4 resolves dotted names through getattr chains ("_rebuild_tensor.__globals__..." reaches builtins): a global is a
+        # plain identifier in a plain module path, or it is refused before anything is looked up
+        if not isinstance(module, str) or not isinstance(name, str) or "." in name or not name.isidentifier() or \
+                not all(part.isidentifier() for part in module.split(".")):
+            raise pickle.UnpicklingError(f"processed dataset file names {module!r}.{name!r}: not a plain global")
         if module.split(".")[0] in _STUB_PREFIXES:
             return _bag_class(module, name)
-        # tensor / storage rebuilders, dtypes, Size -- and nothing else of torch
-        if (module == "torch._utils" and name.startswith("_rebuild_")) or (module == "torch._tensor" and name.startswith("_rebuild_")) or \
-                (module == "torch" and (name.endswith("Storage") or name in ("Size", "Tensor", "device", "dtype") or
-                                        isinstance(getattr(__import__("torch"), name, None), __import__("torch").dtype))) or \
-                (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage")) or \
-                (module == "torch.serialization" and name == "_get_layout"):
+        if (module, name) in _TORCH_GLOBALS or (module, name) in _SAFE_GLOBALS:
             return super().find_class(module, name)
-        if (module, name) in _SAFE_GLOBALS:
+        if module == "torch" and (name in _TORCH_STORAGES or isinstance(getattr(__import__("torch"), name, None), __import__("torch").dtype)):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"processed dataset file refers to {module}.{name}: not a tensor, a container or a PyG object")
 

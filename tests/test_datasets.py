@@ -231,3 +231,26 @@ def test_processed_pt_refuses_foreign_code(tmp_path):
     torch.save((Evil(), None), str(path))
     with pytest.raises(pickle.UnpicklingError):
         datasets.load_processed(str(path))
+
+
+@pytest.mark.parametrize("module,name", [
+    ("torch._utils", "_rebuild_tensor.__globals__.__class__.get"),   # protocol-4 dotted name: a getattr chain into dict.get
+    ("torch._utils", "_rebuild_device_tensor_from_numpy.__globals__"),
+    ("torch._utils", "_rebuild_nonexistent"),                          # (a prefix is not enough)
+    ("torch", "EvilStorage"),                                          # (nor a suffix)
+    ("torch.storage", "_load_from_bytes"),                             # (would re-enter an unrestricted torch.load)
+    ("os", "system"), ("builtins", "eval"), ("builtins", "getattr"),
+])
+def test_restricted_unpickler_refuses_dotted_and_unlisted_names(module, name):
+    """names are matched exactly, and a dotted name (pickle protocol 4 resolves it attribute by attribute) is
+    refused before any lookup -- the harmless payload below used to come back as dict.get"""
+    import io
+
+    up = datasets._PygUnpickler(io.BytesIO(b""))
+    with pytest.raises(pickle.UnpicklingError):
+        up.find_class(module, name)
+    # the same through a real protocol-4 stream: GLOBAL by STACK_GLOBAL with the dotted name
+    payload = pickle.PROTO + bytes([4]) + pickle.SHORT_BINUNICODE + bytes([len(module)]) + module.encode() + \
+        pickle.SHORT_BINUNICODE + bytes([len(name)]) + name.encode() + pickle.STACK_GLOBAL + pickle.STOP
+    with pytest.raises(pickle.UnpicklingError):
+        datasets._PygUnpickler(io.BytesIO(payload)).load()
