@@ -402,26 +402,39 @@ def main():
         # (plans with long slots -- >= 128 tokens per wave and chunk -- take the 16-token-batch form of the kernel, pygim_hip.hip lds_long_slots)
         long_slots = lds_info["chunk_fills"] > 0 and lds_info["tokens"] / (lds_info["chunk_fills"] * 16) >= 128
         code_info = _lib.group_lds_code(handles[0])
-        if code_info["active"]:   # the schedule compiled into machine code (k_lds_code_*: 1.5 instructions per stored entry)
-            kname = (f"k_slice_pack<float,4,4> + k_lds_code_f32 (ONE launch per product: {lds_info['tiles']} row tiles x {nsl} slices; "
+        geo = _lib.group_lds_geometry(handles[0])    # waves, accumulators per wave, chunk columns, ring buffers ... as the library planned them
+        chunk_bytes = geo["chunk_cols"] * 256
+        if code_info["active"]:   # the schedule compiled into machine code (k_lds_code_* / k_lds_code8_*)
+            kfam = "k_lds_code8_f32" if geo["waves"] == 8 else "k_lds_code_f32"
+            kname = (f"k_slice_pack<float,4,4> + {kfam} (ONE launch per product: {lds_info['tiles']} row tiles x {nsl} slices, {geo['waves']} waves x "
+                     f"{geo['acc_per_wave']} accumulators, LDS ring {geo['buffers']} x {geo['chunk_cols']} columns; "
                      f"{code_info['code_bytes'] / 1e9:.2f} GB of generated gfx950 code per graph)")
         else:
             kname = (f"k_slice_pack<float,4,4> + k_lds_spmm_f32_w16{'b' if long_slots else ''} (ONE launch per product: {lds_info['tiles']} row tiles x "
                      f"{nsl} slices)")
         launches = 1
-        staged = lds_info["chunk_fills"] * 81920 * nsl     # 80 KiB chunks: 320 columns x 256 bytes
+        staged = lds_info["chunk_fills"] * chunk_bytes * nsl
+        # the LDS array is what the code-stream kernel keeps busiest: 2 cycles per 256-byte ds_read (one per stored entry that does not
+        # share a neighbour's read) + the DMA's writes at ~128 B/clk (scripts/micro/fillrate.hip), per CU at the clock below
+        lds_reads = (lds_info["nnz"] - geo["shared_entries"]) * nsl
+        lds_cycles = lds_reads * 2 + staged / 128
         on_chip = {"level": "LDS (one 256-byte row slice per stored entry and slice: ds_read_b32, or ds_read2st64_b32 for two entries)", "gather_bytes": gather,
                    "achieved_TBs": round(gather / (k_ms * 1e-3) / 1e12, 2) if k_ms else None, "peak_TBs": round(LDS_READ_B32_TBS, 1),
                    "frac": round(gather / (k_ms * 1e-3) / 1e12 / LDS_READ_B32_TBS, 4) if k_ms else None,
+                   "geometry": geo,
                    "staged_L2_to_LDS_bytes": staged,
                    "staged_TBs": round(staged / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
+                   "lds_reads": lds_reads, "entries_sharing_a_read": geo["shared_entries"] * nsl,
+                   "lds_array_cycles_per_cu": round(lds_cycles / 256),
+                   "lds_array_busy_frac_at_2.4GHz": round(lds_cycles / 256 / (k_ms * 1e-3 * 2.4e9), 3) if k_ms else None,
                    "tokens_incl_padding": lds_info["tokens"],
                    **({"code_stream": code_info, "instruction_fetch_bytes": code_info["code_bytes"] * nsl,
-                       # what the kernel is bound by now: bytes the L2 hands to the CUs (chunks into LDS + the code, each fetched once
-                       # per slice) against the gather ceiling measured in round 2 (17.7 TB/s; 256 CUs x ~70 GB/s of LDS-DMA is the same number)
+                       # bytes the L2 hands to the CUs (chunks into LDS + the code, each fetched once per slice) against what 256 CUs land
+                       # with a DMA request stream that never dries up (scripts/micro/fillrate.hip, round 4: 113 GB/s per CU = 29 TB/s;
+                       # round 3's two-buffer ring drained at every slot boundary: 81 GB/s per CU alone, 17.7 TB/s under the product)
                        "l2_read_TBs": round((staged + code_info["code_bytes"] * nsl) / (k_ms * 1e-3) / 1e12, 2) if k_ms else None,
-                       "l2_read_ceiling_measured_TBs": 17.7,
-                       "l2_read_frac": round((staged + code_info["code_bytes"] * nsl) / (k_ms * 1e-3) / 1e12 / 17.7, 3) if k_ms else None}
+                       "l2_read_ceiling_measured_TBs": 29.0,
+                       "l2_read_frac": round((staged + code_info["code_bytes"] * nsl) / (k_ms * 1e-3) / 1e12 / 29.0, 3) if k_ms else None}
                       if code_info["active"] else {})}
     else:
         # template arguments: <T, VEC, LOG_LPR, AMODE, HAS_VALS, DEQ>; AMODE 3 = 128-byte slice-major rows + 16-bit panel-local ids

@@ -211,6 +211,11 @@ int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
  * instruction stream per (row tile, wave), 1.5 instructions per stored entry): bytes of code (0 = none), stored entries that share
  * an LDS instruction with a neighbour, 1 when products take this form (tunable "lds_code"), 0 */
 int pygim_group_lds_code(int64_t handle, int64_t out[4]);
+/* geometry of that schedule, as the library planned it (callers price staged bytes from THIS, not from assumed constants):
+ * waves per workgroup, accumulators (rows) per wave, columns per chunk (chunk bytes = 256 x this), chunk buffers of the LDS ring,
+ * staged columns per group of reads and x-register sets of a code stream (0 0 for a token plan), stored entries served by another
+ * entry's LDS read (code streams: entries of different rows of one wave that share a column of a chunk), column ranges per row tile */
+int pygim_group_lds_geometry(int64_t handle, int64_t out[8]);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
@@ -219,9 +224,17 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]);
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),
  * "lds_round_tiles", "lds_code" (1 = FLT32 (valued too) / INT32 / INT16 unit-weight plans are compiled into machine code at creation and run by k_lds_code_*,
  * 0 = the token kernels), "lds_col_split" (short row shares: tiles split into column ranges, partial sums reduced in range order; 0 = automatic,
- * 1 = never, S), "lds_col_split_f32" (1 = FLT32 shares too: their sums are then sums of per-range sums), "lds_code_nbuf" (its LDS ring: 0 = by width, 2 = 2 x 320 columns, 3 = 3 x 192), "lds_ablate" (timing experiments, wrong results)};
+ * 1 = never, S), "lds_col_split_f32" (1 = FLT32 shares too: their sums are then sums of per-range sums), "lds_code_nbuf" (its LDS ring: 0 = by width and geometry, 2 = two buffers of 320 columns with a barrier at every slot boundary,
+ * 3 / 4 / 5 = 192 / 160 / 128 columns with ONE barrier in the middle of a slot and nbuf - 2 chunks in flight),
+ * "lds_code_waves" (waves per workgroup of a code-stream plan: 16 x 96 accumulators, 8 x 228 = taller tiles and fewer rounds of workgroups, 0 = automatic),
+ * "lds_code_kc" (columns per chunk, 0 = by the ring), "lds_code_gsize" / "lds_code_nsets" (staged columns per group of LDS reads / x-register sets: the
+ * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_long_slots", "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
- * Plan-shaping knobs (panel_*, long_*, split_unit_pattern, narrow_vals, merge_parts at creation) are read when a group is created; the others per product.  */
+ * READ AT GROUP CREATION (they shape the plan; changing them afterwards does not touch existing groups, and switching "lds_code" off
+ * after a code-stream group was created sends that group's products to the sweep): panel_*, long_*, split_unit_pattern, narrow_vals,
+ * merge_parts, lds_code, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_waves, lds_col_split,
+ * lds_col_split_f32, lds_round_tiles, lds_long_slots, lds_min_reuse_x100 and lds_mode (whether a plan is made at all), lds_threads.
+ * The others are read per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -56,8 +56,10 @@ def lds_rows_per_tile(nrows, nslices, rmax=LDS_ROWS_MAX, cus=CUS):
     tiles = -(-nrows // rmax)
     wgs = tiles * nslices
     rounds = -(-wgs // cus)
-    if rounds > 8 or wgs % cus == 0:
+    if rounds > 8:
         return rmax
+    if wgs % cus == 0:
+        return -(-nrows // tiles)      # whole rounds already: tiles of equal height
     tiles2 = rounds * cus // nslices
     if tiles2 <= tiles:
         return rmax

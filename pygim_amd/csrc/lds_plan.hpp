@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -61,6 +62,7 @@ struct LdsGeometry {
     uint32_t col_splits = 1;     // S > 1: every row tile becomes S workgroup tiles, each with 1/S of the chunk range; tile (t, c) writes its
                                  // partial sums to row r + c * nrows (the row map says so): the caller sums the S row blocks afterwards.
                                  // For row shares too short to fill the chip with whole-X workgroups (a rank's share on N GPUs)
+    uint32_t ka_stride() const { return (KA + 7) & ~7u; }   // row-map entries per wave: the store stage reads the map eight rows at a time
     uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
                                  // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
                                  // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
@@ -83,8 +85,9 @@ struct LdsPlanHost {
 inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
                            LdsPlanHost &out, unsigned threads = 0, const uint32_t *vals = nullptr) {
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, B = geo.BATCH;
-    const uint32_t RS = NW * KA;                                                       // row-map stride of a tile
-    const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, RS) : RS;     // rows of a tile
+    const uint32_t KAS = geo.ka_stride();
+    const uint32_t RS = NW * KAS;                                                      // row-map stride of a tile
+    const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, NW * KA) : NW * KA;   // rows of a tile
     const uint32_t S = std::max(1u, geo.col_splits);
     const uint32_t ntiles = ((nrows + R - 1) / R) * S;                                // workgroup tiles: (row tile, column range)
     const uint32_t nchunks = (ncols + KC - 1) / KC;
@@ -137,7 +140,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             const uint32_t w = (round & 1) ? NW - 1 - pos : pos;
             tt.wave_of[order[i]] = (uint8_t)w;
             tt.k_of[order[i]] = (uint16_t)round;
-            out.rowmap[((size_t)t * NW + w) * KA + round] = r0 + order[i] + cs * nrows;   // (row of the partial-sum block of column range cs)
+            out.rowmap[((size_t)t * NW + w) * KAS + round] = r0 + order[i] + cs * nrows;   // (row of the partial-sum block of column range cs)
         }
         // token counts per (chunk, wave)
         std::vector<uint32_t> cnt((size_t)nchunks * NW, 0);
@@ -210,7 +213,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         // rows in accumulator order per wave == any order that visits a wave's rows k = 0, 1, ...: walk k-major
         for (uint32_t k = 0; k < KA; k++)
             for (uint32_t w = 0; w < NW; w++) {
-                const uint32_t rowm = out.rowmap[((size_t)t * NW + w) * KA + k];
+                const uint32_t rowm = out.rowmap[((size_t)t * NW + w) * KAS + k];
                 if (rowm == 0xFFFFFFFFu) continue;
                 const uint32_t row = rowm - cs * nrows;
                 for (uint32_t e = rowptr[row]; e < rowptr[row + 1]; e++) {
@@ -257,7 +260,8 @@ inline uint32_t lds_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32_t nslice
     if (!nrows || !nslices || !cus) return rmax;
     const uint64_t tiles = (nrows + rmax - 1) / rmax, wgs = tiles * nslices;
     const uint64_t rounds = (wgs + cus - 1) / cus;
-    if (rounds > 8 || wgs % cus == 0) return rmax;
+    if (rounds > 8) return rmax;
+    if (wgs % cus == 0) return (uint32_t)((nrows + tiles - 1) / tiles);   // whole rounds already: tiles of equal height
     // as many tiles as fit the same number of rounds (less than one round: enough tiles to give every CU a workgroup --
     // the caller's reuse rule then decides whether such light tiles are still worth staging X for)
     // (rounded DOWN: 171 tiles x 3 slices = 513 workgroups would start a third round for one workgroup; 170 x 3 = 510 do not)
@@ -284,45 +288,118 @@ inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncol
 //     v_add_f32 acc[k], x, acc[k]                                         -- the accumulator is the instruction's register field
 // i.e. 1.5 instructions and 8.5 bytes of code per entry, no address arithmetic, no index register, no token loads, no batch
 // bookkeeping and no padding (measured in isolation, scripts/micro/codestream.hip: 2.56 CU cycles per entry streamed from memory
-// once against 3.1-3.3 for the four-instruction token of the token kernels).  The slot boundary (DMA of the next chunk, wait,
+// once against 3.1-3.3 for the four-instruction token of the token kernels).  The chunk hand-off (DMA of a later chunk, wait,
 // barrier) is inlined with the chunk ids as literals; every 1 KB the stream touches its own lines 2 KiB ahead into the L2.
+//
+// Round 4: two geometries and two hand-offs.
+//   * 16 waves x 96 accumulators (1 536 rows per tile at most, 4 waves per SIMD) -- round 3's -- and 8 waves x 228 accumulators
+//     (1 824 rows: the Reddit-shaped product of four slices is then TWO rounds of workgroups on 256 CUs instead of three, i.e. a third
+//     less of X streamed through LDS; 2 waves per SIMD with 256 VGPRs each).  The reads run NSETS - 1 groups of GSIZE entries ahead of
+//     the adds (x-register sets), and the pipeline is not drained at a slot boundary.
+//   * ring of two buffers (NBUF = 2): chunk j + 1 goes into the buffer chunk j - 1 was read from, so the workgroup meets at the slot
+//     boundary: all reads of the slot have returned, everybody's pieces of the next chunk have landed (round 3).
+//     Ring of three or more buffers: ONE barrier in the MIDDLE of slot j says "everybody is done with chunk j - 1 and has landed
+//     chunk j + 1"; behind it chunk j + NBUF - 1 is issued into the buffer of chunk j - 1.  Nobody waits at the slot boundary, the reads
+//     in flight cross it, and NBUF - 2 chunks are in flight while one is read.
 // Register contract with the kernel (scripts/gen_lds_kernel.py body_code): see LdsCodeRegs.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct LdsCodeRegs {
     // VGPRs
-    uint32_t vbase[3] = {4, 5, 10};   // lane * 4 + 0 / 65536 / 131072 (LDS rows 0..255, 256..511, 512..639)
-    uint32_t vl16 = 6;       // lane * 16 (DMA)
-    uint32_t vl128 = 11;     // lane * 128 (touch)
-    uint32_t vjunk = 9;
-    uint32_t x0 = 12;        // x registers: two sets of 8 (v12..19, v20..27)
-    uint32_t acc0 = 28;      // accumulators v28 .. v28 + KA - 1
+    uint32_t vbase[3] = {0, 0, 0};   // lane * 4 + 0 / 65536 / 131072 (LDS rows 0..255, 256..511, 512..639)
+    uint32_t vl16 = 0;       // lane * 16 (DMA)
+    uint32_t vtouch = 0;     // lane offsets of a touch: 8 lines of 128 bytes
+    uint32_t vjunk = 0;      // destination of the touches
+    uint32_t x0 = 0;         // x registers: NSETS sets of GSIZE
+    uint32_t gsize = 0, nsets = 0;
+    uint32_t acc0 = 0;       // accumulators v[acc0] .. v[acc0 + KA - 1]
     // SGPRs
     uint32_t s_xs = 80;      // s[80:81]: this slice of X + wave * PIECE (bytes)
     uint32_t s_ldsw = 82;    // LDS byte address of this wave's DMA piece inside a chunk buffer
     uint32_t s_cb = 84;      // s[84:85]: code touch pointer
     uint32_t s_ret = 86;     // s[86:87]: return address
     uint32_t s_pa = 92;      // s[92:93]: DMA source
+    constexpr uint32_t nx() const { return gsize * nsets; }
 };
+// 16 waves: v4 v5 v10 bases, v6 lane * 16, v11 (lane % 8) * 128, v9 junk, x v12..v27, accumulators v28..v123
+// 8 waves:  v0 is the lane id (the only register the compiler keeps), v1..v3 bases, v4 lane * 16 (DMA and touch), v5 junk,
+//           x v6..v27 (22 registers: two sets of 10 or three of 6), accumulators v28..v255
+constexpr LdsCodeRegs lds_code_regs(uint32_t NW, uint32_t gsize = 0, uint32_t nsets = 0) {
+    LdsCodeRegs r;
+    if (NW == 16) {
+        r.vbase[0] = 4; r.vbase[1] = 5; r.vbase[2] = 10;
+        r.vl16 = 6; r.vtouch = 11; r.vjunk = 9; r.x0 = 12; r.acc0 = 28;
+        r.gsize = gsize ? gsize : 8;
+        r.nsets = nsets ? nsets : 2;
+    } else {
+        r.vbase[0] = 1; r.vbase[1] = 2; r.vbase[2] = 3;
+        r.vl16 = 4; r.vtouch = 4; r.vjunk = 5; r.x0 = 6; r.acc0 = 28;
+        r.gsize = gsize ? gsize : 10;
+        r.nsets = nsets ? nsets : 2;
+    }
+    if (r.gsize & 1) r.gsize--;
+    if (r.gsize < 2) r.gsize = 2;
+    if (r.nsets < 2) r.nsets = 2;
+    while (r.x0 + r.nx() > r.acc0 && r.gsize > 2) r.gsize -= 2;
+    return r;
+}
+// what build_lds_plan chooses when the tunables leave it open (measured: profiles/r04_lds_kernel.md)
+constexpr uint32_t LDS_CODE_AUTO_WAVES = 8, LDS_CODE8_AUTO_NBUF = 5;
+constexpr uint32_t LDS_CODE8_KA = 228;   // accumulators per wave of the 8-wave code-stream geometry (v28..v255)
 
 struct LdsCodeHost {
     std::vector<uint32_t> code;          // all streams, each 256-byte aligned, + slack behind the last (the touches read ahead)
     std::vector<uint64_t> start;         // [ntiles][NW]: byte offset of a (tile, wave) stream
     uint64_t entries = 0;                // stored entries compiled (no padding)
     uint64_t pairs = 0;                  // of which read two to an LDS instruction
+    uint64_t shared = 0;                 // entries served by the read of an earlier entry of the same column (no read of their own)
+    LdsCodeRegs regs;                    // the register map the code was written for
 };
+
+// runs fn(i) for i in [0, n) on `threads` threads; an exception in a worker is carried to the caller (a std::thread body that
+// throws would end the process)
+template <typename F> inline void lds_parallel_for(uint32_t n, unsigned threads, F &&fn) {
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = std::min<unsigned>(threads, std::max(1u, n));
+    std::atomic<uint32_t> next(0);
+    std::atomic<bool> failed(false);
+    auto body = [&]() {
+        try {
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n || failed.load(std::memory_order_relaxed)) return;
+                fn(i);
+            }
+        } catch (...) {
+            failed.store(true);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
+    } catch (...) {
+        // (no more threads: the ones that started, and this one, do the work)
+    }
+    body();
+    for (auto &th : pool) th.join();
+    if (failed.load()) throw std::runtime_error("lds plan: a worker failed (out of memory?)");
+}
 
 // opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000), or LDS_CODE_PK_ADD_U16 for
 // INT16 (two features to a lane: v_pk_add_u16, a VOP3P instruction of 8 bytes)
 constexpr uint32_t LDS_CODE_PK_ADD_U16 = 0xFFFFFFFFu;
-inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0) {
+inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
+                               uint32_t nsets = 0) {
     const LdsGeometry &geo = plan.geo;
     const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
-    const LdsCodeRegs R;
+    const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets);
+    out.regs = R;
+    const uint32_t G = R.gsize, NS = R.nsets;
+    if (R.x0 + R.nx() > R.acc0 || R.acc0 + KA > 256 || G > 12 || (NS - 1) * G > 15)
+        throw std::runtime_error("lds code: the geometry does not fit the register map");
     const uint32_t pieces = (KC * 256 / 1024) / NW;   // 1 KiB DMA pieces of a chunk per wave
+    if (pieces * NW * 1024 != KC * 256) throw std::runtime_error("lds code: a chunk is not a whole number of pieces per wave");
     const uint32_t chunk_bytes = KC * 256;
     const uint32_t ntiles = plan.ntiles;
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-    threads = std::min<unsigned>(threads, std::max(1u, ntiles * NW));
     // a touch per 1 KB of code: the 8 lines (1 KB) that start 2 KiB ahead (the kernel's lane offsets repeat every 8 lanes).  A wave
     // consumes ~0.2 bytes of code per cycle: 2 KiB is > 10 000 cycles of lead.  (First version: 64 lines from 8 KiB ahead every 6 KB --
     // 512 waves per XCD x 8 KiB of lead is the whole 4 MiB L2: touched lines were evicted before they were fetched, fabric traffic
@@ -336,15 +413,19 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         void op(uint32_t a) { w.push_back(a); since_touch++; }
         void op(uint32_t a, uint32_t b) { w.push_back(a); w.push_back(b); since_touch += 2; }
     };
+    struct Grp {                           // a group of up to GSIZE staged columns whose reads have been issued, and the entries they serve
+        uint32_t nx = 0, nlds = 0, xb = 0;
+        std::vector<uint32_t> k, xr, v;    // per entry: accumulator, x register, value (valued matrices)
+    };
     const LdsCodeRegs Rr = R;
-    auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs) {
+    auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs, uint64_t &n_shared) {
         const LdsTile &t = plan.tiles[ti];
         auto s_add_lit = [&](uint32_t sdst, uint32_t ssrc, uint32_t lit) { e.op(0x80000000u | (sdst << 16) | (0xFFu << 8) | ssrc, lit); };
         auto s_addc0 = [&](uint32_t sdst, uint32_t ssrc) { e.op(0x82000000u | (sdst << 16) | (0x80u << 8) | ssrc); };
         auto touch = [&]() {
             s_add_lit(Rr.s_cb, Rr.s_cb, (e.since_touch + 5) * 4);   // (+ the five dwords of this touch itself)
             s_addc0(Rr.s_cb + 1, Rr.s_cb + 1);
-            e.op(0xDC508000u, (Rr.vjunk << 24) | (Rr.s_cb << 16) | Rr.vl128);   // global_load_dword vjunk, vl128, s[cb:cb+1]
+            e.op(0xDC508000u, (Rr.vjunk << 24) | (Rr.s_cb << 16) | Rr.vtouch);   // global_load_dword vjunk, vtouch, s[cb:cb+1]
             e.since_touch = 0;
             e.vm_touch++;
         };
@@ -380,6 +461,30 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             const uint32_t nn = (uint32_t)std::min<uint64_t>(younger, 63);
             e.op(0xBF8C0F70u | (nn & 15) | (((nn >> 4) & 3) << 14));
         };
+        auto wait_lgkm = [&](uint32_t n) { e.op(0xBF8CC07Fu | (std::min(n, 15u) << 8)); };
+        const bool valued = !plan.wts.empty();
+        // the reads in flight: groups whose LDS instructions have been issued and whose adds have not, oldest first
+        std::vector<Grp> ring(NS + 1);                              // (re-used: no allocation per group)
+        std::vector<uint32_t> pend;                                 // indices into ring
+        uint32_t gcount = 0;                                        // groups issued so far: group g reads into x-set g % NSETS
+        uint32_t lds_this_slot = 0;                                 // LDS instructions issued since the slot began
+        bool older_reads = false;                                   // a read of an EARLIER slot may still be in flight
+        auto consume_oldest = [&]() {                               // wait for the oldest group's reads, then its adds
+            uint32_t younger = 0;
+            for (size_t q = 1; q < pend.size(); q++) younger += ring[pend[q]].nlds;
+            wait_lgkm(younger);
+            if (younger <= lds_this_slot) older_reads = false;      // (LDS reads return in order)
+            const Grp &g = ring[pend.front()];
+            if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the products first (every entry has
+                          // its own x register here: the multiply overwrites it)
+                for (size_t q = 0; q < g.k.size(); q++) e.op(0x0A0000FFu | (g.xr[q] << 17) | (g.xr[q] << 9), g.v[q]);   // v_mul_f32 x, <literal value>, x
+            for (size_t q = 0; q < g.k.size(); q++) {
+                const uint32_t vk = Rr.acc0 + g.k[q];
+                if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + g.xr[q]));   // v_pk_add_u16 acc, x, acc
+                else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + g.xr[q]));
+            }
+            pend.erase(pend.begin());
+        };
         // the first NBUF - 1 chunks, then the slots
         if (t.nch) {
             for (uint32_t j = 0; j + 1 < NBUF && j < t.nch; j++) dma_chunk(j);
@@ -387,10 +492,11 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             e.op(0xBF8A0000u);                                      // s_barrier
         }
         std::vector<uint64_t> toks;   // token | value << 32 (valued FLT32 matrices: the entry's value rides as a literal of its v_mul_f32)
-        const bool valued = !plan.wts.empty();
         for (uint32_t j = 0; j < t.nch; j++) {
-            bool dma_due = j + NBUF - 1 < t.nch;   // the DMA of chunk j + NBUF - 1 (into the buffer the barrier just freed) goes behind the
-                                                   // slot's FIRST group of reads (their LDS latency covers its issue)
+            // NBUF = 2: the DMA of chunk j + 1 (into the buffer the boundary barrier just freed) goes behind the slot's FIRST group of
+            // reads (their LDS latency covers its issue).  NBUF >= 3: the hand-off sits in the middle of the slot (below)
+            bool dma_due = NBUF == 2 && j + 1 < t.nch;
+            bool handoff_due = NBUF >= 3;
             const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT;
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
@@ -398,69 +504,89 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 if ((tk & 0xFF) < KA) toks.push_back((uint64_t)tk | (valued ? (uint64_t)plan.wts[at + b] << 32 : 0));
             }
             at += (uint64_t)nb * B;
-            // entries of the low LDS block first (stable: a row's entries are in column order, so its order is kept), then pairs
-            std::stable_sort(toks.begin(), toks.end(), [](uint64_t a, uint64_t b) { return ((uint32_t)a >> 16) < ((uint32_t)b >> 16); });   // block = ldsrow >> 8 = token >> 16
+            // by staged column (stable): every row's entries are in column order already, so each row's order is kept; entries of
+            // different rows of this wave that share a column now sit side by side and share ONE read (8 waves x 228 rows: a fifth of
+            // the entries of a uniform Reddit-shaped slot), and neighbours are in the same 256-row LDS block: they pair up
+            std::stable_sort(toks.begin(), toks.end(), [](uint64_t a, uint64_t b) { return ((uint32_t)a >> 8) < ((uint32_t)b >> 8); });
             n_entries += toks.size();
-            // groups of up to 8 entries: reads of group g, wait for group g - 1, adds of group g - 1
-            size_t i = 0;
-            uint32_t gsel = 0, prev_n = 0, prev_x = 0;
-            uint32_t prev_k[8], prev_v[8];
-            auto adds_prev = [&]() {
-                if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the eight products first
-                    for (uint32_t q = 0; q < prev_n; q++) {
-                        const uint32_t vx = prev_x + q;
-                        e.op(0x0A0000FFu | (vx << 17) | (vx << 9), prev_v[q]);   // v_mul_f32 x, <literal value>, x
-                    }
-                for (uint32_t q = 0; q < prev_n; q++) {
-                    const uint32_t vk = Rr.acc0 + prev_k[q];
-                    if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + prev_x + q));   // v_pk_add_u16 acc, x, acc
-                    else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + prev_x + q));
+            lds_this_slot = 0;
+            older_reads = !pend.empty();
+            // the hand-off of a ring of >= 3 buffers, once per slot and wave: my pieces of chunk j + 1 have landed, my reads of chunk
+            // j - 1 have returned; behind the barrier chunk j + NBUF - 1 goes into the buffer of chunk j - 1
+            auto handoff = [&]() {
+                if (j + 1 < t.nch) wait_landed(j + 1);
+                if (older_reads) {
+                    wait_lgkm(lds_this_slot);
+                    older_reads = false;
                 }
+                e.op(0xBF8A0000u);                                  // s_barrier
+                if (j + NBUF - 1 < t.nch) dma_chunk(j + NBUF - 1);
+                handoff_due = false;
             };
-            while (i < toks.size()) {
-                const uint32_t xb = Rr.x0 + 8 * gsel;
-                uint32_t n = 0, nlds = 0, ks[8], vs[8];
-                while (n < 8 && i < toks.size()) {
-                    const uint32_t t0 = (uint32_t)toks[i], r0 = t0 >> 8, blk = r0 >> 8;
-                    if (n + 2 <= 8 && (n & 1) == 0 && i + 1 < toks.size() && (((uint32_t)toks[i + 1] >> 8) >> 8) == blk) {
-                        const uint32_t r1 = (uint32_t)toks[i + 1] >> 8;
-                        e.op(0xD8700000u | ((r1 & 255) << 8) | (r0 & 255), ((xb + n) << 24) | Rr.vbase[blk]);   // ds_read2st64_b32
-                        ks[n] = t0 & 0xFF;
-                        ks[n + 1] = (uint32_t)toks[i + 1] & 0xFF;
-                        vs[n] = (uint32_t)(toks[i] >> 32);
-                        vs[n + 1] = (uint32_t)(toks[i + 1] >> 32);
-                        n += 2;
-                        i += 2;
-                        n_pairs += 2;
+            // the staged columns of the slot: (LDS row, first entry, entries); valued matrices: one per entry
+            struct Col { uint32_t row, first, cnt; };
+            std::vector<Col> cols;
+            for (uint32_t q = 0; q < toks.size(); q++) {
+                const uint32_t r = (uint32_t)toks[q] >> 8;
+                if (!valued && !cols.empty() && cols.back().row == r) cols.back().cnt++;
+                else cols.push_back({r, q, 1});
+            }
+            n_shared += toks.size() - cols.size();
+            const size_t ngroups_est = (cols.size() + G - 1) / G;
+            size_t gi = 0, i = 0;
+            while (i < cols.size()) {
+                Grp &g = ring[gcount % (NS + 1)];
+                g.nx = g.nlds = 0;
+                g.k.clear();
+                g.xr.clear();
+                g.v.clear();
+                g.xb = Rr.x0 + G * (gcount % NS);
+                while (g.nx < G && i < cols.size()) {
+                    const uint32_t r0 = cols[i].row, blk = r0 >> 8;
+                    uint32_t took = 1;
+                    if (g.nx + 2 <= G && (g.nx & 1) == 0 && i + 1 < cols.size() && (cols[i + 1].row >> 8) == blk) {
+                        const uint32_t r1 = cols[i + 1].row;
+                        e.op(0xD8700000u | ((r1 & 255) << 8) | (r0 & 255), ((g.xb + g.nx) << 24) | Rr.vbase[blk]);   // ds_read2st64_b32
+                        took = 2;
+                        n_pairs += cols[i].cnt + cols[i + 1].cnt;
                     } else {
-                        e.op(0xD86C0000u | ((r0 & 255) << 8), ((xb + n) << 24) | Rr.vbase[blk]);             // ds_read_b32
-                        ks[n] = t0 & 0xFF;
-                        vs[n] = (uint32_t)(toks[i] >> 32);
-                        n += 1;
-                        i += 1;
+                        e.op(0xD86C0000u | ((r0 & 255) << 8), ((g.xb + g.nx) << 24) | Rr.vbase[blk]);             // ds_read_b32
                     }
-                    nlds++;
+                    for (uint32_t u = 0; u < took; u++)
+                        for (uint32_t q = cols[i + u].first; q < cols[i + u].first + cols[i + u].cnt; q++) {
+                            g.k.push_back((uint32_t)toks[q] & 0xFF);
+                            g.xr.push_back(g.xb + g.nx + u);
+                            g.v.push_back((uint32_t)(toks[q] >> 32));
+                        }
+                    g.nx += took;
+                    i += took;
+                    g.nlds++;
                 }
+                lds_this_slot += g.nlds;
+                pend.push_back(gcount % (NS + 1));
+                gcount++;
                 if (dma_due) {
-                    dma_chunk(j + NBUF - 1);
+                    dma_chunk(j + 1);
                     dma_due = false;
                 }
-                if (prev_n) {
-                    e.op(0xBF8CC07Fu | (nlds << 8));                // s_waitcnt lgkmcnt(nlds): everything older than this group's reads
-                    adds_prev();
-                }
-                prev_n = n;
-                prev_x = xb;
-                for (uint32_t q = 0; q < n; q++) { prev_k[q] = ks[q]; prev_v[q] = vs[q]; }
-                gsel ^= 1;
+                if (pend.size() >= NS) consume_oldest();            // frees the x-set the next group reads into
+                if (handoff_due && gi + 1 >= (ngroups_est + 1) / 2) handoff();
+                gi++;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }
-            if (dma_due) dma_chunk(j + NBUF - 1);                   // (a slot without entries for this wave)
-            e.op(0xBF8CC07Fu);                                      // s_waitcnt lgkmcnt(0): the last group's reads are in
-            adds_prev();
-            if (j + 1 < t.nch) wait_landed(j + 1);                  // my pieces of the NEXT chunk have landed (younger loads may still fly)
-            e.op(0xBF8A0000u);                                      // s_barrier: everybody is done with this chunk and has landed the next
+            if (dma_due) dma_chunk(j + 1);                          // (a slot without entries for this wave)
+            if (handoff_due) handoff();
+            if (NBUF == 2) {
+                // everybody's reads of this chunk have returned and everybody has landed the next before anybody goes on; the adds of
+                // the groups still in flight overlap the wait, the last group's adds cross the barrier
+                while (pend.size() > 1) consume_oldest();
+                wait_lgkm(0);
+                older_reads = false;
+                if (j + 1 < t.nch) wait_landed(j + 1);              // my pieces of the NEXT chunk have landed (younger loads may still fly)
+                e.op(0xBF8A0000u);                                  // s_barrier
+            }
         }
+        while (!pend.empty()) consume_oldest();
         e.op(0xBF8C0F70u);                                          // s_waitcnt vmcnt(0): no touch is left in flight
         e.op(0xBE801D00u | Rr.s_ret);                               // s_setpc_b64 s[ret:ret+1]
         while (e.w.size() % 64) e.w.push_back(0xBF800000u);         // streams start on 256-byte lines
@@ -468,23 +594,12 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
 
     const uint32_t nstreams = ntiles * NW;
     std::vector<std::vector<uint32_t>> blobs(nstreams);
-    std::vector<uint64_t> ne(nstreams, 0), np(nstreams, 0);
-    {
-        std::atomic<uint32_t> next(0);
-        std::vector<std::thread> pool;
-        auto body = [&]() {
-            for (;;) {
-                const uint32_t s = next.fetch_add(1);
-                if (s >= nstreams) return;
-                Emit e;
-                emit_stream(s / NW, s % NW, e, ne[s], np[s]);
-                blobs[s].swap(e.w);
-            }
-        };
-        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
-        body();
-        for (auto &th : pool) th.join();
-    }
+    std::vector<uint64_t> ne(nstreams, 0), np(nstreams, 0), nsh(nstreams, 0);
+    lds_parallel_for(nstreams, threads, [&](uint32_t s) {
+        Emit e;
+        emit_stream(s / NW, s % NW, e, ne[s], np[s], nsh[s]);
+        blobs[s].swap(e.w);
+    });
     out.start.assign(nstreams, 0);
     uint64_t total = 0;
     for (uint32_t s = 0; s < nstreams; s++) {
@@ -492,23 +607,13 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         total += blobs[s].size();
         out.entries += ne[s];
         out.pairs += np[s];
+        out.shared += nsh[s];
     }
     out.code.assign((size_t)total + 8192, 0xBF800000u);             // (+ 32 KB of s_nop behind the last stream: touches read ahead)
-    {
-        std::atomic<uint32_t> next(0);
-        std::vector<std::thread> pool;
-        auto body = [&]() {
-            for (;;) {
-                const uint32_t s = next.fetch_add(1);
-                if (s >= nstreams) return;
-                std::copy(blobs[s].begin(), blobs[s].end(), out.code.begin() + out.start[s] / 4);
-                std::vector<uint32_t>().swap(blobs[s]);
-            }
-        };
-        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
-        body();
-        for (auto &th : pool) th.join();
-    }
+    lds_parallel_for(nstreams, threads, [&](uint32_t s) {
+        std::copy(blobs[s].begin(), blobs[s].end(), out.code.begin() + out.start[s] / 4);
+        std::vector<uint32_t>().swap(blobs[s]);
+    });
 }
 
 }  // namespace pygim

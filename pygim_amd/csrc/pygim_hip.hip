@@ -13,7 +13,11 @@
 // point fails with PYGIM_ERR_NO_DEVICE.
 #include "../../include/pygim_hip.h"
 #include "kernels.hpp"
+#ifdef PYGIM_LDS_ABLATE
+#include "lds_kernel_gen_ablate.hpp"   // (make ablate: the same kernels + round 3's timing-experiment variants; not committed)
+#else
 #include "lds_kernel_gen.hpp"
+#endif
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
@@ -97,6 +101,10 @@ struct Tunables {
     int64_t lds_col_split = 0;          // column-split workgroup tiles for short row shares: 0 = automatic (integers; FLT32 with lds_col_split_f32), 1 = never, S > 1 = S ranges
     int64_t lds_col_split_f32 = 0;      // 1 = FLT32 shares may be split too (a row's sum is then the sum of its column ranges' sums: the norm-wise contract, not the bit-identical one)
     int64_t lds_code_nbuf = 0;          // chunk buffers of a code-stream plan: 0 = by the product's width (3 x 192 columns up to two slices, else 2 x 320), 2, 3
+    int64_t lds_code_waves = 0;         // waves per workgroup of a code-stream plan: 16 (x 96 accumulators), 8 (x 228: taller tiles, fewer rounds of workgroups), 0 = automatic
+    int64_t lds_code_kc = 0;            // columns per chunk of a code-stream plan (0 = by the ring: 320 / 192 / 160 / 128 for 2 / 3 / 4 / 5 buffers)
+    int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
+    int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
@@ -147,6 +155,9 @@ struct Part {
     uint64_t lds_code_bytes = 0, lds_code_pairs = 0;
     uint32_t lds_col_splits = 1;           // > 1: the plan's tiles are (row tile, column range) pairs writing partial sums (launch_lds reduces them)
     uint32_t lds_code_piece = 0;           // bytes of a chunk one wave DMAs (the code plan's ring geometry)
+    uint32_t lds_kc = 0, lds_nbuf = 0;     // the plan's ring: columns per chunk, buffers
+    uint32_t lds_code_gsize = 0, lds_code_nsets = 0;
+    uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
@@ -845,20 +856,27 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     using KernelFn = void (*)(LdsArgs);
     KernelFn fn = nullptr;
     const bool long16 = p.lds_nw == 16 && p.lds_batch == LDS_L16_BATCH;   // the 16-token-batch geometry (no values)
-    if (deq_amax) {
+    if (p.lds_is_code) {   // the schedule compiled into machine code: 16 waves x 96 accumulators, or 8 x 228 (k_lds_code8_*)
+        if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
+        const bool w8 = p.lds_nw == 8;
+        if constexpr (sizeof(T) == 2) {
+            if (deq_amax) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
+            fn = w8 ? k_lds_code8_i16 : k_lds_code_i16;   // (two features to a lane: v_pk_add_u16)
+        } else if constexpr (std::is_same<T, float>::value) {
+            fn = deq_amax ? (w8 ? k_lds_code8_f32_deq : k_lds_code_f32_deq) : (w8 ? k_lds_code8_f32 : k_lds_code_f32);
+        } else {
+            fn = deq_amax ? (w8 ? k_lds_code8_i32_deq : k_lds_code_i32_deq) : (w8 ? k_lds_code8_i32 : k_lds_code_i32);
+        }
+        a.code = p.lds_code;
+        a.code_start = p.lds_code_start;
+        a.piece_bytes = p.lds_code_piece;
+    } else if (deq_amax) {
         if (p.lds_nw != 16 || p.lds_wdelta || sizeof(T) != 4) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
         if constexpr (std::is_same<T, float>::value) fn = long16 ? k_lds_spmm_f32_w16b_deq : k_lds_spmm_f32_w16_deq;
         else if constexpr (std::is_same<T, int32_t>::value) fn = long16 ? k_lds_spmm_i32_w16b_deq : k_lds_spmm_i32_w16_deq;
     } else if constexpr (sizeof(T) == 2) {
         if (p.lds_nw != 16) return fail(PYGIM_ERR_INVALID, "internal: INT16 LDS-staged product needs the 16-wave plan");
         fn = long16 ? k_lds_spmm_i16_w16b : (p.lds_wdelta ? k_lds_spmm_i16_w16_val : k_lds_spmm_i16_w16);
-        if (p.lds_is_code) {   // the schedule compiled into machine code (two features to a lane: v_pk_add_u16)
-            if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
-            fn = k_lds_code_i16;
-            a.code = p.lds_code;
-            a.code_start = p.lds_code_start;
-            a.piece_bytes = p.lds_code_piece;
-        }
     } else if (long16) {
         if constexpr (std::is_same<T, float>::value) fn = k_lds_spmm_f32_w16b;
         else fn = k_lds_spmm_i32_w16b;
@@ -887,16 +905,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
         fn = p.lds_nw == 16 ? (p.lds_wdelta ? k_lds_spmm_i32_w16_val : k_lds_spmm_i32_w16) : k_lds_spmm_i32_w8;
     }
     if (deq_amax && g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "lds_ablate is a timing experiment of the plain kernel");
-    if constexpr (sizeof(T) == 4) {
-        if (p.lds_is_code) {   // the schedule compiled into machine code
-            if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
-            if constexpr (std::is_same<T, float>::value) fn = deq_amax ? k_lds_code_f32_deq : k_lds_code_f32;
-            else fn = deq_amax ? k_lds_code_i32_deq : k_lds_code_i32;
-            a.code = p.lds_code;
-            a.code_start = p.lds_code_start;
-            a.piece_bytes = p.lds_code_piece;
-        }
-    }
+    if (!fn) return fail(PYGIM_ERR_INVALID, "internal: no LDS-staged kernel for this plan");
     {
         static std::set<std::pair<int, KernelFn>> attr_done;   // (the attribute is per device)
         int dev = 0;
@@ -921,7 +930,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
 template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc, const void *C) {
     if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int16_t>::value)) return false;
     if constexpr (sizeof(T) == 2) {  // two features to a lane: whole lanes, dword-aligned rows of C, the 16-wave plan
-        if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || p.lds_nw != 16) return false;
+        if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || (p.lds_nw != 16 && !p.lds_is_code)) return false;
     }
     if (!p.lds_tiles || g_tune.lds_mode == 2 || (!p.lds_is_code && (p.vals != nullptr) != (p.lds_wdelta != 0)) || g->deq_out || g->pre_xs) return false;
     if (p.lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return false;   // (a code-stream plan serves no token kernel: the sweep instead)
@@ -1322,13 +1331,31 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     geo.KA = lds_ka(geo.NW);
     geo.KC = LDS_KC;
     geo.BATCH = lds_batch(geo.NW);
+    // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its plan is built in the
+    // geometry of its kernels and serves no token kernel
+    // (valued matrices: FLT32 only -- the value is the literal of a v_mul_f32 in the stream; the integer multiplies have no literal form)
+    const bool want_code = g_tune.lds_code && geo.NW == 16 &&
+                           ((es == 4 && t_plan_dtype == PYGIM_FLT32) || (!p.vals && es == 4 && t_plan_dtype == PYGIM_INT32) ||
+                            (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16));
+    const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + 255) / 256 : 4;
+    if (want_code) {
+        // 8 waves x 228 accumulators (2 waves per SIMD): tiles of 1 824 rows -- Reddit h = 256 is two rounds of workgroups on 256 CUs
+        // instead of three, a third less of X staged -- or round 3's 16 waves x 96
+        const int64_t cw = g_tune.lds_code_waves;
+        const bool eight = cw == 8 || (cw != 16 && LDS_CODE_AUTO_WAVES == 8);
+        if (eight) {
+            geo.NW = 8;
+            geo.KA = LDS_CODE8_KA;
+            geo.BATCH = 8;
+        }
+    }
     // tiles sized so that one product of the group's width runs as whole rounds of workgroups (lds_plan.hpp)
     if (g_tune.lds_round_tiles && h_hint > 0)
         geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1));
     // a row share too short to fill the chip with workgroups that each stream a whole slice of X (a rank's share on N GPUs: 24 tiles x
     // 4 slices on 256 CUs): full-height row tiles, each split into S column ranges -- S x as many workgroups, each landing 1/S of X;
     // partial sums per range, reduced in range order (launch_lds).  Integers stay exact; FLT32 only when asked (lds_col_split_f32)
-    if (g_tune.lds_col_split != 1 && geo.NW == 16 && (t_plan_dtype != PYGIM_FLT32 || g_tune.lds_col_split_f32) && !p.vals) {
+    if (g_tune.lds_col_split != 1 && (geo.NW == 16 || want_code) && (t_plan_dtype != PYGIM_FLT32 || g_tune.lds_col_split_f32) && !p.vals) {
         const uint32_t cus = (uint32_t)std::max(g_ctx.cu_count, 1);
         const uint64_t nsl = h_hint > 0 ? (uint64_t)((h_hint * (int64_t)es + 255) / 256) : 1;
         const uint64_t tall = ((uint64_t)p.nrows + geo.NW * geo.KA - 1) / (geo.NW * geo.KA), wgs = tall * nsl;
@@ -1365,21 +1392,19 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
             for (size_t i = 0; i < v16.size(); i++) h_val[i] = (uint32_t)v16[i] * 0x10001u;
         }
     }
-    // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its LDS ring is three
-    // buffers of 192 columns (two chunks in flight), so its plan is built in that geometry and serves no token kernel
-    // (valued matrices: FLT32 only -- the value is the literal of a v_mul_f32 in the stream; the integer multiplies have no literal form)
-    const bool want_code = g_tune.lds_code && geo.NW == 16 &&
-                           ((es == 4 && t_plan_dtype == PYGIM_FLT32) || (!p.vals && es == 4 && t_plan_dtype == PYGIM_INT32) ||
-                            (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16));
     if (want_code) {
-        // the ring: two buffers of 320 columns; for products of one or two slices (their workgroups do little but land chunks) three of
-        // 192, two chunks in flight (Reddit h = 64 / 128: 1.06 / 2.04 -> 1.01 / 1.83 ms; h = 256: 3.23 -> 3.39, h = 192: 2.30 -> 3.84)
-        const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + 255) / 256 : 4;
-        const bool three = g_tune.lds_code_nbuf == 3 || (g_tune.lds_code_nbuf == 0 && nsl_hint <= 2);
-        if (three) {
-            geo.KC = LDS_CODE_KC3;
-            geo.NBUF = 3;
-        }
+        // the ring.  Two buffers of 320 columns: the workgroup meets at every slot boundary (round 3).  Three or more (round 4): one
+        // barrier in the middle of a slot, NBUF - 2 chunks in flight beside the one being read, no drain at the boundary -- the DMA
+        // requests of a CU never dry up (scripts/micro/fillrate.hip: 81 GB/s per CU with 2 x 80 KiB, 113 GB/s with 3 x 48 or 4 x 40 KiB)
+        int64_t nbuf = g_tune.lds_code_nbuf;
+        if (nbuf == 0) nbuf = geo.NW == 8 ? LDS_CODE8_AUTO_NBUF : 2;
+        nbuf = std::min<int64_t>(std::max<int64_t>(nbuf, 2), 8);
+        static const uint32_t kc_of[9] = {0, 0, 320, 192, 160, 128, 96, 64, 64};
+        uint32_t kc = g_tune.lds_code_kc > 0 ? (uint32_t)g_tune.lds_code_kc : kc_of[nbuf];
+        kc = std::max(4 * geo.NW, kc / (4 * geo.NW) * (4 * geo.NW));        // whole 1 KiB pieces per wave
+        while ((uint64_t)kc * 256 * (uint64_t)nbuf > LDS_BYTES || kc * (uint32_t)nbuf > 640) kc -= 4 * geo.NW;   // (the LDS; 10-bit LDS rows in a token)
+        geo.KC = kc;
+        geo.NBUF = (uint32_t)nbuf;
     }
     LdsPlanHost plan;
     lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
@@ -1423,7 +1448,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         LdsCodeHost ch;
         try {
             lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : (t_plan_dtype == PYGIM_INT32 ? 0x68000000u : LDS_CODE_PK_ADD_U16), ch,
-                               (unsigned)std::max<int64_t>(0, g_tune.lds_threads));
+                               (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
+                               (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets));
         } catch (const std::exception &) {
             return 0;   // (out of host memory or threads: the sweep serves the group)
         }
@@ -1439,10 +1465,15 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         p.lds_code_pairs = ch.pairs;
         p.lds_is_code = true;
         p.lds_code_piece = geo.KC * 256 / geo.NW;
+        p.lds_code_gsize = ch.regs.gsize;
+        p.lds_code_nsets = ch.regs.nsets;
+        p.lds_code_shared = ch.shared;
     } else if (!up(&p.lds_tok, plan.tok) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles)) {
         return fail(PYGIM_ERR_HIP, "LDS plan upload");
     }
     p.lds_col_splits = geo.col_splits;
+    p.lds_kc = geo.KC;
+    p.lds_nbuf = geo.NBUF;
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
     p.lds_batch = geo.BATCH;
@@ -1913,7 +1944,7 @@ static Part *lds_fusable_part(Group *g) {
     Part *p = nullptr;
     if (g->parts.size() == 1) p = &g->parts[0];
     else if (g->merged && g_tune.merge_parts) p = g->merged.get();
-    if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || p->lds_nw != 16 || p->nrows == 0 || p->ncols == 0) return nullptr;
+    if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || (p->lds_nw != 16 && !p->lds_is_code) || p->nrows == 0 || p->ncols == 0) return nullptr;
     if (p->lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return nullptr;
     if (p->lds_col_splits > 1) return nullptr;   // (partial sums per column range cannot be dequantised in the store)
     return p;
@@ -2161,6 +2192,10 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_round_tiles") slot = &g_tune.lds_round_tiles;
     else if (n == "lds_code") slot = &g_tune.lds_code;
     else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
+    else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
+    else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
+    else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
+    else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
     else if (n == "lds_col_split") slot = &g_tune.lds_col_split;
     else if (n == "lds_col_split_f32") slot = &g_tune.lds_col_split_f32;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
@@ -2484,6 +2519,23 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
     out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
     out[2] = (p.lds_is_code && g_tune.lds_code) ? 1 : 0;
     out[3] = 0;
+    return 0;
+}
+
+int pygim_group_lds_geometry(int64_t handle, int64_t out[8]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!p.lds_tiles) return 0;
+    out[0] = p.lds_nw;
+    out[1] = p.lds_is_code && p.lds_nw == 8 ? (int64_t)LDS_CODE8_KA : (p.lds_batch == LDS_L16_BATCH && p.lds_nw == 16 ? (int64_t)LDS_L16_KA : (int64_t)lds_ka(p.lds_nw));
+    out[2] = p.lds_kc;
+    out[3] = p.lds_nbuf;
+    out[4] = p.lds_is_code ? p.lds_code_gsize : 0;
+    out[5] = p.lds_is_code ? p.lds_code_nsets : 0;
+    out[6] = p.lds_is_code ? (int64_t)p.lds_code_shared : 0;
+    out[7] = p.lds_col_splits;
     return 0;
 }
 

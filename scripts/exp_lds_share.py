@@ -10,6 +10,10 @@ from pygim_amd.bench_plans import nnz_balanced_row_split
 
 dev = torch.device("cuda", 0)
 _lib.init_ranks(1)
+for kv in filter(None, (sys.argv[1] if len(sys.argv) > 1 else "").split(",")):   # name=value,... tunables for every plan
+    k, v = kv.split("=")
+    _lib.set_tunable(k, int(v))
+print("#", sys.argv[1:] or "defaults", flush=True)
 n, nnz, dmax = synth.SHAPES["reddit"]
 rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
 rp_cpu = rowptr.cpu()
@@ -36,8 +40,8 @@ for frac, h in ((1, 256), (2, 256), (3, 256), (4, 256), (6, 256), (8, 256), (16,
     for mode in (2, 1):
         _lib.set_tunable("lds_mode", mode)
         hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [top], [n], [m], [1], [h], h)
-        res[mode] = (timed(hd, x, out), _lib.group_lds_plan(hd))
+        res[mode] = (timed(hd, x, out), _lib.group_lds_plan(hd), _lib.group_lds_geometry(hd))
         _lib.group_free(hd)
     lp = res[1][1]
     reuse = m / max(lp["tiles"] * n, 1)
-    print(f"rows 1/{frac} ({top}), h={h}: sweep {res[2][0]:6.3f} ms   lds {res[1][0]:6.3f} ms   tiles {lp['tiles']:4d}  entries per staged column {reuse:5.2f}", flush=True)
+    print(f"rows 1/{frac} ({top}), h={h}: sweep {res[2][0]:6.3f} ms   lds {res[1][0]:6.3f} ms   tiles {lp['tiles']:4d}  entries per staged column {reuse:5.2f}  {res[1][2]}", flush=True)

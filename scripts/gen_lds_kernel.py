@@ -38,12 +38,14 @@ class Geo:
     VGPRs: temporaries v[T0..T0+7], two x / address sets of BATCH registers from X0, accumulators v[ACC0..ACC0+KA] (the last
     one is the dummy that padding tokens add into).  SGPRs: three token sets from TOK0, control registers from CTL0."""
 
-    def __init__(self, NW, KA, BATCH, T0, weighted=False):
+    def __init__(self, NW, KA, BATCH, T0, weighted=False, regmap=None, X0=None, ACC0=None, dummy=True):
         self.NW, self.KA, self.BATCH, self.T0, self.weighted = NW, KA, BATCH, T0, weighted
-        self.X0 = T0 + 8
-        self.ACC0 = self.X0 + 2 * BATCH
+        self.X0 = T0 + 8 if X0 is None else X0
+        self.ACC0 = self.X0 + 2 * BATCH if ACC0 is None else ACC0
+        self.regmap = regmap                  # explicit names of (VB, VM, VL16, VL4, VT0, VT1, VZ, VL128) instead of v[T0..T0+7]
+        self.dummy = dummy                    # accumulator KA exists (the token kernels' padding tokens add into it)
         self.vmax = 512 // (NW // 4)          # VGPRs per lane at NW / 4 waves per SIMD
-        assert self.ACC0 + KA + 1 <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
+        assert self.ACC0 + KA + (1 if dummy else 0) <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
         self.pieces = 80 // NW                # 1 KiB DMA pieces of an 80 KiB chunk (320 columns x 256 bytes) per wave
         self.threads = NW * 64
         self.CTL0 = 88                        # control registers s88..s100; token sets below them (s32 is reserved: start at s36)
@@ -56,6 +58,12 @@ GEO_W16 = Geo(16, 96, 8, 4, weighted=True)   # same plan geometry as GEOS[16]
 GEO_L16 = Geo(16, 80, 16, 4)                 # long slots (community-structured graphs): 16-token batches halve the per-batch bookkeeping
 GEO_CODE = Geo(16, 96, 8, 4)                 # the code-stream kernels: chunks of 192 columns (48 KiB, three buffers): 3 DMA pieces per wave
 GEO_CODE.pieces = 48 // 16
+# the 8-wave code-stream kernels (round 4): 228 accumulators per wave, 2 waves per SIMD with 256 VGPRs each -- 1 824-row tiles, so that
+# the Reddit-shaped product of four slices is two rounds of workgroups instead of three.  Register map = lds_plan.hpp lds_code_regs(8):
+# v0 lane id (the compiler's), v1..v3 LDS bases, v4 lane * 16 (DMA and touch), v5 touch destination, x v6..v27, accumulators v28..v255;
+# the store stage borrows x registers (v8, v9 temporaries; v6, v7 epilogue factors)
+GEO_CODE8 = Geo(8, 228, 8, 1, regmap=("v1", "v2", "v4", "v1", "v8", "v9", "v3", "v4"), X0=6, ACC0=28, dummy=False)
+GEO_CODE8.pieces = 0   # (taken from the plan: LdsArgs.piece_bytes)
 
 
 def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
@@ -67,7 +75,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
     DNT = " nt" if ablate in (18, 19) else ""     # experiment: the chunk DMA bypasses the L1
     AB = {0: set(), 17: set(), 18: set(), 19: set(), 10: {5, 6, 7, 8}, 11: {5, 6, 7, 8, 4}, 12: {5, 6, 7, 8, 3}}.get(ablate, {ablate})
     KA, BATCH, NW, ACC0 = g.KA, g.BATCH, g.NW, g.ACC0
-    VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = (f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
+    VB, VM, VL16, VL4, VT0, VT1, VZ, VL128 = g.regmap or tuple(f"v{g.T0 + i}" for i in range(8))  # lane*4+buffer, mask, lane*16, lane*4, 2 tmp, zero, lane*128
     XS = [g.X0, g.X0 + BATCH]
     TOK = [g.TOK0 + i * BATCH for i in range(3)]
     WGT = [g.TOK0 + (3 + i) * BATCH for i in range(3)] if g.weighted else None
@@ -97,12 +105,13 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
 
     # ---- set-up
     a(f"v_lshlrev_b32 {VL4}, 2, %[lane]")
+    if VL128 != VL16:
+        a(f"v_lshlrev_b32 {VL128}, 7, %[lane]")
     a(f"v_lshlrev_b32 {VL16}, 4, %[lane]")
-    a(f"v_lshlrev_b32 {VL128}, 7, %[lane]")
     a(f"v_mov_b32 {VM}, 0x3ff00")
     a(f"v_lshlrev_b32 {VB}, 2, %[lane]")       # (the token carries the LDS row of both buffers: the lane offset is all that is added)
     a(f"v_mov_b32 {VZ}, 0")
-    for i in range(KA + 1):
+    for i in range(KA + (1 if g.dummy else 0)):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
     if code:
         # CODE-STREAM form (lds_plan.hpp lds_code_from_plan): the whole slot loop -- DMA of the chunks, the entries' LDS reads and
@@ -118,11 +127,13 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
         a("s_mov_b32 s82, %[ldsw]")
         a("s_mov_b64 s[84:85], %[code]")
         a("s_add_u32 s84, s84, 0x800")             # the stream touches its own lines 2 KiB ahead, 8 lines (1 KB) per touch:
-        a(f"v_and_b32 {VL128}, 7, %[lane]")        # lane offsets (lane % 8) * 128
-        a(f"v_lshlrev_b32 {VL128}, 7, {VL128}")
+        if VL128 != VL16:
+            a(f"v_and_b32 {VL128}, 7, %[lane]")    # lane offsets (lane % 8) * 128
+            a(f"v_lshlrev_b32 {VL128}, 7, {VL128}")  # (the 8-wave shell touches with lane * 16: the same 8 lines)
         a("s_addc_u32 s85, s85, 0")
         a("s_swappc_b64 s[86:87], %[code]")
         a("s_branch L_out_%=")                     # (the token loop below is not part of this form)
+    cut = len(L)
     a(f"s_mov_b64 {TP}, %[tok]")
     a(f"s_mov_b32 {NLEFT}, %[nch]")
     a(f"s_mov_b32 {BUF}, 0")
@@ -308,6 +319,8 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
     a(f"s_cmp_gt_u32 {NLEFT}, 0")
     a("s_cbranch_scc1 L_slot_%=")
     # ---- results: acc[k] -> C[rowmap[k]] (lanes beyond the slice's width masked off)
+    if code:
+        del L[cut - 1:]                            # (nothing between the stream's return and the store stage)
     a("L_out_%=:")
     a(f"s_mov_b64 {EX}, exec")
     a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
@@ -388,6 +401,13 @@ constexpr uint32_t lds_batch(uint32_t nw) { return nw == 16 ? %(B16)du : %(B8)du
 // ... and the 16-wave geometry for long slots (16-token batches, fewer accumulators)
 constexpr uint32_t LDS_L16_KA = %(KAL)du, LDS_L16_BATCH = %(BL)du;
 
+// the code-stream shells below and lds_plan.hpp's emitter agree on the register map
+static_assert(lds_code_regs(16).vbase[0] == 4 && lds_code_regs(16).vbase[1] == 5 && lds_code_regs(16).vbase[2] == 10 && lds_code_regs(16).vl16 == 6 &&
+              lds_code_regs(16).vtouch == 11 && lds_code_regs(16).vjunk == 9 && lds_code_regs(16).x0 == 12 && lds_code_regs(16).acc0 == 28, "16-wave code map");
+static_assert(lds_code_regs(8).vbase[0] == 1 && lds_code_regs(8).vbase[1] == 2 && lds_code_regs(8).vbase[2] == 3 && lds_code_regs(8).vl16 == 4 &&
+              lds_code_regs(8).vtouch == 4 && lds_code_regs(8).vjunk == 5 && lds_code_regs(8).x0 == 6 && lds_code_regs(8).acc0 == 28 &&
+              LDS_CODE8_KA == %(KAC8)d, "8-wave code map");
+
 struct LdsArgs {
     const uint32_t *tok;      // token streams (with the slot headers, lds_plan.hpp)
     const LdsTile *tiles;
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const uint64_t tok = (uint64_t)(a.tok + (uint64_t)t->tokstart[wave] * BATCH);
     const uint32_t cid0 = __builtin_amdgcn_readfirstlane(t->chunk0);
     const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * %(piece_expr)s);
-    const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * KA);
+    const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * ((KA + 7u) & ~7u));   // (LdsGeometry::ka_stride)
     const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
     const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * %(piece_expr)s);
@@ -455,14 +475,19 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
 """
 
 
+ABLATE = "--ablate" in sys.argv   # also emit the timing-experiment variants of round 3 (wrong results; make -C pygim_amd/csrc ablate)
+
+
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pygim_amd", "csrc", "lds_kernel_gen.hpp")
-    text = HEADER % dict(KA8=GEOS[8].KA, KA16=GEOS[16].KA, B8=GEOS[8].BATCH, B16=GEOS[16].BATCH, KAL=GEO_L16.KA, BL=GEO_L16.BATCH)
+    if "--out" in sys.argv:
+        out = sys.argv[sys.argv.index("--out") + 1]
+    text = HEADER % dict(KA8=GEOS[8].KA, KA16=GEOS[16].KA, B8=GEOS[8].BATCH, B16=GEOS[16].BATCH, KAL=GEO_L16.KA, BL=GEO_L16.BATCH, KAC8=GEO_CODE8.KA)
     variants = []
     for nw in (8, 16):
         variants.append((f"k_lds_spmm_f32_w{nw}", "v_add_f32", nw, 0, "FLT32, unit weights: sums in stored order, bit-identical to the CPU loop"))
         variants.append((f"k_lds_spmm_i32_w{nw}", "v_add_u32", nw, 0, "INT32, unit weights: two's-complement modular sums"))
-    for ab in (6, 7, 10, 11, 12, 15, 16, 17, 18, 19):
+    for ab in ((6, 7, 10, 11, 12, 15, 16, 17, 18, 19) if ABLATE else ()):
         variants.append((f"k_lds_spmm_f32_w16_ab{ab}", "v_add_f32", 16, ab, f"TIMING EXPERIMENT ONLY (wrong results): ablation {ab}, see the generator"))
     variants.append(("k_lds_spmm_f32_w16_val", "v_add_f32", 16, 0, "FLT32 with values: acc += val * x, product and sum rounded separately, stored order", "v_mul_f32"))
     variants.append(("k_lds_spmm_i32_w16_val", "v_add_u32", 16, 0, "INT32 with values: modular", "v_mul_lo_u32"))
@@ -481,13 +506,19 @@ def main():
         variants.append((f"k_lds_code_{base}" + ("_deq" if deq else ""), op, 16, 0,
                          "CODE-STREAM form: the slot loop is a straight-line instruction stream compiled from the schedule (1.5 instructions per stored entry)",
                          None, deq))
+    for base, op, deq in (("f32", "v_add_f32", None), ("i32", "v_add_u32", None), ("f32", "v_add_f32", "f32"), ("i32", "v_add_u32", "i32"),
+                          ("i16", "v_pk_add_u16", None)):
+        variants.append((f"k_lds_code8_{base}" + ("_deq" if deq else ""), op, "C8", 0,
+                         "CODE-STREAM form, 8 waves x 228 accumulators (2 waves per SIMD, 1 824-row tiles: fewer rounds of workgroups, less of X staged)",
+                         None, deq))
     for v in variants:
         name, op, nw, ab, doc = v[:5]
         op_mul = v[5] if len(v) > 5 else None
         deq = v[6] if len(v) > 6 else None
-        g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         if "_code" in name:
-            g = GEO_CODE
+            g = GEO_CODE8 if nw == "C8" else GEO_CODE
+        else:
+            g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         is_code = "_code" in name
         asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code))

@@ -88,7 +88,7 @@ static int emulate(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, 
                 }
                 if (plan.nb[t.nb_off + (size_t)t.nch * NW + w] != 0) return 6;  // closing row of zeros
                 for (uint32_t k = 0; k < KA; k++) {
-                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * KA + k];
+                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * geo.ka_stride() + k];
                     if (row == 0xFFFFFFFFu) continue;
                     if (row >= nrows) return 7;
                     if (s == 0) written[row]++;
@@ -137,7 +137,8 @@ extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *Cout,
-                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr, uint32_t col_splits = 1) {
+                    uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr, uint32_t col_splits = 1,
+                    uint32_t nw = 16, uint32_t gsize = 0, uint32_t nsets = 0, uint32_t rows_per_tile = 0) {
     const uint32_t nrows_real = nrows, S = col_splits ? col_splits : 1;
     std::vector<T> part;
     T *C = Cout;
@@ -147,9 +148,10 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     }
     LdsGeometry geo;
     geo.col_splits = S;
-    geo.NW = 16;
-    geo.KA = 96;
+    geo.NW = nw == 8 ? 8 : 16;          // round 4: 8 waves x 228 accumulators (2 waves per SIMD) beside 16 x 96
+    geo.KA = nw == 8 ? LDS_CODE8_KA : 96;
     geo.BATCH = 8;
+    geo.rows_per_tile = rows_per_tile;
     geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
     geo.NBUF = nbuf;
     LdsPlanHost plan;
@@ -159,8 +161,9 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
     LdsCodeHost ch;
-    lds_code_from_plan(plan, opcode, ch, threads);
-    const LdsCodeRegs R;
+    lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets);
+    const LdsCodeRegs R = ch.regs;
+    if (R.nx() > 32 || NBUF > 8) return 14;
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, chunk_bytes = KC * 256;
     const uint32_t nslices = (h + 63) / 64;
     if (stats) {
@@ -175,15 +178,22 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
         for (uint32_t s = 0; s < nslices; s++) {
             const uint32_t wvalid = std::min(64u, h - s * 64);
             // LDS as the 16 waves of the workgroup see it: which chunk each buffer holds (the DMA of all waves lands the same chunk)
+            uint64_t barriers_w0 = 0;
             for (uint32_t w = 0; w < NW; w++) {
                 std::vector<T> acc((size_t)KA * 64, T(0));
-                int64_t buf_chunk[4] = {-1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
-                int64_t landed_chunk[4] = {-1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
-                bool dirty[4] = {false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
+                int64_t buf_chunk[8] = {-1, -1, -1, -1, -1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
+                int64_t landed_chunk[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
+                bool dirty[8] = {false, false, false, false, false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
+                // a DMA may only go into a buffer that NOBODY reads any more: every wave issues the same DMAs between the same two
+                // barriers, so it is enough that this wave had no read of that buffer in flight at its last barrier and has issued
+                // none since
+                bool inflight_at_barrier[8] = {false, false, false, false, false, false, false, false};
+                bool read_since_barrier[8] = {false, false, false, false, false, false, false, false};
+                uint64_t barriers = 0;
                 struct VLoad { int buf; int64_t cid; bool last; };
                 std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)
-                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; };
-                XReg x[16];
+                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; int64_t chunk = -1; };
+                XReg x[32];
                 std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
                 uint64_t pc = ch.start[(size_t)ti * NW + w] / 4;
                 uint64_t pa = 0;                              // DMA source offset inside the slice (bytes), from the literal
@@ -198,6 +208,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if (i0 == 0xBF8A0000u) {                                                    // s_barrier: landed chunks become visible
                         for (uint32_t b = 0; b < NBUF; b++)
                             if (landed_chunk[b] >= 0) { buf_chunk[b] = landed_chunk[b]; landed_chunk[b] = -1; dirty[b] = false; }
+                        for (uint32_t b = 0; b < NBUF; b++) inflight_at_barrier[b] = read_since_barrier[b] = false;
+                        for (uint32_t r : fifo)
+                            for (int q = 0; q < 2; q++)
+                                if (r + q < 32 && x[r + q].inflight) inflight_at_barrier[x[r + q].ldsrow / KC] = true;
+                        barriers++;
                         pc++;
                         continue;
                     }
@@ -216,7 +231,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc++;
                         continue;
                     }
-                    if (i0 == (0xBE801D00u | R.s_ret)) { done = true; continue; }                // s_setpc_b64: back to the kernel
+                    if (i0 == (0xBE801D00u | R.s_ret)) {                                        // s_setpc_b64: back to the kernel
+                        if (!fifo.empty() || !vfifo.empty()) return 42;                         // (something still in flight)
+                        done = true;
+                        continue;
+                    }
                     if ((i0 & 0xFF00FFFFu) == (0x8000FF00u | R.s_xs) && ((i0 >> 16) & 0xFF) == R.s_pa) {   // s_add_u32 pa, xs, literal (chunk)
                         pa = ch.code[pc + 1];
                         if (pa % chunk_bytes) return 21;
@@ -242,6 +261,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if ((i0 & 0xFFFF8000u) == 0xDDF48000u) {                                    // global_load_lds_dwordx4 (one DMA piece)
                         if (ch.code[pc + 1] != ((R.s_pa << 16) | R.vl16) || (i0 & 0x1FFF) != (pieces_seen % 4) * 1024 || dma_buf < 0) return 24;
                         // the buffer being filled must not be one that is read before the fence: checked at the reads below
+                        if (inflight_at_barrier[dma_buf] || read_since_barrier[dma_buf]) return 36;   // somebody may still be reading it
                         dirty[dma_buf] = true;
                         buf_chunk[dma_buf] = -1;
                         ++pieces_seen;
@@ -249,13 +269,18 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc += 2;
                         continue;
                     }
-                    if ((i0 & 0xFFFF8000u) == 0xDC508000u) { vfifo.push_back({-1, -1, false}); pc += 2; continue; }   // global_load_dword (touch)
+                    if ((i0 & 0xFFFF8000u) == 0xDC508000u) {                                    // global_load_dword (touch)
+                        if (ch.code[pc + 1] != ((R.vjunk << 24) | (R.s_cb << 16) | R.vtouch)) return 37;
+                        vfifo.push_back({-1, -1, false});
+                        pc += 2;
+                        continue;
+                    }
                     if ((i0 & 0xFFFF0000u) == 0xD8700000u || (i0 & 0xFFFF0000u) == 0xD86C0000u) {   // ds_read2st64_b32 / ds_read_b32
                         const bool two = (i0 & 0xFFFF0000u) == 0xD8700000u;
                         const uint32_t i1 = ch.code[pc + 1], vdst = i1 >> 24, vaddr = i1 & 0xFF;
                         int blk = -1;
                         for (int b = 0; b < 3; b++) if (vaddr == R.vbase[b]) blk = b;
-                        if (blk < 0 || vdst < R.x0 || vdst + (two ? 1 : 0) >= R.x0 + 16 || (two && (vdst & 1))) return 25;
+                        if (blk < 0 || vdst < R.x0 || vdst + (two ? 1 : 0) >= R.x0 + R.nx() || (two && ((vdst - R.x0) & 1))) return 25;
                         const uint32_t rows[2] = {two ? (i0 & 0xFF) : ((i0 & 0xFFFF) >> 8), two ? ((i0 >> 8) & 0xFF) : 0};
                         if (!two && (i0 & 0xFF)) return 26;
                         for (int q = 0; q < (two ? 2 : 1); q++) {
@@ -267,6 +292,9 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             xr.ldsrow = blk * 256 + rows[q];
                             if (xr.ldsrow >= NBUF * KC) return 28;
                             if (dirty[xr.ldsrow / KC]) return 29;                               // reading a buffer whose DMA has not been fenced
+                            if (buf_chunk[xr.ldsrow / KC] < 0) return 38;                       // ... or one that holds nothing this wave may rely on
+                            xr.chunk = buf_chunk[xr.ldsrow / KC];                               // (the add may come after the buffer has been handed on)
+                            read_since_barrier[xr.ldsrow / KC] = true;
                         }
                         fifo.push_back(vdst - R.x0);   // (a pair retires as one LDS instruction: both registers with the first index)
                         if (two) x[vdst - R.x0 + 1].inflight = true;
@@ -275,7 +303,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     }
                     if (vals && (i0 & 0xFE0001FFu) == 0x0A0000FFu) {                            // v_mul_f32 x, <literal>, x (valued matrices)
                         const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF;
-                        if (vd != vs1 || vd < R.x0 || vd >= R.x0 + 16) return 33;
+                        if (vd != vs1 || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
                         XReg &xr = x[vd - R.x0];
                         bool infl = false;
                         for (uint32_t r : fifo) if (r == vd - R.x0 || (r + 1 == vd - R.x0 && x[r + 1].inflight && x[r].inflight)) infl = true;
@@ -288,14 +316,14 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     }
                     if ((i0 & 0xFE000000u) == opcode) {                                         // v_add acc[k], x, acc[k]
                         const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, src0 = i0 & 0x1FF;
-                        if (vd != vs1 || vd < R.acc0 || vd >= R.acc0 + KA || src0 < 256 + R.x0 || src0 >= 256 + R.x0 + 16) return 30;
+                        if (vd != vs1 || vd < R.acc0 || vd >= R.acc0 + KA || src0 < 256 + R.x0 || src0 >= 256 + R.x0 + R.nx()) return 30;
                         XReg &xr = x[src0 - 256 - R.x0];
                         // a pair's second register retires with the pair: find whether its instruction is still in the fifo
                         bool infl = false;
                         for (uint32_t r : fifo) if (r == src0 - 256 - R.x0 || (r + 1 == src0 - 256 - R.x0 && x[r + 1].inflight && x[r].inflight)) infl = true;
                         if (!xr.valid || infl) return 31;                                       // the read has not been waited for
                         xr.inflight = false;
-                        const int64_t chunk = buf_chunk[xr.ldsrow / KC];
+                        const int64_t chunk = xr.chunk;   // what the buffer held when the read was issued (and in flight: no DMA may touch it, 36)
                         if (chunk < 0) return 32;
                         const uint64_t xrow = (uint64_t)chunk * KC + xr.ldsrow % KC;
                         const uint32_t k = vd - R.acc0;
@@ -320,8 +348,10 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     }
                     return 40;   // an instruction the stream must not contain
                 }
+                if (w == 0) barriers_w0 = barriers;
+                else if (barriers != barriers_w0) return 43;   // the waves of a workgroup meet at the same barriers
                 for (uint32_t k = 0; k < KA; k++) {
-                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * KA + k];
+                    const uint32_t row = plan.rowmap[((size_t)ti * NW + w) * geo.ka_stride() + k];
                     if (row == 0xFFFFFFFFu) continue;
                     if (row >= nrows) return 7;
                     if (s == 0) written[row]++;
@@ -351,6 +381,17 @@ extern "C" {
 int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals, uint32_t col_splits) {
     return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits);
+}
+// ... with the geometry as arguments (round 4): waves per workgroup (16 x 96 or 8 x 228 accumulators), entries per group, x-register sets
+int lds_code_f32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals, uint32_t col_splits, uint32_t nw,
+                     uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits, nw, gsize, nsets, rows_per_tile);
+}
+int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,
+                     uint32_t nsets, uint32_t rows_per_tile) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits) {

@@ -48,8 +48,11 @@ def test_reddit_csr_f32_h256():
     x2 = synth.features(n, h, torch.float32, seed=5, device=dev)
     hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
     try:
-        info = _lib.group_info(hd)
-        assert info["n_panels"] >= 2 and info["n_long_rows"] > 0  # both the panel sweep and the long-row path run
+        # the product this workload takes: the LDS-staged schedule compiled into machine code (the sweep's plan is built beside it and
+        # serves accumulate-into-C calls of other widths)
+        assert _lib.group_lds_code(hd)["active"] == 1 and _lib.group_lds_plan(hd)["nnz"] == nnz
+        geo = _lib.group_lds_geometry(hd)
+        assert geo["waves"] * geo["acc_per_wave"] >= -(-n // _lib.group_lds_plan(hd)["tiles"]) and geo["chunk_cols"] * 256 * geo["buffers"] <= 163840, geo
         c1 = run(hd, x1, n, h)
         # checksum: sum_i C[i, :] = sum_j colcount[j] * X[j, :]   (small integers: exact in f64)
         colcount = torch.bincount(col.long(), minlength=n).double()
@@ -261,7 +264,7 @@ def test_reddit_lds_staged_product_is_the_cpu_loop_bit_for_bit(clustered):
             plan = _lib.group_lds_plan(hd)
             assert plan["tiles"] > 0 and plan["nnz"] == nnz, plan
             if clustered:
-                assert plan["chunk_fills"] * 5 < plan["tiles"] * ((n + 319) // 320)   # a tile streams only the chunks it touches
+                assert plan["chunk_fills"] * 5 < plan["tiles"] * -(-n // _lib.group_lds_geometry(hd)["chunk_cols"])   # a tile streams only the chunks it touches
             got = run(hd, xr, n, h).cpu().numpy()
             ref = np.zeros((n, h), dtype=np.float32)
             oracle.spmm_csr_rowpar(rp_h, col_h, None if v is None else v.cpu().numpy(), xr.cpu().numpy(),

@@ -35,6 +35,8 @@ def lds_forced():
     _lib.set_tunable("lds_long_slots", 128)
     _lib.set_tunable("lds_round_tiles", 1)
     _lib.set_tunable("lds_code", 1)
+    for k in ("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets"):
+        _lib.set_tunable(k, 0)
 
 
 def features(rng, n, h, dt):
@@ -379,3 +381,43 @@ def test_short_row_shares_split_their_tiles_into_column_ranges(rng, lds_forced, 
             assert tiles is None or pl["tiles"] == tiles
     finally:
         _lib.set_tunable("lds_code", old_code)
+
+
+# (waves, ring buffers, columns per chunk, staged columns per group, x-register sets) -- the knobs of the code-stream plan, round 4:
+# 8 waves x 228 accumulators (k_lds_code8_*), rings of 3 / 4 / 5 buffers with the barrier in the middle of a slot, deeper read pipelines
+CODE_GEOS = [(16, 2, 0, 0, 0), (16, 3, 0, 0, 0), (16, 3, 192, 6, 3), (8, 2, 0, 0, 0), (8, 3, 0, 0, 0), (8, 4, 0, 0, 0), (8, 4, 160, 6, 3),
+             (8, 5, 0, 0, 0), (8, 6, 0, 0, 0), (8, 3, 64, 2, 2), (16, 4, 128, 8, 2)]
+
+
+@pytest.mark.parametrize("geo", CODE_GEOS)
+def test_code_stream_geometries_are_bit_exact(rng, lds_forced, geo):
+    """tests/test_lds_plan.py runs these plans through the CPU interpreter; here the same plans run on the GPU (k_lds_code_* / k_lds_code8_*)
+    against the oracle's loop: FLT32 bit-identical (every row summed by one wave in stored order, whatever the geometry), INT32 modular,
+    INT16 two features to a lane, and the valued FLT32 form"""
+    for k, v in zip(("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets"), geo):
+        _lib.set_tunable(k, v)
+    for dt in (np.float32, np.int32):
+        for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),
+                                 (2000, 9000, 300, 25), (1500, 300, 64, 250), (6000, 6000, 128, 60)):
+            rowptr, col = random_csr(rng, n, ncols, avg, long_rows=[(0, 5000)] if n > 100 else ())
+            x = features(rng, ncols, h, dt)
+            got, plan = product(rowptr, col, x, want_plan=len(col) > 0)
+            assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (geo, dt, n, ncols, h)
+    # the geometry the library reports is the one that was asked for
+    rowptr, col = random_csr(rng, 3000, 4000, 30)
+    x = features(rng, 4000, 128, np.float32)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rp.ctypes.data], [ci.ctypes.data], None, [3000], [4000], [len(ci)], [1], [128], 128)
+    try:
+        g = _lib.group_lds_geometry(hd)
+        assert g["waves"] == geo[0] and g["buffers"] == geo[1] and g["acc_per_wave"] == (228 if geo[0] == 8 else 96), g
+        assert g["chunk_cols"] * 256 * g["buffers"] <= 163840 and g["chunk_cols"] % (4 * geo[0]) == 0
+        assert _lib.group_lds_code(hd)["active"] == 1
+    finally:
+        _lib.group_free(hd)
+    # valued FLT32: the value is the literal of a v_mul_f32 in front of the add
+    rowptr, col = random_csr(rng, 2500, 3000, 20, long_rows=[(5, 2800)])
+    x = features(rng, 3000, 96, np.float32)
+    vals = (rng.random(len(col), dtype=np.float32) * 2 - 1).astype(np.float32)
+    got, _ = product(rowptr, col, x, vals=vals)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), geo

@@ -126,7 +126,7 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
     for _ in range(400):
         nrows = int(rng.integers(1, 3_000_000))
         nsl = int(rng.integers(1, 9))
-        rmax = int(rng.choice([1536, 1280]))
+        rmax = int(rng.choice([1536, 1280, 1824]))
         assert emul.lds_emul_rows_per_tile(nrows, rmax, nsl, 256) == autotune.lds_rows_per_tile(nrows, nsl, rmax=rmax, cus=256), (nrows, nsl)
     assert emul.lds_emul_rows_per_tile(232965, 1536, 4, 256) == 1214      # Reddit h = 256: 192 tiles x 4 slices = 3 full rounds
     assert emul.lds_emul_rows_per_tile(232965, 1536, 2, 256) == 911       # h = 128: 256 tiles x 2 slices = 2 rounds
@@ -139,6 +139,8 @@ def test_tile_height_rule_matches_its_python_mirror(emul):
         base_rounds = -(-(152 * nsl) // 256)
         assert rpt <= 1536 and -(-(tiles * nsl) // 256) == base_rounds, (nsl, rpt, tiles)
     assert emul.lds_emul_rows_per_tile(232965, 1536, 3, 256) == 1371
+    assert emul.lds_emul_rows_per_tile(232965, 1824, 4, 256) == 1821      # round 4, 8 waves x 228 rows: 128 tiles x 4 slices = 2 full rounds
+    assert emul.lds_emul_rows_per_tile(232965, 1824, 2, 256) == 1821      # h = 128: one round
 
 
 def _run_code(emul, rowptr, col, ncols, x, threads=4, kc=320, nbuf=2, vals=None, splits=1):
@@ -221,3 +223,60 @@ def test_column_split_tiles(emul, splits):
             ref = part if ref is None else (ref + part).astype(np.float32)
         got, _ = _run_code(emul, rowptr, col, ncols, xf, kc=kc, nbuf=2 if kc == 320 else 3, splits=splits)
         assert got.tobytes() == ref.tobytes(), kc
+
+
+def _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize=0, nsets=0, rows_per_tile=0, threads=4, vals=None, splits=1):
+    nrows = len(rowptr) - 1
+    h = x.shape[1]
+    out = np.full((nrows, h), 77, dtype=x.dtype)
+    stats = (ctypes.c_uint64 * 4)()
+    fn = emul.lds_code_f32_geo if x.dtype == np.float32 else emul.lds_code_i32_geo
+    rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
+    xx = np.ascontiguousarray(x)
+    rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
+            out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf,
+            *(() if x.dtype != np.float32 else (None if vals is None else np.ascontiguousarray(vals, np.float32).ctypes.data_as(ctypes.c_void_p),)),
+            splits, nw, gsize, nsets, rows_per_tile)
+    assert rc == 0, f"the interpreter rejected the code stream (code {rc}) for nw={nw} kc={kc} nbuf={nbuf} g={gsize} ns={nsets}"
+    return out, list(stats)
+
+
+# (waves, columns per chunk, ring buffers, entries per group, x-register sets): round 3's two rings with the pipeline that now crosses
+# slot boundaries; the 8-wave geometry (228 accumulators per wave, 2 waves per SIMD) with two- and mid-slot-barrier rings
+CODE_GEOS = [(16, 320, 2, 8, 2), (16, 192, 3, 8, 2), (16, 192, 3, 6, 3), (8, 320, 2, 10, 2), (8, 192, 3, 10, 2), (8, 160, 4, 10, 2),
+             (8, 160, 4, 6, 3), (8, 128, 5, 6, 3), (8, 192, 3, 2, 2)]
+
+
+@pytest.mark.parametrize("geo", CODE_GEOS)
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_code_stream_geometries(emul, geo, dtype):
+    """every geometry of the code-stream kernels through the interpreter: bit-exact against the oracle's loop, every hazard rule of the
+    LDS ring kept (no read of a buffer whose DMA is not fenced, no DMA into a buffer somebody may still read, the same barriers in
+    every wave of a workgroup, nothing in flight at the return)"""
+    nw, kc, nbuf, gsize, nsets = geo
+    rng = np.random.default_rng(nw * 1000 + kc + nbuf)
+    for nrows, ncols, h, deg, rpt in ((1, 1, 3, 1, 0), (700, 900, 64, 9, 0), (2500, 2100, 100, 40, 0), (2000, 5000, 130, 25, 333), (400, 3000, 64, 300, 0)):
+        rowptr, col = random_csr(rng, nrows, ncols, avg_deg=deg, empty_frac=0.1, long_rows=[(0, min(3000, 2 * ncols))] if nrows > 100 else ())
+        if dtype == np.float32:
+            x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+        else:
+            x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+        want = oracle.spmm_csr(rowptr, col, None, x)
+        got, stats = _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize, nsets, rows_per_tile=rpt)
+        assert got.tobytes() == want.tobytes(), (geo, nrows)
+        assert stats[2] == len(col)
+
+
+@pytest.mark.parametrize("geo", [(8, 160, 4, 10, 2), (8, 192, 3, 6, 3), (16, 192, 3, 8, 2)])
+def test_code_stream_geometries_valued_and_split(emul, geo):
+    nw, kc, nbuf, gsize, nsets = geo
+    rng = np.random.default_rng(77)
+    nrows, ncols, h = 1500, 2600, 96
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=30, long_rows=[(3, 2500)])
+    x = (rng.random((ncols, h), dtype=np.float32) * 2 - 1).astype(np.float32)
+    vals = (rng.random(len(col), dtype=np.float32) * 2 - 1).astype(np.float32)
+    got, _ = _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize, nsets, vals=vals)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
+    xi = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+    got, _ = _run_code_geo(emul, rowptr, col, ncols, xi, nw, kc, nbuf, gsize, nsets, splits=3)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xi).tobytes()
