@@ -216,6 +216,10 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]);
  * staged columns per group of reads and x-register sets of a code stream (0 0 for a token plan), stored entries served by another
  * entry's LDS read (code streams: entries of different rows of one wave that share a column of a chunk), column ranges per row tile */
 int pygim_group_lds_geometry(int64_t handle, int64_t out[8]);
+/* which form of the product the group got at creation and, when it is not the fastest one, why (text, NUL-terminated, at most cap - 1
+ * characters): "code-stream form" | "code-stream form not available: <reason>; products take the token form ..." | "... the L2 sweep
+ * serves this group".  The ladder is code stream -> token kernels -> sweep; nothing falls back silently. */
+int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
  * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",

@@ -18,7 +18,7 @@ EXPORTS = [
     "pygim_group_info", "pygim_set_tunable", "pygim_group_kernel_ms", "pygim_quant_spmm_run",
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
-    "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry",
+    "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry", "pygim_group_lds_note",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -72,6 +72,7 @@ def lib():
         L.pygim_group_lds_plan.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_code.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_geometry.argtypes = [c_i64, p_i64]
+        L.pygim_group_lds_note.argtypes = [c_i64, ctypes.c_char_p, c_i64]
         L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
@@ -207,6 +208,13 @@ def group_lds_geometry(handle):
     out = (ctypes.c_int64 * 8)()
     check(lib().pygim_group_lds_geometry(int(handle), out))
     return dict(zip(["waves", "acc_per_wave", "chunk_cols", "buffers", "group", "x_sets", "shared_entries", "col_splits"], [int(v) for v in out]))
+
+
+def group_lds_note(handle):
+    """which form of the product the group got (code stream / token kernels / sweep) and why"""
+    buf = ctypes.create_string_buffer(1024)
+    check(lib().pygim_group_lds_note(int(handle), buf, 1024))
+    return buf.value.decode()
 
 
 def generation():

@@ -26,19 +26,17 @@ RATE_STREAM = 5.0e12        # streaming reads/writes (index arrays, C)
 XGMI_IN = 7 * 45e9          # inbound bytes/s per GPU, 7 links (spec 7 x ~64 GB/s per direction; 70 % assumed)
 PANEL_BYTES = 4 << 20
 LAUNCH = 6e-6               # per kernel launch incl. ramp, back to back
-# LDS-staged product (k_lds_spmm, round 3; profiles/r03_lds_kernel.md): one 1024-thread workgroup per CU and (row tile, 64-feature slice)
+# LDS-staged product, code-stream form (k_lds_code8_*, round 4; profiles/r04_lds_kernel.md): one 512-thread workgroup per CU and
+# (row tile, 64-feature slice), 8 waves x 228 accumulators, X streamed through a ring of 5 x 128 columns
 CUS = 256
-LDS_CLOCK = 2.3e9           # Hz held under this kernel (GRBM_GUI_ACTIVE / 8 / time)
-LDS_ROWS_MAX = 16 * 96      # rows of a tile (waves x accumulators per wave)
-LDS_CYC_PER_TOKEN = 2.9     # CU cycles per stored entry and slice in the code-stream form (k_lds_code_*; clustered columns: nothing else in the way; the token kernels: 3.9)
-LDS_KC = 320                # columns of a chunk, products of three or more slices: 2 x 80 KiB ring (lds_plan.hpp, pygim_hip.hip build_lds_plan)
-LDS_KC3 = 192               # ... of one or two slices: 3 x 48 KiB ring, two chunks in flight
-LDS_CYC_PER_SLOT = 1030     # CU cycles per chunk of X beside the entries (barrier, DMA issue; fitted to h = 256 uniform)
-LDS_CYC_FILL = 3300         # CU cycles to land an 80 KiB chunk with every CU streaming (~56 GB/s per CU: the L2's gather ceiling shared by 256): a slot cannot be shorter
-LDS_CYC_FILL3 = 1750        # ... a 48 KiB chunk of the three-buffer ring
-LDS_PAD = 1.0               # the code stream has no padding entries (the token kernels: 1.07-1.085)
+LDS_ROWS_MAX = 8 * 228      # rows of a tile (waves x accumulators per wave)
+# fitted to row shares 1/1 ... 1/16 of the Reddit-shaped graph at h = 64 / 128 / 256 (profiles/r04_exp_share.txt): a workgroup takes
+#   columns it streams x 3.43 ns  (a 256-byte row of X through LDS-DMA with ~96 KiB in flight: ~75 GB/s per CU)
+# + stored entries x 0.26 ns      (what the entries add on top: LDS reads beside the DMA's writes)
+LDS_NS_PER_COLUMN = 3.43
+LDS_NS_PER_ENTRY = 0.26
 LDS_COL_SPLIT = False       # True when the caller lets FLT32 shares be split into column ranges (tunable lds_col_split_f32; bench.py at N > 1)
-LDS_MIN_REUSE = 1.1         # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
+LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
 @dataclass
@@ -72,27 +70,23 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
     if es != 4 or h < 33 or nrows == 0 or nnz == 0:
         return None
     nsl = -(-h // 64)
-    three = nsl <= 2
+    pack_s = ncols * h * es * 2 / RATE_STREAM
     # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
     tall = -(-int(nrows) // LDS_ROWS_MAX)
     if LDS_COL_SPLIT and tall * nsl * 2 <= CUS:
         split = min(8, CUS // (tall * nsl))
         if nnz / (tall * ncols) < LDS_MIN_REUSE:
             return None
-        slots = -(-int(ncols) // (LDS_KC3 if three else LDS_KC)) / split
-        per_slot = LDS_CYC_PER_SLOT * (0.6 if three else 1.0)
-        per_wg = max(nnz * LDS_PAD / tall / split * LDS_CYC_PER_TOKEN + slots * per_slot, slots * (LDS_CYC_FILL3 if three else LDS_CYC_FILL))
+        per_wg = (ncols / split * LDS_NS_PER_COLUMN + nnz / tall / split * LDS_NS_PER_ENTRY) * 1e-9
         reduce_s = (split + 1) * nrows * h * es / RATE_STREAM
-        return per_wg / LDS_CLOCK + reduce_s + ncols * h * es * 2 / RATE_STREAM + 2 * LAUNCH
+        return per_wg + reduce_s + pack_s + 2 * LAUNCH
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    slots = -(-int(ncols) // (LDS_KC3 if three else LDS_KC))
-    per_slot = LDS_CYC_PER_SLOT * (0.6 if three else 1.0)
-    per_wg = max(nnz * LDS_PAD / tiles * LDS_CYC_PER_TOKEN + slots * per_slot, slots * (LDS_CYC_FILL3 if three else LDS_CYC_FILL))
+    per_wg = (ncols * LDS_NS_PER_COLUMN + nnz / tiles * LDS_NS_PER_ENTRY) * 1e-9
     rounds = -(-tiles * nsl // CUS)
-    return rounds * per_wg / LDS_CLOCK + ncols * h * es * 2 / RATE_STREAM + LAUNCH
+    return rounds * per_wg + pack_s + LAUNCH
 
 
 def product_seconds(nrows, ncols, nnz, h, es):

@@ -77,8 +77,37 @@ struct LdsPlanHost {
     std::vector<uint32_t> wts;       // valued matrices: the entries' 4-byte values (raw bits) in token order, 0 for padding; else empty
     std::vector<uint32_t> nb, chunks, rowmap;
     std::vector<LdsTile> tiles;      // heaviest tile first (workgroups are dispatched in index order)
-    bool header_overflow = false;    // a batch count or chunk id does not fit a 16-bit header field: the plan cannot be used
+    std::atomic<bool> header_overflow{false};   // (set by any worker) a batch count or chunk id does not fit a 16-bit header field: the plan cannot be used
 };
+
+// runs fn(i) for i in [0, n) on `threads` threads; an exception in a worker is carried to the caller (a std::thread body that
+// throws would end the process)
+template <typename F> inline void lds_parallel_for(uint32_t n, unsigned threads, F &&fn) {
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = std::min<unsigned>(threads, std::max(1u, n));
+    std::atomic<uint32_t> next(0);
+    std::atomic<bool> failed(false);
+    auto body = [&]() {
+        try {
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n || failed.load(std::memory_order_relaxed)) return;
+                fn(i);
+            }
+        } catch (...) {
+            failed.store(true);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
+    } catch (...) {
+        // (no more threads: the ones that started, and this one, do the work)
+    }
+    body();
+    for (auto &th : pool) th.join();
+    if (failed.load()) throw std::runtime_error("lds plan: a worker failed (out of memory?)");
+}
 
 // rowptr / col: CSR with sorted column ids inside every row (checked by the caller).
 // threads = 0: std::thread::hardware_concurrency().
@@ -96,8 +125,6 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     out.nchunks = nchunks;
     out.tiles.assign(ntiles, LdsTile());
     out.rowmap.assign((size_t)ntiles * RS, 0xFFFFFFFFu);
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-    threads = std::min<unsigned>(threads, std::max(1u, ntiles));
 
     // per tile: the (wave, k) of every row, the chunk list, per (slot, wave) token counts
     struct TileTmp {
@@ -108,20 +135,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         uint64_t batches[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     };
     std::vector<TileTmp> tmp(ntiles);
-    auto run = [&](auto &&fn) {
-        std::atomic<uint32_t> next(0);
-        std::vector<std::thread> pool;
-        auto body = [&]() {
-            for (;;) {
-                const uint32_t t = next.fetch_add(1);
-                if (t >= ntiles) return;
-                fn(t);
-            }
-        };
-        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
-        body();
-        for (auto &th : pool) th.join();
-    };
+    auto run = [&](auto &&fn) { lds_parallel_for(ntiles, threads, fn); };   // (a worker's exception is carried to the caller)
     run([&](uint32_t t) {
         TileTmp &tt = tmp[t];
         const uint32_t rt = t / S, cs = t % S;
@@ -354,35 +368,6 @@ struct LdsCodeHost {
     uint64_t shared = 0;                 // entries served by the read of an earlier entry of the same column (no read of their own)
     LdsCodeRegs regs;                    // the register map the code was written for
 };
-
-// runs fn(i) for i in [0, n) on `threads` threads; an exception in a worker is carried to the caller (a std::thread body that
-// throws would end the process)
-template <typename F> inline void lds_parallel_for(uint32_t n, unsigned threads, F &&fn) {
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-    threads = std::min<unsigned>(threads, std::max(1u, n));
-    std::atomic<uint32_t> next(0);
-    std::atomic<bool> failed(false);
-    auto body = [&]() {
-        try {
-            for (;;) {
-                const uint32_t i = next.fetch_add(1);
-                if (i >= n || failed.load(std::memory_order_relaxed)) return;
-                fn(i);
-            }
-        } catch (...) {
-            failed.store(true);
-        }
-    };
-    std::vector<std::thread> pool;
-    try {
-        for (unsigned i = 1; i < threads; i++) pool.emplace_back(body);
-    } catch (...) {
-        // (no more threads: the ones that started, and this one, do the work)
-    }
-    body();
-    for (auto &th : pool) th.join();
-    if (failed.load()) throw std::runtime_error("lds plan: a worker failed (out of memory?)");
-}
 
 // opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000), or LDS_CODE_PK_ADD_U16 for
 // INT16 (two features to a lane: v_pk_add_u16, a VOP3P instruction of 8 bytes)

@@ -92,7 +92,7 @@ struct Tunables {
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
     int64_t lds_mode = 0;               // LDS-staged product (k_lds_spmm): 0 = auto (reuse rule), 1 = whenever a part has the plan, 2 = never
-    int64_t lds_min_reuse_x100 = 110;   // auto: least stored entries per staged column of X (x 100) for the LDS-staged product (measured crossing: profiles/r03_exp_lds_share.txt)
+    int64_t lds_min_reuse_x100 = 75;    // auto: least stored entries per staged column of X (x 100) for the LDS-staged product (measured crossing: between 0.48 and 0.96, profiles/r04_exp_share.txt; round 3's kernel: 1.1)
     int64_t lds_min_width = 33;         // narrower products keep the sweep (a 64-feature slice would be mostly padding)
     int64_t lds_threads = 0;            // host threads of the schedule builder (0 = all)
     int64_t lds_waves = 16;             // waves per workgroup of the LDS-staged kernel the plan is made for (8 or 16)
@@ -106,6 +106,7 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_fail = 0;               // (tests) force a step of the code-stream set-up to fail: 1 = code generation, 2 = executable memory, 4 = schedule build
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
 
@@ -158,6 +159,7 @@ struct Part {
     uint32_t lds_kc = 0, lds_nbuf = 0;     // the plan's ring: columns per chunk, buffers
     uint32_t lds_code_gsize = 0, lds_code_nsets = 0;
     uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
+    std::string lds_note;                  // which form of the product this part got, and why not a faster one
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
@@ -397,33 +399,44 @@ static ExecPool *exec_pool_locked(int dev) {
     ep.ok = true;
     return &ep;
 }
-static void *exec_alloc_upload(const void *host, size_t bytes) {
+static void *exec_alloc_upload(const void *host, size_t bytes, std::string *why = nullptr) {
+    auto say = [&](const char *m) { if (why) *why = m; };
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) { say("no current HIP device"); return nullptr; }
     ExecPool *ep;
     {
         std::lock_guard<std::mutex> lk(g_ctx.mu);
         ep = exec_pool_locked(dev);
     }
-    if (!ep) return nullptr;
-    // the code goes up through HIP (a staging buffer and a copy kernel: the executable allocation is a device address like any
+    if (!ep) { say("the HSA runtime offers no executable device memory pool"); return nullptr; }
+    // the code goes up through HIP (a bounded staging buffer and a copy kernel: the executable allocation is a device address like any
     // other inside a kernel); the HSA runtime is asked for the memory only
     void *ptr = nullptr, *stage = nullptr;
-    if (hipMalloc(&stage, bytes) != hipSuccess) {
+    const size_t piece = std::min<size_t>(bytes, (size_t)64 << 20);   // 64 MiB at a time: no second full-size allocation beside the code
+    if (hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) {
+        say("the executable pool could not allocate the code");
+        return nullptr;
+    }
+    if (hipMalloc(&stage, std::max<size_t>(piece, 256)) != hipSuccess) {
         (void)hipGetLastError();
+        (void)hsa_amd_memory_pool_free(ptr);
+        say("out of device memory for the staging buffer of the code upload");
         return nullptr;
     }
-    if (hipMemcpy(stage, host, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) {
-        (void)hipFree(stage);
-        return nullptr;
+    bool ok = true;
+    for (size_t off = 0; off < bytes && ok; off += piece) {
+        const size_t nb = std::min(piece, bytes - off);
+        ok = hipMemcpy(stage, (const char *)host + off, nb, hipMemcpyHostToDevice) == hipSuccess;
+        const uint64_t n16 = nb / 16;   // (the code blob is a multiple of 256 bytes)
+        if (ok && n16) {
+            hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (const u32x4_t *)stage, (u32x4_t *)((char *)ptr + off), n16);
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;   // (the staging buffer is re-used)
+        }
     }
-    const uint64_t n16 = bytes / 16;   // (the code blob is a multiple of 256 bytes)
-    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (const u32x4_t *)stage, (u32x4_t *)ptr, n16);
-    const bool ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     (void)hipFree(stage);
     if (!ok) {
         (void)hsa_amd_memory_pool_free(ptr);
+        say("copying the code to the device failed");
         return nullptr;
     }
     return ptr;
@@ -1321,7 +1334,26 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
 
 // One-time: the schedule of the LDS-staged product (lds_plan.hpp) for parts it pays for.  Built on the host from
 // the row pointers and column ids (the reference balances its DPU row ranges on the host too, spmm_mul_csr.c:118-259).
+// The ladder: the code-stream form; if its generation or its executable memory fails, the SAME product as a token
+// plan (k_lds_spmm_*: the schedule as data, ~20 % slower) -- not the L2 sweep (2-3 x slower); if the schedule itself cannot be built
+// (host memory), the sweep.  Whatever happened is kept as text with the part (pygim_group_lds_note).
+static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint,
+                               bool allow_code);
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint) {
+    p.lds_note.clear();
+    int rc = build_lds_plan_form(p, es, d_flag_sorted, st, h_rowptr, h_hint, true);
+    if (rc == -1) {
+        const std::string why = p.lds_note;
+        rc = build_lds_plan_form(p, es, d_flag_sorted, st, h_rowptr, h_hint, false);
+        p.lds_note = why + (p.lds_tiles ? "; products take the token form of the LDS-staged kernel (k_lds_spmm_*)" : "; no token plan either: the L2 sweep serves this group");
+    }
+    if (p.lds_note.empty())
+        p.lds_note = p.lds_tiles ? (p.lds_is_code ? "code-stream form" : "token form of the LDS-staged kernel") : "no LDS-staged plan (rule, type or width): the L2 sweep serves this group";
+    return rc;
+}
+
+static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint,
+                               bool allow_code) {
     if (g_tune.lds_mode == 2 || (es != 4 && es != 2) || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
     if ((p.vals || es == 2) && g_tune.lds_waves != 16) return 0;  // the valued and the INT16 kernels exist for the 16-wave geometry
     if (h_hint > 0 && (h_hint * (int64_t)es) / 4 < g_tune.lds_min_width) return 0;   // no product of this group is wide enough (want_lds): no plan, no code
@@ -1334,7 +1366,7 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
     // FLT32 / INT32 with unit weights: the code-stream form (the schedule compiled into machine code); its plan is built in the
     // geometry of its kernels and serves no token kernel
     // (valued matrices: FLT32 only -- the value is the literal of a v_mul_f32 in the stream; the integer multiplies have no literal form)
-    const bool want_code = g_tune.lds_code && geo.NW == 16 &&
+    const bool want_code = allow_code && g_tune.lds_code && geo.NW == 16 &&
                            ((es == 4 && t_plan_dtype == PYGIM_FLT32) || (!p.vals && es == 4 && t_plan_dtype == PYGIM_INT32) ||
                             (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16));
     const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + 255) / 256 : 4;
@@ -1407,8 +1439,14 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         geo.NBUF = (uint32_t)nbuf;
     }
     LdsPlanHost plan;
-    lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
-                   p.vals ? h_val.data() : nullptr);
+    try {
+        if (g_tune.lds_fail & 4) throw std::runtime_error("lds_fail: forced failure of the schedule build");
+        lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
+                       p.vals ? h_val.data() : nullptr);
+    } catch (const std::exception &e) {   // host memory, threads: no LDS-staged plan, the sweep serves the group
+        p.lds_note = std::string("the schedule of the LDS-staged product could not be built (") + e.what() + "): the L2 sweep serves this group";
+        return 0;
+    }
     // long slots (a community-structured graph: a tile streams few chunks, a wave gets hundreds of tokens per chunk): the per-batch
     // bookkeeping is what is left to save -- the 16-token-batch geometry, when the tiles fit its 80 accumulators per wave
     if (geo.NW == 16 && !p.vals && !want_code && g_tune.lds_long_slots && plan.slots > 0 &&
@@ -1421,8 +1459,13 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
                                : 0;
         const uint32_t r_now = geo.rows_per_tile ? geo.rows_per_tile : geo.NW * geo.KA, r_new = gl.rows_per_tile ? gl.rows_per_tile : gl.NW * gl.KA;
         if (r_new >= r_now) {  // no more tiles than before
-            lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, gl, plan,
-                           (unsigned)std::max<int64_t>(0, g_tune.lds_threads), nullptr);
+            try {
+                lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, gl, plan,
+                               (unsigned)std::max<int64_t>(0, g_tune.lds_threads), nullptr);
+            } catch (const std::exception &e) {
+                p.lds_note = std::string("the schedule of the LDS-staged product could not be built (") + e.what() + "): the L2 sweep serves this group";
+                return 0;
+            }
             geo = gl;
         }
     }
@@ -1441,21 +1484,31 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         if (hipMalloc((void **)dst, bytes) != hipSuccess) return false;
         return v.empty() || hipMemcpy(*dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (plan.header_overflow) return 0;  // a slot header field would not fit its 14 bits (a wave with > 16 383 batches in one chunk, > 5 M columns)
+    if (plan.header_overflow) {  // a slot header field would not fit its 14 bits (a wave with > 16 383 batches in one chunk, > 5 M columns)
+        p.lds_note = "the LDS-staged schedule does not fit its slot headers (more than 16 383 batches of one wave in one chunk, or more than 5 M columns): the L2 sweep serves this group";
+        return 0;
+    }
     if (want_code) {
         // the schedule as machine code (1.5 instructions per stored entry instead of 4 + bookkeeping) in EXECUTABLE memory; the token
         // stream itself stays on the host (the kernel needs the tile table and the row map only)
         LdsCodeHost ch;
         try {
+            if (g_tune.lds_fail & 1) throw std::runtime_error("lds_fail: forced failure of the code generation");
             lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : (t_plan_dtype == PYGIM_INT32 ? 0x68000000u : LDS_CODE_PK_ADD_U16), ch,
                                (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
                                (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets));
-        } catch (const std::exception &) {
-            return 0;   // (out of host memory or threads: the sweep serves the group)
+        } catch (const std::exception &e) {   // out of host memory or threads: the same schedule as a token plan (build_lds_plan)
+            p.lds_note = std::string("code-stream form not available: generating the instruction streams failed (") + e.what() + ")";
+            return -1;
         }
         std::vector<uint32_t>().swap(plan.tok);
-        void *code = exec_alloc_upload(ch.code.data(), ch.code.size() * 4);
-        if (!code) return 0;             // (no executable pool on this runtime: the sweep serves the group)
+        std::string why_exec;
+        void *code = (g_tune.lds_fail & 2) ? nullptr : exec_alloc_upload(ch.code.data(), ch.code.size() * 4, &why_exec);
+        if (!code) {                     // no executable pool on this runtime, or out of device memory: the token plan
+            p.lds_note = "code-stream form not available: " + (why_exec.empty() ? std::string("lds_fail: forced failure of the executable allocation") : why_exec) +
+                         " (" + std::to_string(ch.code.size() * 4) + " bytes of code)";
+            return -1;
+        }
         if (!up(&p.lds_code_start, ch.start) || !up(&p.lds_rowmap, plan.rowmap) || !up(&p.lds_tiles, plan.tiles)) {
             (void)hsa_amd_memory_pool_free(code);
             return fail(PYGIM_ERR_HIP, "code-stream plan upload");
@@ -2193,6 +2246,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code") slot = &g_tune.lds_code;
     else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
     else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
+    else if (n == "lds_fail") slot = &g_tune.lds_fail;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
@@ -2536,6 +2590,17 @@ int pygim_group_lds_geometry(int64_t handle, int64_t out[8]) {
     out[5] = p.lds_is_code ? p.lds_code_nsets : 0;
     out[6] = p.lds_is_code ? (int64_t)p.lds_code_shared : 0;
     out[7] = p.lds_col_splits;
+    return 0;
+}
+
+int pygim_group_lds_note(int64_t handle, char *out, int64_t cap) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    if (!out || cap <= 0) return fail(PYGIM_ERR_INVALID, "no buffer");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    const size_t n = std::min<size_t>(p.lds_note.size(), (size_t)cap - 1);
+    std::memcpy(out, p.lds_note.data(), n);
+    out[n] = 0;
     return 0;
 }
 

@@ -1,8 +1,26 @@
-cd $GRAFT_REPO_ROOT
-PYGIM_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/bench_n2_gloo.json 2> gpurun_out/bench_n2_gloo.err; echo rc=$?
-tail -c 1500 gpurun_out/bench_n2_gloo.json; tail -5 gpurun_out/bench_n2_gloo.err
-# (four ranks on ONE GPU: the small shape -- four processes each building the 115 M-entry graph with torch on one device did not finish
-# the graph construction in 5 minutes on the round-3 boxes, before any library call; a rank's watchdog, PYGIM_RANK_TIMEOUT, now says where it waits)
-PYGIM_BENCH_BACKEND=gloo PYGIM_RANK_TIMEOUT=600 timeout 900 python bench.py --gpus 4 --steps 3 --warmup 1 --shape products-mini --partition pipelined-feature > gpurun_out/bench_n4_gloo.json 2> gpurun_out/bench_n4_gloo.err; echo rc=$?
-tail -c 800 gpurun_out/bench_n4_gloo.json
-timeout 600 python bench.py --clustered --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_clustered.json 2>/dev/null; tail -c 600 gpurun_out/bench_clustered.json
+#!/bin/bash
+# N > 1 logic checks of bench.py on ONE GPU (gloo between processes that share the device): never a measurement.
+# usage: scripts/check_multirank.sh [ranks] [shape]     (default: 8 ranks, the full Reddit shape, every --partition choice)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+R=${1:-8}
+SHAPE=${2:-reddit}
+mkdir -p gpurun_out/multirank
+for part in auto row feature pipelined pipelined-feature; do
+  t0=$(date +%s)
+  PYGIM_BENCH_BACKEND=gloo PYGIM_RANK_TIMEOUT=1500 PYGIM_COLLECTIVE_TIMEOUT=1200 timeout 1700 python bench.py --gpus $R --steps 3 --warmup 1 --shape $SHAPE --partition $part \
+      > gpurun_out/multirank/n${R}_${part}.json 2> gpurun_out/multirank/n${R}_${part}.err
+  rc=$?
+  echo "ranks=$R shape=$SHAPE partition=$part rc=$rc seconds=$(( $(date +%s) - t0 ))"
+  python3 - "$R" "$part" <<'PY'
+import json, sys
+r, part = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads([l for l in open(f"gpurun_out/multirank/n{r}_{part}.json") if l.startswith("{")][0])
+    fam = sorted({g["kernel"] + (f" S={g['col_splits']}" if g["col_splits"] > 1 else "") for pr in d["config"]["per_rank"] for g in pr["groups"]})
+    print(f"   n_gpus {d['n_gpus']}  candidate {d['config']['candidate']}  ms/step {d['ms_per_step']}  check: {d['check'][:90]}")
+    print(f"   kernels {fam}  create ms per rank {[pr['group_create_ms'] for pr in d['config']['per_rank']]}  threads {d['config']['per_rank'][0]['plan_threads']}")
+except Exception as e:
+    print("   no JSON line:", e)
+PY
+  grep -h "\[bench\] rank" gpurun_out/multirank/n${R}_${part}.err | cut -c1-260 | head -8
+done

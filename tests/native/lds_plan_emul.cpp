@@ -203,6 +203,12 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 bool done = false;
                 for (uint64_t guard = 0; !done; guard++) {
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
+                    // vmcnt is a 6-bit counter: a wave has at most 63 vector loads in flight (the next one is not issued before the oldest
+                    // has returned), so whatever lies more than 63 loads back HAS landed -- s_waitcnt vmcnt(63) is the no-op it encodes as
+                    while (vfifo.size() > 63) {
+                        if (vfifo.front().last) landed_chunk[vfifo.front().buf] = vfifo.front().cid;
+                        vfifo.erase(vfifo.begin());
+                    }
                     const uint32_t i0 = ch.code[pc];
                     if (i0 == 0xBF800000u) { pc++; continue; }                                  // s_nop 0
                     if (i0 == 0xBF8A0000u) {                                                    // s_barrier: landed chunks become visible

@@ -155,3 +155,28 @@ def test_bench_launches_its_own_ranks_as_a_plain_command():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["check"].startswith("column-count checksum")
     bad = subprocess.run(cmd + ["--shape", "no-such-shape"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_a_rank_that_fails_in_set_up_ends_every_rank_promptly():
+    """no rank may sit in a fence while another has raised.  One rank is made to fail while it sets its
+    partition up (PYGIM_BENCH_FAIL_RANK); every candidate's set-up ends in a status word that all ranks reduce, so the launch exits
+    non-zero within seconds -- not at the collective time-out, not at the watchdog -- and prints no JSON line.  Every rank also
+    reports what it built (kernel family, creation time, threads) before the timed region."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYGIM_BENCH_BACKEND="gloo", PYGIM_RANK_TIMEOUT="600", PYGIM_COLLECTIVE_TIMEOUT="300")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--shape", "products-mini"]
+    for part in ("auto", "row", "pipelined"):
+        t0 = time.time()
+        bad = subprocess.run(cmd + ["--partition", part], capture_output=True, text=True, timeout=900, env={**env, "PYGIM_BENCH_FAIL_RANK": "1"}, cwd=ROOT)
+        took = time.time() - t0
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")], (part, bad.stdout[-500:])
+        assert "forced set-up failure" in bad.stderr and "no candidate could be set up on every rank" in bad.stderr, bad.stderr[-3000:]
+        assert took < 240, f"--partition {part}: the failing launch took {took:.0f} s (hung until a time-out?)"
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert ok.returncode == 0, ok.stderr[-3000:]
+    d = json.loads([ln for ln in ok.stdout.splitlines() if ln.startswith("{")][0])
+    assert len(d["config"]["per_rank"]) == 2 and all(pr["groups"] and pr["group_create_ms"] > 0 for pr in d["config"]["per_rank"])
+    assert "contract verified" in d["check"]
+    assert ok.stderr.count("[bench] rank ") >= 2

@@ -421,3 +421,43 @@ def test_code_stream_geometries_are_bit_exact(rng, lds_forced, geo):
     vals = (rng.random(len(col), dtype=np.float32) * 2 - 1).astype(np.float32)
     got, _ = product(rowptr, col, x, vals=vals)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), geo
+
+
+@pytest.mark.parametrize("fail,want", [(1, "token"), (2, "token"), (4, "sweep")])
+def test_fallback_ladder_says_what_it_did(rng, lds_forced, fail, want):
+    """when the code-stream form cannot be set up (its generation fails: 1; no executable memory: 2) the group takes
+    the TOKEN form of the same product -- not the sweep -- and when the schedule itself cannot be built (4) the sweep; every step down is
+    recorded as text with the group (pygim_group_lds_note), nothing falls back silently, and the product is the oracle's either way"""
+    rowptr, col = random_csr(rng, 3000, 2500, 20, long_rows=[(0, 2400)])
+    x = features(rng, 2500, 128, np.float32)
+    want_c = oracle.spmm_csr(rowptr, col, None, x)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    old = _lib.set_tunable("lds_fail", fail)
+    try:
+        hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rp.ctypes.data], [ci.ctypes.data], None, [3000], [2500], [len(ci)], [1], [128], 128)
+    finally:
+        _lib.set_tunable("lds_fail", old)
+    try:
+        note, plan, code = _lib.group_lds_note(hd), _lib.group_lds_plan(hd), _lib.group_lds_code(hd)
+        assert code["active"] == 0 and code["code_bytes"] == 0
+        if want == "token":
+            assert plan["tiles"] > 0 and "code-stream form not available" in note and "token form" in note, note
+            assert ("lds_fail" in note) and (("generation" in note) if fail == 1 else ("executable" in note)), note
+            assert _lib.group_lds_geometry(hd)["waves"] == 16
+        else:
+            assert plan["tiles"] == 0 and "could not be built" in note and "sweep" in note, note
+        out = np.full((3000, 128), 77, dtype=np.float32)
+        _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+        if want == "token":
+            assert out.tobytes() == want_c.tobytes()          # the token kernels sum in stored order too
+        else:
+            bound = oracle.spmm_csr(rowptr, col, None, np.abs(x))
+            assert np.all(np.abs(out.astype(np.float64) - want_c) <= 1e-5 * bound + 1e-30)
+    finally:
+        _lib.group_free(hd)
+    # ... and the undisturbed group says it is a code stream
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rp.ctypes.data], [ci.ctypes.data], None, [3000], [2500], [len(ci)], [1], [128], 128)
+    try:
+        assert _lib.group_lds_note(hd) == "code-stream form" and _lib.group_lds_code(hd)["active"] == 1
+    finally:
+        _lib.group_free(hd)

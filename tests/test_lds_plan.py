@@ -280,3 +280,22 @@ def test_code_stream_geometries_valued_and_split(emul, geo):
     xi = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
     got, _ = _run_code_geo(emul, rowptr, col, ncols, xi, nw, kc, nbuf, gsize, nsets, splits=3)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xi).tobytes()
+
+
+def test_schedule_builder_and_encoder_under_asan_ubsan(tmp_path):
+    """lds_plan.hpp writes gfx950 instruction words that end up in EXECUTABLE GPU memory; its vectors are indexed by hand.  The same
+    builder + encoder + interpreter, compiled with -fsanitize=address,undefined, over random shapes and every geometry (VERDICT r03
+    item 4; there is no GPU sanitizer on this pool, so the host side is where such a bug can be caught).  PYGIM_SAN_CASES=15000 is the soak."""
+    import shutil
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "tests", "native", "lds_plan_san_main.cpp")
+    exe = os.path.join(ROOT, "tests", "native", "lds_plan_san")
+    deps = [src, _SRC, os.path.join(ROOT, "pygim_amd", "csrc", "lds_plan.hpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(exe) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread", src, "-o", exe])
+    cases = os.environ.get("PYGIM_SAN_CASES", "60")
+    r = subprocess.run([exe, cases], capture_output=True, text=True, timeout=3600,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0 and "no finding" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
