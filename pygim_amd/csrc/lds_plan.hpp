@@ -63,6 +63,8 @@ struct LdsGeometry {
                                  // partial sums to row r + c * nrows (the row map says so): the caller sums the S row blocks afterwards.
                                  // For row shares too short to fill the chip with whole-X workgroups (a rank's share on N GPUs)
     uint32_t ka_stride() const { return (KA + 7) & ~7u; }   // row-map entries per wave: the store stage reads the map eight rows at a time
+    uint32_t row_bytes = 256;    // bytes of a staged row of X: 256 (64 features of 4 bytes, 128 of 2) or 512 (64 features of 8 bytes: INT64 / DBL64
+                                 // code streams, round 4 -- ds_read_b64 per entry, a register PAIR per accumulator and per staged value)
     uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
                                  // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
                                  // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
@@ -332,13 +334,15 @@ struct LdsCodeRegs {
     uint32_t s_cb = 84;      // s[84:85]: code touch pointer
     uint32_t s_ret = 86;     // s[86:87]: return address
     uint32_t s_pa = 92;      // s[92:93]: DMA source
-    constexpr uint32_t nx() const { return gsize * nsets; }
+    uint32_t wide = 0;       // 1: 8-byte elements -- x values and accumulators are register pairs
+    constexpr uint32_t nx() const { return gsize * nsets * (wide ? 2 : 1); }   // x REGISTERS
 };
 // 16 waves: v4 v5 v10 bases, v6 lane * 16, v11 (lane % 8) * 128, v9 junk, x v12..v27, accumulators v28..v123
 // 8 waves:  v0 is the lane id (the only register the compiler keeps), v1..v3 bases, v4 lane * 16 (DMA and touch), v5 junk,
 //           x v6..v27 (22 registers: two sets of 10 or three of 6), accumulators v28..v255
-constexpr LdsCodeRegs lds_code_regs(uint32_t NW, uint32_t gsize = 0, uint32_t nsets = 0) {
+constexpr LdsCodeRegs lds_code_regs(uint32_t NW, uint32_t gsize = 0, uint32_t nsets = 0, bool wide = false) {
     LdsCodeRegs r;
+    r.wide = wide ? 1 : 0;
     if (NW == 16) {
         r.vbase[0] = 4; r.vbase[1] = 5; r.vbase[2] = 10;
         r.vl16 = 6; r.vtouch = 11; r.vjunk = 9; r.x0 = 12; r.acc0 = 28;
@@ -347,17 +351,18 @@ constexpr LdsCodeRegs lds_code_regs(uint32_t NW, uint32_t gsize = 0, uint32_t ns
     } else {
         r.vbase[0] = 1; r.vbase[1] = 2; r.vbase[2] = 3;
         r.vl16 = 4; r.vtouch = 4; r.vjunk = 5; r.x0 = 6; r.acc0 = 28;
-        r.gsize = gsize ? gsize : 10;
+        r.gsize = gsize ? gsize : (wide ? 5 : 10);
         r.nsets = nsets ? nsets : 2;
     }
-    if (r.gsize & 1) r.gsize--;
+    if (!wide && (r.gsize & 1)) r.gsize--;   // (4-byte rows are read two to an instruction)
     if (r.gsize < 2) r.gsize = 2;
     if (r.nsets < 2) r.nsets = 2;
-    while (r.x0 + r.nx() > r.acc0 && r.gsize > 2) r.gsize -= 2;
+    while (r.x0 + r.nx() > r.acc0 && r.gsize > 2) r.gsize -= wide ? 1 : 2;
     return r;
 }
 // what build_lds_plan chooses when the tunables leave it open (measured: profiles/r04_lds_kernel.md)
 constexpr uint32_t LDS_CODE_AUTO_WAVES = 8, LDS_CODE8_AUTO_NBUF = 5;
+constexpr uint32_t LDS_CODE8_KA64 = 114;  // ... of its 8-byte form: a register pair per accumulator
 constexpr uint32_t LDS_CODE8_KA = 228;   // accumulators per wave of the 8-wave code-stream geometry (v28..v255)
 
 struct LdsCodeHost {
@@ -372,18 +377,26 @@ struct LdsCodeHost {
 // opcode_add: the VOP2 opcode field of the accumulate (v_add_f32 = 0x02000000, v_add_u32 = 0x68000000), or LDS_CODE_PK_ADD_U16 for
 // INT16 (two features to a lane: v_pk_add_u16, a VOP3P instruction of 8 bytes)
 constexpr uint32_t LDS_CODE_PK_ADD_U16 = 0xFFFFFFFFu;
+// 8-byte elements (geometry row_bytes = 512): v_add_f64 on register pairs; v_add_co_u32 + v_addc_co_u32
+constexpr uint32_t LDS_CODE_ADD_F64 = 0xFFFFFFFEu, LDS_CODE_ADD_U64 = 0xFFFFFFFDu;
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
                                uint32_t nsets = 0) {
     const LdsGeometry &geo = plan.geo;
     const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
-    const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets);
+    const uint32_t RB = geo.row_bytes;
+    const bool wide = RB == 512;
+    if (RB != 256 && RB != 512) throw std::runtime_error("lds code: rows of 256 or 512 bytes");
+    if (wide != (opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64)) throw std::runtime_error("lds code: 512-byte rows are the 8-byte element types'");
+    const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets, wide);
     out.regs = R;
     const uint32_t G = R.gsize, NS = R.nsets;
-    if (R.x0 + R.nx() > R.acc0 || R.acc0 + KA > 256 || G > 12 || (NS - 1) * G > 15)
+    if (R.x0 + R.nx() > R.acc0 || R.acc0 + KA * (wide ? 2 : 1) > 256 || G > 12 || (NS - 1) * G > 15)
         throw std::runtime_error("lds code: the geometry does not fit the register map");
-    const uint32_t pieces = (KC * 256 / 1024) / NW;   // 1 KiB DMA pieces of a chunk per wave
-    if (pieces * NW * 1024 != KC * 256) throw std::runtime_error("lds code: a chunk is not a whole number of pieces per wave");
-    const uint32_t chunk_bytes = KC * 256;
+    const uint32_t pieces = (KC * RB / 1024) / NW;   // 1 KiB DMA pieces of a chunk per wave
+    if (pieces * NW * 1024 != KC * RB) throw std::runtime_error("lds code: a chunk is not a whole number of pieces per wave");
+    const uint32_t chunk_bytes = KC * RB;
+    const uint32_t RPB = 65536 / RB;                  // rows of a 64 KiB LDS block (one base register each)
+    if ((KC * geo.NBUF + RPB - 1) / RPB > 3) throw std::runtime_error("lds code: the ring is larger than three 64 KiB blocks");
     const uint32_t ntiles = plan.ntiles;
     // a touch per 1 KB of code: the 8 lines (1 KB) that start 2 KiB ahead (the kernel's lane offsets repeat every 8 lanes).  A wave
     // consumes ~0.2 bytes of code per cycle: 2 KiB is > 10 000 cycles of lead.  (First version: 64 lines from 8 KiB ahead every 6 KB --
@@ -464,9 +477,13 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                           // its own x register here: the multiply overwrites it)
                 for (size_t q = 0; q < g.k.size(); q++) e.op(0x0A0000FFu | (g.xr[q] << 17) | (g.xr[q] << 9), g.v[q]);   // v_mul_f32 x, <literal value>, x
             for (size_t q = 0; q < g.k.size(); q++) {
-                const uint32_t vk = Rr.acc0 + g.k[q];
-                if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + g.xr[q]));   // v_pk_add_u16 acc, x, acc
-                else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + g.xr[q]));
+                const uint32_t vk = Rr.acc0 + g.k[q] * (wide ? 2 : 1), vx = g.xr[q];
+                if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + vx));   // v_pk_add_u16 acc, x, acc
+                else if (opcode_add == LDS_CODE_ADD_F64) e.op(0xD2800000u | vk, (256 + vx) | ((256 + vk) << 9));             // v_add_f64 acc[0:1], x[0:1], acc[0:1]
+                else if (opcode_add == LDS_CODE_ADD_U64) {
+                    e.op(0x32000000u | (vk << 17) | (vk << 9) | (256 + vx));                                                  // v_add_co_u32 acc0, vcc, x0, acc0
+                    e.op(0x38000000u | ((vk + 1) << 17) | ((vk + 1) << 9) | (256 + vx + 1));                                  // v_addc_co_u32 acc1, vcc, x1, acc1, vcc
+                } else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + vx));
             }
             pend.erase(pend.begin());
         };
@@ -525,11 +542,14 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 g.k.clear();
                 g.xr.clear();
                 g.v.clear();
-                g.xb = Rr.x0 + G * (gcount % NS);
+                const uint32_t XW = wide ? 2 : 1;                   // registers of a staged value
+                g.xb = Rr.x0 + G * XW * (gcount % NS);
                 while (g.nx < G && i < cols.size()) {
-                    const uint32_t r0 = cols[i].row, blk = r0 >> 8;
+                    const uint32_t r0 = cols[i].row, blk = r0 / RPB;
                     uint32_t took = 1;
-                    if (g.nx + 2 <= G && (g.nx & 1) == 0 && i + 1 < cols.size() && (cols[i + 1].row >> 8) == blk) {
+                    if (wide) {
+                        e.op(0xD8EC0000u | ((r0 % RPB) * RB), ((g.xb + g.nx * 2) << 24) | Rr.vbase[blk]);                    // ds_read_b64 x[0:1], base offset:row * 512
+                    } else if (g.nx + 2 <= G && (g.nx & 1) == 0 && i + 1 < cols.size() && (cols[i + 1].row >> 8) == blk) {
                         const uint32_t r1 = cols[i + 1].row;
                         e.op(0xD8700000u | ((r1 & 255) << 8) | (r0 & 255), ((g.xb + g.nx) << 24) | Rr.vbase[blk]);   // ds_read2st64_b32
                         took = 2;
@@ -540,7 +560,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     for (uint32_t u = 0; u < took; u++)
                         for (uint32_t q = cols[i + u].first; q < cols[i + u].first + cols[i + u].cnt; q++) {
                             g.k.push_back((uint32_t)toks[q] & 0xFF);
-                            g.xr.push_back(g.xb + g.nx + u);
+                            g.xr.push_back(g.xb + (g.nx + u) * XW);
                             g.v.push_back((uint32_t)(toks[q] >> 32));
                         }
                     g.nx += took;

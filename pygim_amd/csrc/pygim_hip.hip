@@ -23,7 +23,12 @@
 
 // rows of a slice of the slice-major copy: whole chunks of either kernel family (320-column chunks of the token kernels, 192 of the
 // code-stream kernels), so that the DMA of a tile's last chunk stays inside the copy
-constexpr uint64_t LDS_ROWS_PAD = 960;
+// rows of a slice of the staged copy: whole chunks of the part's ring (the DMA of a tile's last chunk reads KC rows whatever the
+// matrix's width), 64-row aligned
+static inline uint64_t lds_rows_pad(uint64_t ncols, uint32_t kc) {
+    const uint64_t k = kc ? kc : 320;
+    return ((ncols + k - 1) / k * k + 63) / 64 * 64;
+}
 
 #include <algorithm>
 #include <atomic>
@@ -157,6 +162,7 @@ struct Part {
     uint32_t lds_col_splits = 1;           // > 1: the plan's tiles are (row tile, column range) pairs writing partial sums (launch_lds reduces them)
     uint32_t lds_code_piece = 0;           // bytes of a chunk one wave DMAs (the code plan's ring geometry)
     uint32_t lds_kc = 0, lds_nbuf = 0;     // the plan's ring: columns per chunk, buffers
+    uint32_t lds_row_bytes = 256, lds_ka = 0;   // bytes of a staged row (512: the 8-byte element form), accumulators (rows) per wave
     uint32_t lds_code_gsize = 0, lds_code_nsets = 0;
     uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
     std::string lds_note;                  // which form of the product this part got, and why not a faster one
@@ -465,6 +471,7 @@ void free_part(Part &p) {
     p.lds_code = nullptr;
     p.lds_code_start = nullptr;
     p.lds_is_code = false;
+    p.lds_row_bytes = 256;
     p.lds_col_splits = 1;
     if (p.extra) free_part(*p.extra);
 }
@@ -787,13 +794,15 @@ int launch_block_t(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc
 template <typename T>
 int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, uint32_t w, bool accumulate, hipStream_t st,
                const void *lds_xs = nullptr, const uint32_t *deq_amax = nullptr, int deq_log2 = 0) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 2, "4-byte elements, or INT16 two to a lane");
-    constexpr uint32_t EPS = 256 / sizeof(T);              // elements of a 256-byte slice
-    constexpr int PVEC = 16 / (int)sizeof(T);
-    const uint32_t w_lanes = (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);
+    constexpr bool WIDE8 = sizeof(T) == 1;                 // INT8: staged as INT16 (k_slice_pack_widen8), summed by the INT16 stream
+    constexpr bool EL8 = sizeof(T) == 8;                   // INT64 / DBL64: slices of 64 features = 512 bytes, a register pair per value
+    constexpr uint32_t ROWB = EL8 ? 512 : 256;             // bytes of a staged row
+    constexpr uint32_t EPS = WIDE8 ? 128 : ROWB / sizeof(T);   // elements of a slice
+    constexpr int PVEC = WIDE8 ? 8 : 16 / (int)sizeof(T);
+    const uint32_t w_lanes = (WIDE8 || EL8) ? w : (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);   // (INT8: the kernel masks features one by one; 8-byte: a lane = a feature)
     const uint32_t nslices = (w + EPS - 1) / EPS;
-    const uint64_t rows_pad = ((uint64_t)p.ncols + LDS_ROWS_PAD - 1) / LDS_ROWS_PAD * LDS_ROWS_PAD;
-    const size_t need = (size_t)rows_pad * nslices * 256;
+    const uint64_t rows_pad = lds_rows_pad((uint64_t)p.ncols, p.lds_kc);
+    const size_t need = (size_t)rows_pad * nslices * ROWB;
     KernelTimer kt(g, st, !p.is_extra);
     XsPin pin;
     void *xs_use = const_cast<void *>(lds_xs);
@@ -806,7 +815,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             for (auto &kv : g_ctx.xs_bufs) {
                 Context::XsBuf &b = kv.second;
                 if (kv.first.first == dev && b.ptr && b.src == (const void *)X && b.ld == ldx && b.rows == p.ncols && b.w == (int64_t)w &&
-                    b.es == sizeof(T) && b.kind == 1 && (!hit || b.stamp > hit->stamp))
+                    b.es == sizeof(T) && b.kind == (WIDE8 ? 3 : 1) && (!hit || b.stamp > hit->stamp))
                     hit = &b;
             }
             if (hit) {
@@ -826,11 +835,21 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             b->rows = p.ncols;
             b->w = (int64_t)w;
             b->es = sizeof(T);
-            b->kind = 1;
+            b->kind = WIDE8 ? 3 : 1;
             const uint64_t threads = (uint64_t)p.ncols * nslices * 16;
-            if (threads > 0)
+            if constexpr (WIDE8) {
+                if (threads > 0)
+                    hipLaunchKernelGGL(k_slice_pack_widen8, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const int8_t *)X, ldx,
+                                       (uint32_t)p.ncols, w, nslices, (int16_t *)xs_use, (uint32_t)rows_pad);
+            } else if constexpr (EL8) {
+                const uint64_t th8 = (uint64_t)p.ncols * nslices * 32;   // 32 pieces of 16 bytes per 512-byte row
+                if (th8 > 0)
+                    hipLaunchKernelGGL((k_slice_pack<T, 2, 5>), dim3((unsigned)((th8 + 255) / 256)), dim3(256), 0, st, X, ldx,
+                                       (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)rows_pad);
+            } else if (threads > 0) {
                 hipLaunchKernelGGL((k_slice_pack<T, PVEC, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
                                    (uint32_t)p.ncols, w, nslices, (T *)xs_use, (uint32_t)rows_pad);
+            }
         }
     }
     LdsArgs a{};
@@ -839,8 +858,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.rowmap = p.lds_rowmap;
     a.xs = (const char *)xs_use;
     a.c = (char *)C;
-    a.slice_stride = rows_pad * 256;
-    a.ldc_bytes = (uint32_t)((size_t)ldc * sizeof(T));
+    a.slice_stride = rows_pad * ROWB;
+    a.ldc_bytes = (uint32_t)((size_t)ldc * ((WIDE8 && deq_amax) ? 4 : sizeof(T)));   // (the dequantising store writes floats)
     a.w = w_lanes;
     a.nslices = nslices;
     a.ntiles = p.lds_ntiles;
@@ -872,7 +891,14 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     if (p.lds_is_code) {   // the schedule compiled into machine code: 16 waves x 96 accumulators, or 8 x 228 (k_lds_code8_*)
         if (!g_tune.lds_code || g_tune.lds_ablate) return fail(PYGIM_ERR_INVALID, "this group's LDS plan is a code stream: lds_code was switched off (or lds_ablate on) after it was created");
         const bool w8 = p.lds_nw == 8;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (EL8) {
+            if (!w8 || deq_amax || S > 1 || p.lds_row_bytes != 512) return fail(PYGIM_ERR_INVALID, "internal: 8-byte LDS-staged product on an unsupported plan");
+            if constexpr (std::is_same<T, double>::value) fn = k_lds_code8_f64;
+            else fn = k_lds_code8_i64;
+        } else if constexpr (sizeof(T) == 1) {
+            if (!w8 || accumulate || S > 1) return fail(PYGIM_ERR_INVALID, "internal: INT8 LDS-staged product on an unsupported plan");
+            fn = deq_amax ? k_lds_code8_i8_deq : k_lds_code8_i8;   // (widened to 16 bits in the staged copy: the INT16 stream)
+        } else if constexpr (sizeof(T) == 2) {
             if (deq_amax) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
             fn = w8 ? k_lds_code8_i16 : k_lds_code_i16;   // (two features to a lane: v_pk_add_u16)
         } else if constexpr (std::is_same<T, float>::value) {
@@ -883,6 +909,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
         a.code = p.lds_code;
         a.code_start = p.lds_code_start;
         a.piece_bytes = p.lds_code_piece;
+    } else if constexpr (sizeof(T) == 1 || sizeof(T) == 8) {
+        return fail(PYGIM_ERR_INVALID, "internal: the INT8 / INT64 / DBL64 LDS-staged product exists in the code-stream form only");
     } else if (deq_amax) {
         if (p.lds_nw != 16 || p.lds_wdelta || sizeof(T) != 4) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
         if constexpr (std::is_same<T, float>::value) fn = long16 ? k_lds_spmm_f32_w16b_deq : k_lds_spmm_f32_w16_deq;
@@ -940,15 +968,22 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     return 0;
 }
 
-template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc, const void *C) {
-    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int16_t>::value)) return false;
+template <typename T> bool want_lds(const Group *g, const Part &p, uint32_t w, int64_t ldc, const void *C, bool accumulate = false) {
+    if constexpr (sizeof(T) == 8) {  // INT64 / DBL64: the 8-wave code stream on 512-byte rows (unit weights)
+        if (!p.lds_is_code || p.lds_nw != 8 || p.lds_row_bytes != 512 || p.lds_col_splits > 1 || p.vals) return false;
+    } else if (p.lds_row_bytes == 512) return false;
+    if constexpr (sizeof(T) == 1) {  // INT8 rides the 8-wave INT16 code stream (features widened to 16 bits in the staged copy); it neither accumulates
+                                     // into C nor splits tiles into column ranges
+        if (!p.lds_is_code || p.lds_nw != 8 || accumulate || p.lds_col_splits > 1 || p.vals) return false;
+        if ((int64_t)(w / 2) < g_tune.lds_min_width) return false;
+    }
     if constexpr (sizeof(T) == 2) {  // two features to a lane: whole lanes, dword-aligned rows of C, the 16-wave plan
         if ((w & 1) || (ldc & 1) || ((uintptr_t)C & 3) || (p.lds_nw != 16 && !p.lds_is_code)) return false;
     }
     if (!p.lds_tiles || g_tune.lds_mode == 2 || (!p.lds_is_code && (p.vals != nullptr) != (p.lds_wdelta != 0)) || g->deq_out || g->pre_xs) return false;
     if (p.lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return false;   // (a code-stream plan serves no token kernel: the sweep instead)
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode == 1 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0)) return false;  // another kernel was asked for by name
-    if ((int64_t)((size_t)w * sizeof(T) / 4) < g_tune.lds_min_width) return false;   // (lanes: 4-byte units of a row)
+    if (sizeof(T) > 1 && (int64_t)(sizeof(T) == 8 ? (size_t)w : (size_t)w * sizeof(T) / 4) < g_tune.lds_min_width) return false;   // (lanes: 4-byte units of a row; 8-byte: features)
     if ((uint64_t)ldc * sizeof(T) >= (1ull << 32)) return false;
     return true;
 }
@@ -959,9 +994,7 @@ int launch_block(Group *g, Part &p, const void *X, int64_t ldx, void *C, int64_t
     const T *x = (const T *)X;
     T *c = (T *)C;
     const uint32_t ww = (uint32_t)w;
-    if constexpr (sizeof(T) == 4 || std::is_same<T, int16_t>::value) {
-        if (want_lds<T>(g, p, ww, ldc, C)) return launch_lds<T>(g, p, x, ldx, c, ldc, ww, accumulate, st);
-    }
+    if (want_lds<T>(g, p, ww, ldc, C, accumulate)) return launch_lds<T>(g, p, x, ldx, c, ldc, ww, accumulate, st);
     // SpMV end of the path: rows of X of at most 4 elements -> lanes over the ENTRIES of a row (k_csr_vec)
     if (ww <= 4 && g_tune.vec_kernel && g_tune.force_vec_bytes == 0 && g_tune.csr_kernel == 0 && p.rowptr && p.nrows > 0) {
         // LDS-staged form: the plan's column panels with 16-bit local ids, a panel of X (panel_cols x w elements) plus the
@@ -1353,11 +1386,20 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
 }
 
 static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint,
-                               bool allow_code) {
-    if (g_tune.lds_mode == 2 || (es != 4 && es != 2) || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
+                               bool allow_code) {   // (es by value: INT8 plans are made as INT16 plans)
+    const bool int8_code = es == 1 && t_plan_dtype == PYGIM_INT8 && !p.vals && allow_code && g_tune.lds_code && g_tune.lds_waves == 16 && g_tune.lds_code_waves != 16;
+    if (es == 1) {   // INT8: the 8-wave INT16 code stream on features widened to 16 bits (no token form, no 16-wave form)
+        if (!int8_code) return 0;
+        es = 2;
+    }
+    // INT64 / DBL64, unit weights: the 8-wave code stream on rows of 512 bytes (a register pair per value; no token form)
+    const bool el8_code = es == 8 && (t_plan_dtype == PYGIM_INT64 || t_plan_dtype == PYGIM_DBL64) && !p.vals && allow_code && g_tune.lds_code &&
+                          g_tune.lds_waves == 16 && g_tune.lds_code_waves != 16;
+    if (es == 8 && !el8_code) return 0;
+    if (g_tune.lds_mode == 2 || (es != 4 && es != 2 && es != 8) || p.is_extra || p.nnz == 0 || p.nrows == 0 || p.ncols == 0) return 0;
     if ((p.vals || es == 2) && g_tune.lds_waves != 16) return 0;  // the valued and the INT16 kernels exist for the 16-wave geometry
-    if (h_hint > 0 && (h_hint * (int64_t)es) / 4 < g_tune.lds_min_width) return 0;   // no product of this group is wide enough (want_lds): no plan, no code
-    if ((uint64_t)p.ncols * 256ull >= (1ull << 32) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
+    if (h_hint > 0 && (es == 8 ? h_hint : (h_hint * (int64_t)es) / 4) < g_tune.lds_min_width) return 0;   // no product of this group is wide enough (want_lds): no plan, no code
+    if ((uint64_t)p.ncols * (es == 8 ? 512ull : 256ull) >= (1ull << 32) - (1ull << 20) || (uint64_t)p.nnz >= (1ull << 31)) return 0;
     LdsGeometry geo;
     geo.NW = g_tune.lds_waves == 16 ? 16 : 8;
     geo.KA = lds_ka(geo.NW);
@@ -1368,28 +1410,30 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     // (valued matrices: FLT32 only -- the value is the literal of a v_mul_f32 in the stream; the integer multiplies have no literal form)
     const bool want_code = allow_code && g_tune.lds_code && geo.NW == 16 &&
                            ((es == 4 && t_plan_dtype == PYGIM_FLT32) || (!p.vals && es == 4 && t_plan_dtype == PYGIM_INT32) ||
-                            (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16));
-    const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + 255) / 256 : 4;
+                            (!p.vals && es == 2 && t_plan_dtype == PYGIM_INT16) || int8_code || el8_code);
+    const int64_t slice_b = es == 8 ? 512 : 256;   // bytes of a row of a slice
+    const int64_t nsl_hint = h_hint > 0 ? (h_hint * (int64_t)es + slice_b - 1) / slice_b : 4;
     if (want_code) {
         // 8 waves x 228 accumulators (2 waves per SIMD): tiles of 1 824 rows -- Reddit h = 256 is two rounds of workgroups on 256 CUs
         // instead of three, a third less of X staged -- or round 3's 16 waves x 96
         const int64_t cw = g_tune.lds_code_waves;
-        const bool eight = cw == 8 || (cw != 16 && LDS_CODE_AUTO_WAVES == 8);
+        const bool eight = cw == 8 || (cw != 16 && LDS_CODE_AUTO_WAVES == 8) || int8_code || el8_code;
         if (eight) {
             geo.NW = 8;
-            geo.KA = LDS_CODE8_KA;
+            geo.KA = el8_code ? LDS_CODE8_KA64 : LDS_CODE8_KA;
             geo.BATCH = 8;
         }
+        if (el8_code) geo.row_bytes = 512;
     }
     // tiles sized so that one product of the group's width runs as whole rounds of workgroups (lds_plan.hpp)
     if (g_tune.lds_round_tiles && h_hint > 0)
-        geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1));
+        geo.rows_per_tile = lds_rows_per_tile((uint32_t)p.nrows, geo.NW * geo.KA, (uint32_t)nsl_hint, (uint32_t)std::max(g_ctx.cu_count, 1));
     // a row share too short to fill the chip with workgroups that each stream a whole slice of X (a rank's share on N GPUs: 24 tiles x
     // 4 slices on 256 CUs): full-height row tiles, each split into S column ranges -- S x as many workgroups, each landing 1/S of X;
     // partial sums per range, reduced in range order (launch_lds).  Integers stay exact; FLT32 only when asked (lds_col_split_f32)
-    if (g_tune.lds_col_split != 1 && (geo.NW == 16 || want_code) && (t_plan_dtype != PYGIM_FLT32 || g_tune.lds_col_split_f32) && !p.vals) {
+    if (g_tune.lds_col_split != 1 && (geo.NW == 16 || want_code) && !int8_code && !el8_code && (t_plan_dtype != PYGIM_FLT32 || g_tune.lds_col_split_f32) && !p.vals) {
         const uint32_t cus = (uint32_t)std::max(g_ctx.cu_count, 1);
-        const uint64_t nsl = h_hint > 0 ? (uint64_t)((h_hint * (int64_t)es + 255) / 256) : 1;
+        const uint64_t nsl = h_hint > 0 ? (uint64_t)nsl_hint : 1;
         const uint64_t tall = ((uint64_t)p.nrows + geo.NW * geo.KA - 1) / (geo.NW * geo.KA), wgs = tall * nsl;
         uint32_t S = 1;
         if (g_tune.lds_col_split > 1) S = (uint32_t)std::min<int64_t>(g_tune.lds_col_split, 16);
@@ -1432,9 +1476,10 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         if (nbuf == 0) nbuf = geo.NW == 8 ? LDS_CODE8_AUTO_NBUF : 2;
         nbuf = std::min<int64_t>(std::max<int64_t>(nbuf, 2), 8);
         static const uint32_t kc_of[9] = {0, 0, 320, 192, 160, 128, 96, 64, 64};
-        uint32_t kc = g_tune.lds_code_kc > 0 ? (uint32_t)g_tune.lds_code_kc : kc_of[nbuf];
-        kc = std::max(4 * geo.NW, kc / (4 * geo.NW) * (4 * geo.NW));        // whole 1 KiB pieces per wave
-        while ((uint64_t)kc * 256 * (uint64_t)nbuf > LDS_BYTES || kc * (uint32_t)nbuf > 640) kc -= 4 * geo.NW;   // (the LDS; 10-bit LDS rows in a token)
+        uint32_t kc = g_tune.lds_code_kc > 0 ? (uint32_t)g_tune.lds_code_kc : kc_of[nbuf] * 256 / geo.row_bytes;
+        const uint32_t kq = 1024 * geo.NW / geo.row_bytes;                  // columns of one 1 KiB piece per wave
+        kc = std::max(kq, kc / kq * kq);                                    // whole pieces per wave
+        while ((uint64_t)kc * geo.row_bytes * (uint64_t)nbuf > LDS_BYTES || kc * (uint32_t)nbuf > 640) kc -= kq;   // (the LDS; 10-bit LDS rows in a token)
         geo.KC = kc;
         geo.NBUF = (uint32_t)nbuf;
     }
@@ -1455,7 +1500,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         gl.KA = LDS_L16_KA;
         gl.BATCH = LDS_L16_BATCH;
         gl.rows_per_tile = geo.col_splits > 1 ? 0 : g_tune.lds_round_tiles && h_hint > 0
-                               ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)((h_hint * (int64_t)es + 255) / 256), (uint32_t)std::max(g_ctx.cu_count, 1))
+                               ? lds_rows_per_tile((uint32_t)p.nrows, gl.NW * gl.KA, (uint32_t)nsl_hint, (uint32_t)std::max(g_ctx.cu_count, 1))
                                : 0;
         const uint32_t r_now = geo.rows_per_tile ? geo.rows_per_tile : geo.NW * geo.KA, r_new = gl.rows_per_tile ? gl.rows_per_tile : gl.NW * gl.KA;
         if (r_new >= r_now) {  // no more tiles than before
@@ -1494,7 +1539,8 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         LdsCodeHost ch;
         try {
             if (g_tune.lds_fail & 1) throw std::runtime_error("lds_fail: forced failure of the code generation");
-            lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : (t_plan_dtype == PYGIM_INT32 ? 0x68000000u : LDS_CODE_PK_ADD_U16), ch,
+            lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : t_plan_dtype == PYGIM_INT32 ? 0x68000000u : t_plan_dtype == PYGIM_DBL64 ? LDS_CODE_ADD_F64 :
+                                     t_plan_dtype == PYGIM_INT64 ? LDS_CODE_ADD_U64 : LDS_CODE_PK_ADD_U16, ch,
                                (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
                                (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets));
         } catch (const std::exception &e) {   // out of host memory or threads: the same schedule as a token plan (build_lds_plan)
@@ -1517,7 +1563,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         p.lds_code_bytes = ch.code.size() * 4;
         p.lds_code_pairs = ch.pairs;
         p.lds_is_code = true;
-        p.lds_code_piece = geo.KC * 256 / geo.NW;
+        p.lds_code_piece = geo.KC * geo.row_bytes / geo.NW;
         p.lds_code_gsize = ch.regs.gsize;
         p.lds_code_nsets = ch.regs.nsets;
         p.lds_code_shared = ch.shared;
@@ -1527,6 +1573,8 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     p.lds_col_splits = geo.col_splits;
     p.lds_kc = geo.KC;
     p.lds_nbuf = geo.NBUF;
+    p.lds_row_bytes = geo.row_bytes;
+    p.lds_ka = geo.KA;
     p.lds_ntiles = plan.ntiles;
     p.lds_nw = geo.NW;
     p.lds_batch = geo.BATCH;
@@ -1991,8 +2039,8 @@ static Part *fusable_part(Group *g) {
 // (INT32 / FLT32 adjacency types; the per-column epilogue, if any, is applied in the same store)
 template <typename T>
 static Part *lds_fusable_part(Group *g) {
-    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value)) return nullptr;
-    if (!g->all_ones || g_tune.lds_mode == 2 || (int64_t)g->h < g_tune.lds_min_width) return nullptr;
+    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int8_t>::value)) return nullptr;
+    if (!g->all_ones || g_tune.lds_mode == 2 || (int64_t)g->h / (sizeof(T) == 1 ? 2 : 1) < g_tune.lds_min_width) return nullptr;
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode != 0 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0 || !g_tune.fuse_windows)) return nullptr;
     Part *p = nullptr;
     if (g->parts.size() == 1) p = &g->parts[0];
@@ -2000,6 +2048,7 @@ static Part *lds_fusable_part(Group *g) {
     if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || (p->lds_nw != 16 && !p->lds_is_code) || p->nrows == 0 || p->ncols == 0) return nullptr;
     if (p->lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return nullptr;
     if (p->lds_col_splits > 1) return nullptr;   // (partial sums per column range cannot be dequantised in the store)
+    if (sizeof(T) == 1 && (!p->lds_is_code || p->lds_nw != 8)) return nullptr;
     return p;
 }
 
@@ -2021,12 +2070,15 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, amax);
     if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
     if (rows * h == 0 && scale_out) hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, (uint32_t *)scale_out);
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 || sizeof(T) == 1) {
         if (Part *p = lds_fusable_part<T>(g)) {
             // FUSED on the LDS-staged kernel: the 256-byte-slice copy is written quantised from the float features, the kernel's
-            // store dequantises (no quantised matrix, no integer result)
-            const uint32_t nslices = (h + 63) / 64;
-            const uint64_t rows_pad = ((uint64_t)p->ncols + LDS_ROWS_PAD - 1) / LDS_ROWS_PAD * LDS_ROWS_PAD;
+            // store dequantises (no quantised matrix, no integer result).  INT8 (the conv layers' own type, models/quantize.py:22-23):
+            // the quantised values are staged as 16-bit numbers, 128 features to a slice, and summed by the INT16 stream
+            using S = typename std::conditional<sizeof(T) == 1, int16_t, T>::type;
+            constexpr uint32_t EPS = 256 / sizeof(S);
+            const uint32_t nslices = (h + EPS - 1) / EPS;
+            const uint64_t rows_pad = lds_rows_pad((uint64_t)p->ncols, p->lds_kc);
             void *xs = nullptr;
             {
                 std::lock_guard<std::mutex> lk(g_ctx.mu);
@@ -2038,8 +2090,8 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
             XsPin pin;
             pin.hold(xs);
             const uint64_t threads = (uint64_t)p->ncols * nslices * 16;
-            hipLaunchKernelGGL((k_slice_pack_quant<T, 4, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
-                               (uint32_t)p->ncols, h, nslices, amax, log2_range, (T *)xs, scale_out, (uint32_t)rows_pad);
+            hipLaunchKernelGGL((k_slice_pack_quant<S, 16 / (int)sizeof(S), 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx,
+                               (uint32_t)p->ncols, h, nslices, amax, log2_range, (S *)xs, scale_out, (uint32_t)rows_pad);
             HIP_TRY(hipGetLastError());
             return launch_lds<T>(g, *p, (const T *)nullptr, (int64_t)h, (T *)out, (int64_t)h, h, false, st, xs, amax, log2_range);
         }
@@ -2103,7 +2155,7 @@ template <typename T>
 static int dequant_run_t(Group *g, const void *Xq, int64_t ldx, float *out, const uint32_t *amax, int log2_range, hipStream_t st) {
     const uint64_t orows = (uint64_t)g->total_rows;
     const uint32_t h = (uint32_t)g->h;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 || sizeof(T) == 1) {
         if (Part *pl = lds_fusable_part<T>(g))  // the LDS-staged kernel packs the quantised rows itself and dequantises in its store
             return launch_lds<T>(g, *pl, (const T *)Xq, ldx, (T *)out, (int64_t)h, h, false, st, nullptr, amax, log2_range);
     }
@@ -2583,7 +2635,7 @@ int pygim_group_lds_geometry(int64_t handle, int64_t out[8]) {
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!p.lds_tiles) return 0;
     out[0] = p.lds_nw;
-    out[1] = p.lds_is_code && p.lds_nw == 8 ? (int64_t)LDS_CODE8_KA : (p.lds_batch == LDS_L16_BATCH && p.lds_nw == 16 ? (int64_t)LDS_L16_KA : (int64_t)lds_ka(p.lds_nw));
+    out[1] = p.lds_ka;
     out[2] = p.lds_kc;
     out[3] = p.lds_nbuf;
     out[4] = p.lds_is_code ? p.lds_code_gsize : 0;

@@ -43,6 +43,8 @@ class Geo:
         self.X0 = T0 + 8 if X0 is None else X0
         self.ACC0 = self.X0 + 2 * BATCH if ACC0 is None else ACC0
         self.regmap = regmap                  # explicit names of (VB, VM, VL16, VL4, VT0, VT1, VZ, VL128) instead of v[T0..T0+7]
+        self.acc_regs = None                  # accumulator REGISTERS to clear (default KA [+ the dummy]); 8-byte elements: 2 per row
+        self.lane_shift = 2                   # LDS base registers = lane << lane_shift (+ 64 KiB, + 128 KiB): 4-byte lanes, or 8-byte
         self.dummy = dummy                    # accumulator KA exists (the token kernels' padding tokens add into it)
         self.vmax = 512 // (NW // 4)          # VGPRs per lane at NW / 4 waves per SIMD
         assert self.ACC0 + KA + (1 if dummy else 0) <= min(self.vmax, 256), (self.ACC0 + KA + 1, self.vmax)
@@ -64,9 +66,14 @@ GEO_CODE.pieces = 48 // 16
 # the store stage borrows x registers (v8, v9 temporaries; v6, v7 epilogue factors)
 GEO_CODE8 = Geo(8, 228, 8, 1, regmap=("v1", "v2", "v4", "v1", "v8", "v9", "v3", "v4"), X0=6, ACC0=28, dummy=False)
 GEO_CODE8.pieces = 0   # (taken from the plan: LdsArgs.piece_bytes)
+# ... and its 8-byte form (INT64 / DBL64): 114 rows per wave, a register pair per running sum, rows of 512 bytes in LDS (lane * 8)
+GEO_CODE8_64 = Geo(8, 114, 8, 1, regmap=("v1", "v2", "v4", "v1", "v8", "v9", "v3", "v4"), X0=6, ACC0=28, dummy=False)
+GEO_CODE8_64.pieces = 0
+GEO_CODE8_64.acc_regs = 228
+GEO_CODE8_64.lane_shift = 3
 
 
-def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
+def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
     3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
     6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
@@ -104,14 +111,14 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
         a(f"s_lshr_b32 {CIDN}, s{TOK[r] + 2}, 18")    # chunk id of the slot after it (DMA)
 
     # ---- set-up
-    a(f"v_lshlrev_b32 {VL4}, 2, %[lane]")
+    a(f"v_lshlrev_b32 {VL4}, {g.lane_shift}, %[lane]")
     if VL128 != VL16:
         a(f"v_lshlrev_b32 {VL128}, 7, %[lane]")
     a(f"v_lshlrev_b32 {VL16}, 4, %[lane]")
     a(f"v_mov_b32 {VM}, 0x3ff00")
-    a(f"v_lshlrev_b32 {VB}, 2, %[lane]")       # (the token carries the LDS row of both buffers: the lane offset is all that is added)
+    a(f"v_lshlrev_b32 {VB}, {g.lane_shift}, %[lane]")       # (the token carries the LDS row of both buffers: the lane offset is all that is added)
     a(f"v_mov_b32 {VZ}, 0")
-    for i in range(KA + (1 if g.dummy else 0)):
+    for i in range(g.acc_regs or (KA + (1 if g.dummy else 0))):
         a(f"v_mov_b32 v{ACC0 + i}, 0")
     if code:
         # CODE-STREAM form (lds_plan.hpp lds_code_from_plan): the whole slot loop -- DMA of the chunks, the entries' LDS reads and
@@ -322,6 +329,139 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False):
     if code:
         del L[cut - 1:]                            # (nothing between the stream's return and the store stage)
     a("L_out_%=:")
+    if out_kind in ("f64", "i64"):
+        # 8-byte elements (round 4): row k's running sum is the register pair v[ACC0 + 2k : ACC0 + 2k + 1], one feature per lane (64 to a
+        # slice of 512 bytes); the store writes 8 bytes per lane, or adds into C first (v_add_f64 / a 64-bit integer add)
+        assert code and g.regmap and VT0 == "v8" and VT1 == "v9"
+        a(f"s_mov_b64 {EX}, exec")
+        a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
+        a("s_and_b64 exec, exec, vcc")
+        a(f"s_mov_b64 {NP}, %[rowmap]")
+        a(f"s_mov_b32 {KREG}, 0")
+        a("L_orow_%=:")
+        a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
+        a("s_waitcnt lgkmcnt(0)")
+        for i in range(8):
+            rid = f"s{TOK[0] + i}"
+            a(f"s_cmp_eq_u32 {rid}, -1")
+            a(f"s_cbranch_scc1 L_oskip{i}_%=")
+            a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
+            a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
+            a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
+            a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
+            a(f"s_add_u32 {DLDS}, {KREG}, {i}")
+            a(f"s_lshl_b32 {DLDS}, {DLDS}, 1")
+            a(f"s_set_gpr_idx_on {DLDS}, gpr_idx(SRC0)")
+            a(f"v_mov_b32 v8, v{ACC0}")
+            a(f"v_mov_b32 v9, v{ACC0 + 1}")
+            a("s_set_gpr_idx_off")
+            a("s_cmp_eq_u32 %[accum], 0")
+            a(f"s_cbranch_scc1 L_ost{i}_%=")
+            a(f"global_load_dwordx2 v[16:17], {VB}, {PA}")
+            a("s_waitcnt vmcnt(0)")
+            if out_kind == "f64":
+                a("v_add_f64 v[8:9], v[16:17], v[8:9]")
+            else:
+                a("v_add_co_u32 v8, vcc, v16, v8")
+                a("v_addc_co_u32 v9, vcc, v17, v9, vcc")
+            a(f"L_ost{i}_%=:")
+            a(f"global_store_dwordx2 {VB}, v[8:9], {PA}")
+            a(f"L_oskip{i}_%=:")
+        a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
+        a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
+        a(f"s_add_u32 {KREG}, {KREG}, 8")
+        a(f"s_cmp_lt_u32 {KREG}, {KA}")
+        a("s_cbranch_scc1 L_orow_%=")
+        a(f"s_mov_b64 exec, {EX}")
+        a("s_waitcnt vmcnt(0)")
+        return L
+    if out_kind in ("i8", "i8_deq"):
+        # INT8 through the INT16 stream (round 4): the slice-major copy holds the int8 features WIDENED to 16 bits (a slice = 128 features
+        # = the same 256 bytes), the stream's v_pk_add_u16 sums wrap modulo 2^16, and the low byte of each half IS the modular int8 sum
+        # (models/quantize.py:22-23 quantises to int8; torch's int8 sums wrap the same way).  A lane holds features 2l and 2l + 1:
+        # "i8":     two byte stores per lane (features beyond the width masked off one by one: widths need not be even)
+        # "i8_deq": sign-extend, float(sum) * scale, the optional per-column epilogue, two dword stores per lane
+        assert code and g.regmap
+        VL2, VL8, T2, T3, VP, VQ = "v10", "v11", "v16", "v17", 12, 14
+        EXA, EXB = "s[80:81]", "s[82:83]"                   # (the stream's registers are free again)
+        a(f"s_mov_b64 {EX}, exec")
+        a(f"v_lshlrev_b32 {VL2}, 1, %[lane]")
+        a(f"v_lshlrev_b32 {VL8}, 3, %[lane]")
+        ST = "s84"                                          # (TMP is half of the saved exec mask in this stage)
+        a(f"s_add_u32 {ST}, %[wvalid], 1")                  # [wvalid] = features of this slice (<= 128)
+        a(f"s_lshr_b32 {ST}, {ST}, 1")
+        a(f"v_cmp_gt_u32 vcc, {ST}, %[lane]")               # lane l holds a valid feature 2l
+        a(f"s_mov_b64 {EXA}, vcc")
+        a(f"s_lshr_b32 {ST}, %[wvalid], 1")
+        a(f"v_cmp_gt_u32 vcc, {ST}, %[lane]")               # ... and a valid feature 2l + 1
+        a(f"s_mov_b64 {EXB}, vcc")
+        a(f"s_mov_b64 {NP}, %[rowmap]")
+        a(f"s_mov_b32 {KREG}, 0")
+        if out_kind == "i8_deq":
+            a("s_cmp_eq_u64 %[pmul], 0")
+            a("s_cbranch_scc1 L_nopost_%=")
+            a(f"s_mov_b64 exec, {EXA}")                        # (nothing is read past the last column's factor)
+            a(f"global_load_dword v{VP}, {VL8}, %[pmul]")
+            a(f"global_load_dword v{VQ}, {VL8}, %[padd]")
+            a(f"s_mov_b64 exec, {EXB}")
+            a(f"global_load_dword v{VP + 1}, {VL8}, %[pmul] offset:4")
+            a(f"global_load_dword v{VQ + 1}, {VL8}, %[padd] offset:4")
+            a(f"s_mov_b64 exec, {EX}")
+            a("s_waitcnt vmcnt(0)")
+            a("L_nopost_%=:")
+        a("L_orow_%=:")
+        a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
+        a("s_waitcnt lgkmcnt(0)")
+        for i in range(8):
+            rid = f"s{TOK[0] + i}"
+            a(f"s_cmp_eq_u32 {rid}, -1")
+            a(f"s_cbranch_scc1 L_oskip{i}_%=")
+            a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
+            a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
+            a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
+            a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
+            a(f"s_add_u32 {DLDS}, {KREG}, {i}")
+            a(f"s_set_gpr_idx_on {DLDS}, gpr_idx(SRC0)")
+            a(f"v_mov_b32 {VT0}, v{ACC0}")
+            a("s_set_gpr_idx_off")
+            if out_kind == "i8":
+                a(f"s_mov_b64 exec, {EXA}")
+                a(f"global_store_byte {VL2}, {VT0}, {PA}")
+                a(f"s_mov_b64 exec, {EXB}")
+                a(f"global_store_byte_d16_hi {VL2}, {VT0}, {PA} offset:1")
+                a(f"s_mov_b64 exec, {EX}")
+            else:
+                a(f"v_bfe_i32 {T2}, {VT0}, 0, 8")
+                a(f"v_bfe_i32 {T3}, {VT0}, 16, 8")
+                a(f"v_cvt_f32_i32 {T2}, {T2}")
+                a(f"v_cvt_f32_i32 {T3}, {T3}")
+                a(f"v_mul_f32 {T2}, %[scale], {T2}")
+                a(f"v_mul_f32 {T3}, %[scale], {T3}")
+                a("s_cmp_eq_u64 %[pmul], 0")
+                a(f"s_cbranch_scc1 L_np{i}_%=")
+                a(f"v_mul_f32 {T2}, v{VP}, {T2}")
+                a(f"v_mul_f32 {T3}, v{VP + 1}, {T3}")
+                a(f"v_add_f32 {T2}, v{VQ}, {T2}")
+                a(f"v_add_f32 {T3}, v{VQ + 1}, {T3}")
+                a("s_cmp_eq_u32 %[relu], 0")
+                a(f"s_cbranch_scc1 L_np{i}_%=")
+                a(f"v_max_f32 {T2}, 0, {T2}")
+                a(f"v_max_f32 {T3}, 0, {T3}")
+                a(f"L_np{i}_%=:")
+                a(f"s_mov_b64 exec, {EXA}")
+                a(f"global_store_dword {VL8}, {T2}, {PA}")
+                a(f"s_mov_b64 exec, {EXB}")
+                a(f"global_store_dword {VL8}, {T3}, {PA} offset:4")
+                a(f"s_mov_b64 exec, {EX}")
+            a(f"L_oskip{i}_%=:")
+        a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
+        a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
+        a(f"s_add_u32 {KREG}, {KREG}, 8")
+        a(f"s_cmp_lt_u32 {KREG}, {KA}")
+        a("s_cbranch_scc1 L_orow_%=")
+        a(f"s_mov_b64 exec, {EX}")
+        a("s_waitcnt vmcnt(0)")
+        return L
     a(f"s_mov_b64 {EX}, exec")
     a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
     a("s_and_b64 exec, exec, vcc")
@@ -451,8 +591,8 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     const uint32_t cid0 = __builtin_amdgcn_readfirstlane(t->chunk0);
     const uint64_t xs = (uint64_t)(a.xs + (uint64_t)slice * a.slice_stride + wave * %(piece_expr)s);
     const uint64_t rowmap = (uint64_t)(a.rowmap + ((uint64_t)ti * NW + wave) * ((KA + 7u) & ~7u));   // (LdsGeometry::ka_stride)
-    const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * 256u);
-    const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(64u, a.w - slice * 64u));
+    const uint64_t cb = (uint64_t)(a.c + (uint64_t)slice * %(cslice)du);
+    const uint32_t wvalid = __builtin_amdgcn_readfirstlane(min(%(fps)du, a.w - slice * %(fps)du));
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dyn + wave * %(piece_expr)s);
     const uint32_t scale = %(scale_expr)s;
 %(post_decl)s#define PYGIM_SU(x) __builtin_amdgcn_readfirstlane((uint32_t)(x))
@@ -511,17 +651,27 @@ def main():
         variants.append((f"k_lds_code8_{base}" + ("_deq" if deq else ""), op, "C8", 0,
                          "CODE-STREAM form, 8 waves x 228 accumulators (2 waves per SIMD, 1 824-row tiles: fewer rounds of workgroups, less of X staged)",
                          None, deq))
+    variants.append(("k_lds_code8_f64", "v_add_f64", "C8W", 0,
+                     "CODE-STREAM form, DBL64: 512-byte rows in LDS, one ds_read_b64 per staged column, a register pair per running sum (8 waves x 114 rows)", None, None, "f64"))
+    variants.append(("k_lds_code8_i64", "v_add_co_u32", "C8W", 0,
+                     "CODE-STREAM form, INT64: as DBL64, the add is v_add_co_u32 + v_addc_co_u32 (modular)", None, None, "i64"))
+    variants.append(("k_lds_code8_i8", "v_pk_add_u16", "C8", 0,
+                     "CODE-STREAM form, INT8: features widened to 16 bits in the staged copy, packed 16-bit sums, the store keeps each sum's low byte", None, None, "i8"))
+    variants.append(("k_lds_code8_i8_deq", "v_pk_add_u16", "C8", 0,
+                     "CODE-STREAM form, INT8 quantised features (the conv layers' own type), the store dequantises: out = float(int8 sum) * scale", None, "i8", "i8_deq"))
     for v in variants:
         name, op, nw, ab, doc = v[:5]
         op_mul = v[5] if len(v) > 5 else None
         deq = v[6] if len(v) > 6 else None
         if "_code" in name:
-            g = GEO_CODE8 if nw == "C8" else GEO_CODE
+            g = GEO_CODE8_64 if nw == "C8W" else (GEO_CODE8 if nw == "C8" else GEO_CODE)
         else:
             g = GEO_L16 if nw == "L16" else (GEO_W16 if op_mul else GEOS[nw])
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         is_code = "_code" in name
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code))
+        out_kind = v[7] if len(v) > 7 else None
+        cslice, fps = {None: (256, 64), "i8": (128, 128), "i8_deq": (512, 128), "f64": (512, 64), "i64": (512, 64)}[out_kind]
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code, out_kind=out_kind))
         guard = "_ab" in name   # ablation builds (timing experiments, wrong results) only with -DPYGIM_LDS_ABLATE (make ablate)
         if guard:
             text += "\n#ifdef PYGIM_LDS_ABLATE"
@@ -529,8 +679,9 @@ def main():
                               piece=g.pieces * 1024,
                               scale_expr=("__builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(*a.deq_amax) * 2.0f / (float)(1u << a.deq_log2)))"
                                           if deq else "0u"),
-                              post_decl=("    const uint64_t pmul = a.post_mul ? (uint64_t)(a.post_mul + slice * 64u) : 0ull, "
-                                         "padd = a.post_mul ? (uint64_t)(a.post_add + slice * 64u) : 0ull;\n" if deq else ""),
+                              post_decl=((f"    const uint64_t pmul = a.post_mul ? (uint64_t)(a.post_mul + slice * {fps}u) : 0ull, "
+                                          f"padd = a.post_mul ? (uint64_t)(a.post_add + slice * {fps}u) : 0ull;\n") if deq else ""),
+                              cslice=cslice, fps=fps,
                               post_decl2=("    const uint64_t pmul_s = ((uint64_t)PYGIM_SU2(pmul >> 32) << 32) | PYGIM_SU2(pmul), "
                                           "padd_s = ((uint64_t)PYGIM_SU2(padd >> 32) << 32) | PYGIM_SU2(padd);" if deq else ""),
                               post_ops=(',\n          [pmul] "s"(pmul_s), [padd] "s"(padd_s), [relu] "s"(a.post_relu)' if deq else ""),

@@ -4,6 +4,7 @@
 #include "../../pygim_amd/csrc/lds_plan.hpp"
 
 #include <cstring>
+#include <type_traits>
 
 using namespace pygim;
 
@@ -148,8 +149,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     }
     LdsGeometry geo;
     geo.col_splits = S;
+    constexpr bool WIDE = sizeof(T) == 8;   // INT64 / DBL64: 512-byte rows, ds_read_b64, register pairs (8 waves x 114 accumulators)
+    if (WIDE && nw != 8) return 12;
     geo.NW = nw == 8 ? 8 : 16;          // round 4: 8 waves x 228 accumulators (2 waves per SIMD) beside 16 x 96
-    geo.KA = nw == 8 ? LDS_CODE8_KA : 96;
+    geo.KA = nw == 8 ? (WIDE ? LDS_CODE8_KA64 : LDS_CODE8_KA) : 96;
+    geo.row_bytes = WIDE ? 512 : 256;
     geo.BATCH = 8;
     geo.rows_per_tile = rows_per_tile;
     geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
@@ -159,12 +163,13 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     if (plan.header_overflow) return 13;
     nrows = S * nrows_real;   // rows of the (partial-sum) result the plan writes
     const uint32_t NBUF = geo.NBUF;
-    const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : 0x68000000u;
+    const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : std::is_same<T, double>::value ? LDS_CODE_ADD_F64 :
+                            std::is_same<T, int64_t>::value ? LDS_CODE_ADD_U64 : 0x68000000u;
     LdsCodeHost ch;
     lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets);
     const LdsCodeRegs R = ch.regs;
     if (R.nx() > 32 || NBUF > 8) return 14;
-    const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, chunk_bytes = KC * 256;
+    const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, RB = geo.row_bytes, chunk_bytes = KC * RB, RPB = 65536 / RB;
     const uint32_t nslices = (h + 63) / 64;
     if (stats) {
         stats[0] = plan.ntiles;
@@ -199,8 +204,9 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 uint64_t pa = 0;                              // DMA source offset inside the slice (bytes), from the literal
                 int64_t dma_buf = -1, dma_cid = -1;
                 uint32_t pieces_seen = 0;
-                const uint32_t pieces = (KC * 256 / 1024) / NW;
+                const uint32_t pieces = (KC * RB / 1024) / NW;
                 bool done = false;
+                int64_t lo_half = -1;                         // INT64: the v_add_co_u32 of a pair has been seen for this accumulator
                 for (uint64_t guard = 0; !done; guard++) {
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
                     // vmcnt is a 6-bit counter: a wave has at most 63 vector loads in flight (the next one is not issued before the oldest
@@ -280,6 +286,71 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         vfifo.push_back({-1, -1, false});
                         pc += 2;
                         continue;
+                    }
+                    if (WIDE && (i0 & 0xFFFF0000u) == 0xD8EC0000u) {                            // ds_read_b64 x[0:1], base offset:row * 512
+                        const uint32_t i1 = ch.code[pc + 1], vdst = i1 >> 24, vaddr = i1 & 0xFF, off = i0 & 0xFFFF;
+                        int blk = -1;
+                        for (int b = 0; b < 3; b++) if (vaddr == R.vbase[b]) blk = b;
+                        if (blk < 0 || vdst < R.x0 || vdst + 1 >= R.x0 + R.nx() || ((vdst - R.x0) & 1) || off % RB) return 25;
+                        XReg &xr = x[vdst - R.x0];
+                        if (xr.inflight) return 27;
+                        xr.valid = xr.inflight = true;
+                        xr.has_mul = false;
+                        xr.ldsrow = blk * RPB + off / RB;
+                        if (xr.ldsrow >= NBUF * KC) return 28;
+                        if (dirty[xr.ldsrow / KC]) return 29;
+                        if (buf_chunk[xr.ldsrow / KC] < 0) return 38;
+                        xr.chunk = buf_chunk[xr.ldsrow / KC];
+                        read_since_barrier[xr.ldsrow / KC] = true;
+                        fifo.push_back(vdst - R.x0);
+                        pc += 2;
+                        continue;
+                    }
+                    if (WIDE) {
+                        // v_add_f64 acc[0:1], x[0:1], acc[0:1]   |   v_add_co_u32 acc0, vcc, x0, acc0 ; v_addc_co_u32 acc1, vcc, x1, acc1, vcc
+                        uint32_t vd = 0, vx = 0;
+                        bool is_add = false;
+                        if (opcode == LDS_CODE_ADD_F64 && (i0 & 0xFFFFFF00u) == 0xD2800000u) {
+                            const uint32_t d1 = ch.code[pc + 1];
+                            vd = i0 & 0xFF;
+                            vx = (d1 & 0x1FF) - 256;
+                            if (((d1 >> 9) & 0x1FF) != 256 + vd || (d1 >> 18)) return 30;
+                            is_add = true;
+                            pc += 2;
+                        } else if (opcode == LDS_CODE_ADD_U64 && (i0 & 0xFE000000u) == 0x32000000u) {
+                            if (lo_half >= 0) return 44;
+                            lo_half = i0;
+                            pc++;
+                            continue;
+                        } else if (opcode == LDS_CODE_ADD_U64 && (i0 & 0xFE000000u) == 0x38000000u) {
+                            if (lo_half < 0) return 44;
+                            const uint32_t l0 = (uint32_t)lo_half;
+                            vd = (l0 >> 17) & 0xFF;
+                            vx = (l0 & 0x1FF) - 256;
+                            if (((l0 >> 9) & 0xFF) != vd || ((i0 >> 17) & 0xFF) != vd + 1 || ((i0 >> 9) & 0xFF) != vd + 1 || (i0 & 0x1FF) != 256 + vx + 1) return 30;
+                            lo_half = -1;
+                            is_add = true;
+                            pc++;
+                        }
+                        if (is_add) {
+                            if (vd < R.acc0 || vd + 1 >= R.acc0 + 2 * KA || ((vd - R.acc0) & 1) || vx < R.x0 || vx + 1 >= R.x0 + R.nx() || ((vx - R.x0) & 1)) return 30;
+                            XReg &xr = x[vx - R.x0];
+                            bool infl = false;
+                            for (uint32_t r : fifo) if (r == vx - R.x0) infl = true;
+                            if (!xr.valid || infl) return 31;
+                            xr.inflight = false;
+                            if (xr.chunk < 0) return 32;
+                            const uint64_t xrow = (uint64_t)xr.chunk * KC + xr.ldsrow % KC;
+                            const uint32_t k = (vd - R.acc0) / 2;
+                            for (uint32_t l = 0; l < wvalid; l++) {
+                                const T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
+                                T &a = acc[(size_t)k * 64 + l];
+                                if constexpr (std::is_integral<T>::value) a = (T)((uint64_t)a + (uint64_t)xv);
+                                else a = a + xv;
+                            }
+                            if (s == 0) entries_seen++;
+                            continue;
+                        }
                     }
                     if ((i0 & 0xFFFF0000u) == 0xD8700000u || (i0 & 0xFFFF0000u) == 0xD86C0000u) {   // ds_read2st64_b32 / ds_read_b32
                         const bool two = (i0 & 0xFFFF0000u) == 0xD8700000u;
@@ -375,7 +446,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 T acc = part[(size_t)r * h + f];
                 for (uint32_t c = 1; c < S; c++) {
                     const T v = part[((size_t)c * nrows_real + r) * h + f];
-                    if constexpr (std::is_integral<T>::value) acc = (T)((uint32_t)acc + (uint32_t)v);
+                    if constexpr (std::is_integral<T>::value) acc = (T)((typename std::make_unsigned<T>::type)acc + (typename std::make_unsigned<T>::type)v);
                     else acc = acc + v;
                 }
                 Cout[(size_t)r * h + f] = acc;
@@ -393,6 +464,15 @@ int lds_code_f32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals, uint32_t col_splits, uint32_t nw,
                      uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
     return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits, nw, gsize, nsets, rows_per_tile);
+}
+// 8-byte element types (INT64 / DBL64): the 8-wave geometry with 512-byte rows
+int lds_code_f64_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const double *X, uint32_t h, double *C,
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
+    return run_code<double>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile);
+}
+int lds_code_i64_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int64_t *X, uint32_t h, int64_t *C,
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
+    return run_code<int64_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile);
 }
 int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,

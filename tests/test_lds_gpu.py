@@ -253,7 +253,9 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data], [n], [ncols],
                                [len(ci)], [1], [h], h)
         try:
-            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32")), dt
+            # (round 4: unit-weight INT8 rides the INT16 code stream, its features widened to 16 bits in the staged copy)
+            #  and unit-weight INT64 / DBL64 their own 8-byte code stream: rows of 512 bytes in LDS, a register pair per running sum)
+            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32") or (dt in ("INT8", "INT64", "DBL64") and v is None)), dt
             out = np.full((n, h), 77, dtype=npdt)
             _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
         finally:
@@ -302,13 +304,13 @@ def test_int16_two_features_to_a_lane(rng, lds_forced):
             assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (n, h, v is not None, code)
 
 
-@pytest.mark.parametrize("dt,code", [(np.int32, "INT32"), (np.float32, "FLT32")])
+@pytest.mark.parametrize("dt,code", [(np.int32, "INT32"), (np.float32, "FLT32"), (np.int8, "INT8")])
 def test_quantised_aggregation_with_the_dequantising_store(rng, lds_forced, dt, code):
     """the conv layers' quantise -> aggregate -> dequantise (models/quantize.py:20-42, pyg_gcn_conv.py:130-137) in one device call on
     the LDS-staged kernel: the slice-major copy is written quantised, the kernel's store writes float(sum) * scale -- equal to the
-    oracle's statement of the three steps bit for bit.  (INT8 / INT16 adjacency types keep the sweep's fused store: a byte-wise
-    SDWA form of this kernel was built in round 3 and dropped -- wrong under the VGPR index mode, and no faster than the sweep's
-    1.76 ms when run for timing.)"""
+    oracle's statement of the three steps bit for bit.  INT8 (round 4, the type models/quantize.py:22-23 quantises to): the quantised
+    features are staged as 16-bit numbers, summed by the INT16 code stream, and the store sign-extends each sum's low byte = the
+    modular int8 sum.  (INT16 keeps the sweep's fused store.)"""
     n, h = 3000, 256
     rowptr, col = random_csr(rng, n, n, 25, long_rows=[(5, 2500)])
     xf = rng.standard_normal((n, h)).astype(np.float32)
@@ -461,3 +463,59 @@ def test_fallback_ladder_says_what_it_did(rng, lds_forced, fail, want):
         assert _lib.group_lds_note(hd) == "code-stream form" and _lib.group_lds_code(hd)["active"] == 1
     finally:
         _lib.group_free(hd)
+
+
+def test_int8_rides_the_int16_code_stream(rng, lds_forced):
+    """INT8, unit weights (round 4): features widened to 16 bits in the slice-major copy (128 to a slice), packed 16-bit sums in the
+    8-wave code stream, the store keeps each sum's low byte -- the two's-complement modular int8 sum of the oracle's loop, bit for bit;
+    widths that end inside a lane or a slice (odd widths too), rows of C at any byte stride"""
+    for n, ncols, h, avg in ((2000, 1500, 256, 30), (1000, 3000, 100, 12), (1500, 900, 101, 40), (700, 700, 255, 9), (1200, 5000, 129, 25), (600, 600, 67, 200)):
+        rowptr, col = random_csr(rng, n, ncols, avg, empty_frac=0.1, long_rows=[(3, min(ncols, 2000))])
+        x = rng.integers(-128, 127, size=(ncols, h), dtype=np.int64, endpoint=True).astype(np.int8)
+        rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+        hd = _lib.group_create(_lib.CSR, _lib.INT8, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+        try:
+            assert _lib.group_lds_plan(hd)["tiles"] > 0 and _lib.group_lds_code(hd)["active"] == 1 and _lib.group_lds_geometry(hd)["waves"] == 8
+            out = np.full((n, h), 77, dtype=np.int8)
+            _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+        finally:
+            _lib.group_free(hd)
+        assert out.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (n, ncols, h)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.int64])
+def test_8_byte_elements_on_their_code_stream(rng, lds_forced, dt):
+    """INT64 / DBL64, unit weights (round 4; support/common.h:39-60 makes all six val_dt first-class): slices of 64 features = 512-byte
+    rows in LDS, one ds_read_b64 per staged column, a register pair per running sum (8 waves x 114 rows), v_add_f64 or a 64-bit
+    integer add.  DBL64 sums are bit-identical to the oracle's loop (stored order), INT64 modular; widths that end inside a slice,
+    C += A.X, ring geometries"""
+    code = _lib.DBL64 if dt == np.float64 else _lib.INT64
+    for geo in ((0, 0, 0, 0), (4, 64, 5, 2), (6, 48, 3, 3), (3, 96, 2, 2)):
+        for k, v in zip(("lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets"), geo):
+            _lib.set_tunable(k, v)
+        for n, ncols, h, avg in ((1, 1, 64, 1), (2000, 1500, 256, 30), (1000, 3000, 100, 12), (1500, 900, 65, 40), (900, 5000, 33, 25), (600, 600, 64, 200)):
+            rowptr, col = random_csr(rng, n, ncols, avg, empty_frac=0.1, long_rows=[(0, min(ncols, 2500))] if n > 100 else ())
+            if dt == np.float64:
+                x = rng.random((ncols, h)) * 2 - 1
+            else:
+                x = rng.integers(-2**63, 2**63 - 1, size=(ncols, h), dtype=np.int64)
+            rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+            hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+            try:
+                if len(col):
+                    g = _lib.group_lds_geometry(hd)
+                    assert _lib.group_lds_code(hd)["active"] == 1 and g["waves"] == 8 and g["acc_per_wave"] == 114 and g["chunk_cols"] * 512 * g["buffers"] <= 163840, g
+                out = np.full((n, h), 77, dtype=dt)
+                _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+                want = oracle.spmm_csr(rowptr, col, None, x)
+                assert out.tobytes() == want.tobytes(), (dt, geo, n, ncols, h)
+                if n > 100:   # C += A.X into a wider matrix (pygim_block_run's accumulate form)
+                    wide = np.ascontiguousarray(rng.integers(-5, 5, size=(n, h + 7)).astype(dt))
+                    before = wide.copy()
+                    _lib.block_run(hd, 0, x.ctypes.data, h, wide.ctypes.data, h + 7, h, True)
+                    if dt == np.float64:
+                        assert np.array_equal(wide[:, :h], before[:, :h] + want) and np.array_equal(wide[:, h:], before[:, h:])
+                    else:
+                        assert np.array_equal(wide[:, :h], (before[:, :h].astype(np.uint64) + want.astype(np.uint64)).astype(np.int64)) and np.array_equal(wide[:, h:], before[:, h:])
+            finally:
+                _lib.group_free(hd)

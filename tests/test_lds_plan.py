@@ -299,3 +299,29 @@ def test_schedule_builder_and_encoder_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, cases], capture_output=True, text=True, timeout=3600,
                        env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
     assert r.returncode == 0 and "no finding" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("geo", [(64, 5, 0, 0), (64, 4, 5, 2), (48, 6, 3, 3), (96, 3, 2, 2), (16, 5, 5, 2)])
+@pytest.mark.parametrize("dtype", [np.float64, np.int64])
+def test_code_stream_of_8_byte_elements(emul, geo, dtype):
+    """INT64 / DBL64 in the code-stream form (round 4): rows of 512 bytes in LDS (64 features of 8 bytes), one ds_read_b64 per staged
+    column, a register PAIR per accumulator (8 waves x 114 rows) -- v_add_f64, or v_add_co_u32 + v_addc_co_u32 -- interpreted on the
+    CPU against the oracle's loop: DBL64 bit-identical (stored order), INT64 modular"""
+    kc, nbuf, gsize, nsets = geo
+    rng = np.random.default_rng(kc * 10 + nbuf)
+    fn = emul.lds_code_f64_geo if dtype == np.float64 else emul.lds_code_i64_geo
+    for nrows, ncols, h, deg, rpt, splits in ((1, 1, 3, 1, 0, 1), (700, 900, 64, 9, 0, 1), (2000, 1500, 100, 40, 0, 1), (1500, 4000, 130, 25, 333, 1), (1300, 2600, 70, 50, 0, 3)):
+        rowptr, col = random_csr(rng, nrows, ncols, avg_deg=deg, empty_frac=0.1, long_rows=[(0, min(3000, 2 * ncols))] if nrows > 100 else ())
+        if dtype == np.float64:
+            x = rng.random((ncols, h)) * 2 - 1 if splits == 1 else rng.integers(-8, 8, size=(ncols, h)).astype(np.float64)   # (split plans: exact sums)
+        else:
+            x = rng.integers(-2**63, 2**63 - 1, size=(ncols, h), dtype=np.int64)
+        want = oracle.spmm_csr(rowptr, col, None, x)
+        out = np.full((nrows, h), 77, dtype=dtype)
+        stats = (ctypes.c_uint64 * 4)()
+        rp, ci, xx = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32), np.ascontiguousarray(x)
+        rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
+                out.ctypes.data_as(ctypes.c_void_p), 4, stats, kc, nbuf, splits, gsize, nsets, rpt)
+        assert rc == 0, f"the interpreter rejected the code stream (code {rc}) for {geo} {nrows} x {ncols}"
+        assert out.tobytes() == want.tobytes(), (geo, dtype, nrows)
+        assert stats[2] == len(col)
