@@ -509,10 +509,12 @@ def test_8_byte_elements_on_their_code_stream(rng, lds_forced, dt):
                 _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
                 want = oracle.spmm_csr(rowptr, col, None, x)
                 assert out.tobytes() == want.tobytes(), (dt, geo, n, ncols, h)
-                if n > 100:   # C += A.X into a wider matrix (pygim_block_run's accumulate form)
-                    wide = np.ascontiguousarray(rng.integers(-5, 5, size=(n, h + 7)).astype(dt))
-                    before = wide.copy()
-                    _lib.block_run(hd, 0, x.ctypes.data, h, wide.ctypes.data, h + 7, h, True)
+                if n > 100:   # C += A.X into a wider matrix (pygim_block_run's accumulate form; device pointers)
+                    before = np.ascontiguousarray(rng.integers(-5, 5, size=(n, h + 7)).astype(dt))
+                    wide_d, x_d = torch.from_numpy(before.copy()).cuda(), torch.from_numpy(np.ascontiguousarray(x)).cuda()
+                    _lib.block_run(hd, 0, x_d.data_ptr(), h, wide_d.data_ptr(), h + 7, h, True)
+                    torch.cuda.synchronize()
+                    wide = wide_d.cpu().numpy()
                     if dt == np.float64:
                         assert np.array_equal(wide[:, :h], before[:, :h] + want) and np.array_equal(wide[:, h:], before[:, h:])
                     else:
