@@ -379,8 +379,10 @@ struct LdsCodeHost {
 constexpr uint32_t LDS_CODE_PK_ADD_U16 = 0xFFFFFFFFu;
 // 8-byte elements (geometry row_bytes = 512): v_add_f64 on register pairs; v_add_co_u32 + v_addc_co_u32
 constexpr uint32_t LDS_CODE_ADD_F64 = 0xFFFFFFFEu, LDS_CODE_ADD_U64 = 0xFFFFFFFDu;
+// experiment (timing only, WRONG results): bit 0 = no workgroup barriers, bit 1 = no chunk DMA (what the hand-offs / the fill cost:
+// 2.09 -> 1.81 / 1.63 / both 1.49 ms on the bench workload, profiles/r04_lds_kernel.md)
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
-                               uint32_t nsets = 0) {
+                               uint32_t nsets = 0, uint32_t experiment = 0) {
     const LdsGeometry &geo = plan.geo;
     const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
     const uint32_t RB = geo.row_bytes;
@@ -439,7 +441,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     s_add_lit(124 /* m0 */, Rr.s_ldsw, buf * chunk_bytes + (i / 4) * 0x1000);
                     e.op(0xBF800000u);                              // s_nop 0 (M0 write -> LDS-DMA)
                 }
-                e.op(0xDDF48000u | ((i % 4) * 1024), (Rr.s_pa << 16) | Rr.vl16);   // global_load_lds_dwordx4 vl16, s[pa:pa+1] offset
+                if (!(experiment & 2)) e.op(0xDDF48000u | ((i % 4) * 1024), (Rr.s_pa << 16) | Rr.vl16);   // global_load_lds_dwordx4 vl16, s[pa:pa+1] offset
             }
         };
         uint64_t at = (uint64_t)t.tokstart[wv] * B;
@@ -451,7 +453,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         std::vector<uint64_t> landed_mark(t.nch + NBUF + 1, 0);     // vm_now() right after the last piece of chunk j
         auto dma_chunk = [&](uint32_t j) {                          // chunk of slot j -> buffer j % NBUF
             dma(plan.chunks[t.chunk_off + j], j % NBUF);
-            dma_issued += pieces;
+            dma_issued += (experiment & 2) ? 0 : pieces;
             landed_mark[j] = vm_now();
         };
         auto wait_landed = [&](uint32_t j) {                        // s_waitcnt vmcnt(N): everything up to chunk j's last piece has landed
@@ -491,7 +493,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         if (t.nch) {
             for (uint32_t j = 0; j + 1 < NBUF && j < t.nch; j++) dma_chunk(j);
             wait_landed(0);
-            e.op(0xBF8A0000u);                                      // s_barrier
+            if (!(experiment & 1)) e.op(0xBF8A0000u);               // s_barrier
         }
         std::vector<uint64_t> toks;   // token | value << 32 (valued FLT32 matrices: the entry's value rides as a literal of its v_mul_f32)
         for (uint32_t j = 0; j < t.nch; j++) {
@@ -521,7 +523,9 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     wait_lgkm(lds_this_slot);
                     older_reads = false;
                 }
-                e.op(0xBF8A0000u);                                  // s_barrier
+                if (!(experiment & 1)) e.op(0xBF8A0000u);           // s_barrier
+                // (the pieces go out at once: letting the waves take turns behind the barrier -- wave w first reads w mod 2 / 4 / 8 more
+                // groups -- measured 2.15 / 2.13 / 2.11 ms against 2.06: the fill is on the critical path, earlier is better)
                 if (j + NBUF - 1 < t.nch) dma_chunk(j + NBUF - 1);
                 handoff_due = false;
             };
@@ -588,7 +592,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 wait_lgkm(0);
                 older_reads = false;
                 if (j + 1 < t.nch) wait_landed(j + 1);              // my pieces of the NEXT chunk have landed (younger loads may still fly)
-                e.op(0xBF8A0000u);                                  // s_barrier
+                if (!(experiment & 1)) e.op(0xBF8A0000u);           // s_barrier
             }
         }
         while (!pend.empty()) consume_oldest();

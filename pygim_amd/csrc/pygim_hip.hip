@@ -111,6 +111,7 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_code_exp = 0;           // (timing experiments, WRONG results) code streams without barriers (1) / without the chunk DMA (2)
     int64_t lds_fail = 0;               // (tests) force a step of the code-stream set-up to fail: 1 = code generation, 2 = executable memory, 4 = schedule build
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
 } g_tune;
@@ -1542,7 +1543,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
             lds_code_from_plan(plan, t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : t_plan_dtype == PYGIM_INT32 ? 0x68000000u : t_plan_dtype == PYGIM_DBL64 ? LDS_CODE_ADD_F64 :
                                      t_plan_dtype == PYGIM_INT64 ? LDS_CODE_ADD_U64 : LDS_CODE_PK_ADD_U16, ch,
                                (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
-                               (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets));
+                               (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_exp));
         } catch (const std::exception &e) {   // out of host memory or threads: the same schedule as a token plan (build_lds_plan)
             p.lds_note = std::string("code-stream form not available: generating the instruction streams failed (") + e.what() + ")";
             return -1;
@@ -2299,6 +2300,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
     else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
     else if (n == "lds_fail") slot = &g_tune.lds_fail;
+    else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
