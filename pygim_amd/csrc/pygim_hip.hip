@@ -1475,8 +1475,8 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         // requests of a CU never dry up (scripts/micro/fillrate.hip: 81 GB/s per CU with 2 x 80 KiB, 113 GB/s with 3 x 48 or 4 x 40 KiB)
         int64_t nbuf = g_tune.lds_code_nbuf;
         if (nbuf == 0) nbuf = geo.NW == 8 ? LDS_CODE8_AUTO_NBUF : 2;
-        nbuf = std::min<int64_t>(std::max<int64_t>(nbuf, 2), 8);
-        static const uint32_t kc_of[9] = {0, 0, 320, 192, 160, 128, 96, 64, 64};
+        nbuf = std::min<int64_t>(std::max<int64_t>(nbuf, 2), 10);
+        static const uint32_t kc_of[11] = {0, 0, 320, 192, 160, 128, 96, 64, 64, 64, 64};
         uint32_t kc = g_tune.lds_code_kc > 0 ? (uint32_t)g_tune.lds_code_kc : kc_of[nbuf] * 256 / geo.row_bytes;
         const uint32_t kq = 1024 * geo.NW / geo.row_bytes;                  // columns of one 1 KiB piece per wave
         kc = std::max(kq, kc / kq * kq);                                    // whole pieces per wave

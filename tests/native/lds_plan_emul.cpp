@@ -168,7 +168,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     LdsCodeHost ch;
     lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets);
     const LdsCodeRegs R = ch.regs;
-    if (R.nx() > 32 || NBUF > 8) return 14;
+    if (R.nx() > 32 || NBUF > 16) return 14;
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, RB = geo.row_bytes, chunk_bytes = KC * RB, RPB = 65536 / RB;
     const uint32_t nslices = (h + 63) / 64;
     if (stats) {
@@ -186,14 +186,14 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
             uint64_t barriers_w0 = 0;
             for (uint32_t w = 0; w < NW; w++) {
                 std::vector<T> acc((size_t)KA * 64, T(0));
-                int64_t buf_chunk[8] = {-1, -1, -1, -1, -1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
-                int64_t landed_chunk[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
-                bool dirty[8] = {false, false, false, false, false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
+                int64_t buf_chunk[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
+                int64_t landed_chunk[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
+                bool dirty[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
                 // a DMA may only go into a buffer that NOBODY reads any more: every wave issues the same DMAs between the same two
                 // barriers, so it is enough that this wave had no read of that buffer in flight at its last barrier and has issued
                 // none since
-                bool inflight_at_barrier[8] = {false, false, false, false, false, false, false, false};
-                bool read_since_barrier[8] = {false, false, false, false, false, false, false, false};
+                bool inflight_at_barrier[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+                bool read_since_barrier[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
                 uint64_t barriers = 0;
                 struct VLoad { int buf; int64_t cid; bool last; };
                 std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)

@@ -244,7 +244,7 @@ def _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize=0, nsets=0, r
 # (waves, columns per chunk, ring buffers, entries per group, x-register sets): round 3's two rings with the pipeline that now crosses
 # slot boundaries; the 8-wave geometry (228 accumulators per wave, 2 waves per SIMD) with two- and mid-slot-barrier rings
 CODE_GEOS = [(16, 320, 2, 8, 2), (16, 192, 3, 8, 2), (16, 192, 3, 6, 3), (8, 320, 2, 10, 2), (8, 192, 3, 10, 2), (8, 160, 4, 10, 2),
-             (8, 160, 4, 6, 3), (8, 128, 5, 6, 3), (8, 192, 3, 2, 2)]
+             (8, 160, 4, 6, 3), (8, 128, 5, 6, 3), (8, 192, 3, 2, 2), (8, 64, 10, 10, 2)]
 
 
 @pytest.mark.parametrize("geo", CODE_GEOS)
