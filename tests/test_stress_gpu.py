@@ -59,7 +59,11 @@ def test_random_configurations(seed):
              "panel_col16": int(rng.choice([0, 1])),
              # round 3: the LDS-staged product (INT32 / FLT32, rows of >= 33 features) in all its geometries, beside the others
              "lds_mode": int(rng.choice([0, 1, 1, 2])), "lds_waves": int(rng.choice([8, 16])),
-             "lds_long_slots": int(rng.choice([0, 1, 128])), "lds_round_tiles": int(rng.choice([0, 1]))}
+             "lds_long_slots": int(rng.choice([0, 1, 128])), "lds_round_tiles": int(rng.choice([0, 1])),
+             # round 4: the code-stream geometries (8 waves x 228 / 16 x 96 accumulators, rings of 2..6 buffers, read pipeline depth) for every
+             # element type that has the form (INT8 widened, INT64 / DBL64 as register pairs)
+             "lds_code": int(rng.choice([0, 1, 1, 1])), "lds_code_waves": int(rng.choice([0, 0, 8, 16])), "lds_code_nbuf": int(rng.choice([0, 0, 2, 3, 4, 5, 6])),
+             "lds_code_gsize": int(rng.choice([0, 0, 2, 4, 6])), "lds_code_nsets": int(rng.choice([0, 0, 2, 3]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
@@ -112,7 +116,8 @@ def test_random_groups(seed):
              "panel_col16": int(rng.choice([0, 1])), "merge_parts": int(rng.choice([0, 1])),
              "split_unit_pattern": int(rng.choice([0, 1])), "lds_mode": int(rng.choice([0, 1, 1, 2])),
              "lds_long_slots": int(rng.choice([0, 1, 128])), "narrow_vals": int(rng.choice([0, 1])),
-             "lds_code": int(rng.choice([0, 1, 1]))}
+             "lds_code": int(rng.choice([0, 1, 1])), "lds_code_waves": int(rng.choice([0, 0, 8, 16])), "lds_code_nbuf": int(rng.choice([0, 0, 2, 3, 4, 5])),
+             "lds_code_gsize": int(rng.choice([0, 0, 4])), "lds_code_nsets": int(rng.choice([0, 0, 3]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
