@@ -65,6 +65,10 @@ struct LdsGeometry {
     uint32_t ka_stride() const { return (KA + 7) & ~7u; }   // row-map entries per wave: the store stage reads the map eight rows at a time
     uint32_t row_bytes = 256;    // bytes of a staged row of X: 256 (64 features of 4 bytes, 128 of 2) or 512 (64 features of 8 bytes: INT64 / DBL64
                                  // code streams, round 4 -- ds_read_b64 per entry, a register PAIR per accumulator and per staged value)
+    uint32_t boundary = 0;       // code streams, rings of >= 3 buffers: 1 = the workgroup meets at the slot BOUNDARY (as a ring of two must): chunk
+                                 // j + NBUF - 1 is issued at the start of slot j, NBUF - 1 chunks are in flight while one is read -- one more than with
+                                 // the barrier in the middle of a slot -- at the price of draining the read pipeline once per slot: for plans whose
+                                 // workgroups mostly land chunks (few stored entries per staged column)
     uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
                                  // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
                                  // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
@@ -312,11 +316,14 @@ inline double lds_plan_uniform_reuse(uint64_t nnz, uint32_t nrows, uint32_t ncol
 //     (1 824 rows: the Reddit-shaped product of four slices is then TWO rounds of workgroups on 256 CUs instead of three, i.e. a third
 //     less of X streamed through LDS; 2 waves per SIMD with 256 VGPRs each).  The reads run NSETS - 1 groups of GSIZE entries ahead of
 //     the adds (x-register sets), and the pipeline is not drained at a slot boundary.
-//   * ring of two buffers (NBUF = 2): chunk j + 1 goes into the buffer chunk j - 1 was read from, so the workgroup meets at the slot
-//     boundary: all reads of the slot have returned, everybody's pieces of the next chunk have landed (round 3).
-//     Ring of three or more buffers: ONE barrier in the MIDDLE of slot j says "everybody is done with chunk j - 1 and has landed
-//     chunk j + 1"; behind it chunk j + NBUF - 1 is issued into the buffer of chunk j - 1.  Nobody waits at the slot boundary, the reads
-//     in flight cross it, and NBUF - 2 chunks are in flight while one is read.
+//   * BOUNDARY hand-off (any ring; the only one a ring of two allows; the default): the workgroup meets at the end of slot j -- all its
+//     reads of chunk j have returned, everybody's pieces of chunk j + 1 have landed -- and chunk j + NBUF is issued behind the first
+//     reads of the next slot, into the buffer of chunk j: NBUF - 1 chunks are in flight while one is read (ring of 5 x 128 columns: four,
+//     128 KiB), the last group's adds cross the barrier.
+//     MID-SLOT hand-off (rings of three or more buffers, geometry.boundary = 0): ONE barrier in the MIDDLE of slot j says "everybody is
+//     done with chunk j - 1 and has landed chunk j + 1"; behind it chunk j + NBUF - 1 is issued into the buffer of chunk j - 1.  Nobody
+//     waits at the slot boundary and the reads in flight cross it, but only NBUF - 2 chunks are in flight -- measured 1-2 % behind the
+//     boundary form on every shape (profiles/r04_lds_kernel.md).
 // Register contract with the kernel (scripts/gen_lds_kernel.py body_code): see LdsCodeRegs.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct LdsCodeRegs {
@@ -446,6 +453,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         };
         uint64_t at = (uint64_t)t.tokstart[wv] * B;
         const uint32_t NBUF = geo.NBUF;
+        const bool mid = NBUF >= 3 && !geo.boundary;                // where the workgroup meets: in the middle of a slot, or at its boundary
         // vector loads issued so far (DMA pieces and touches): the wait for "chunk j + 1 has landed" names how many YOUNGER loads may
         // still be in flight -- known when the code is generated (vmcnt retires in issue order)
         uint64_t dma_issued = 0;
@@ -497,10 +505,11 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         }
         std::vector<uint64_t> toks;   // token | value << 32 (valued FLT32 matrices: the entry's value rides as a literal of its v_mul_f32)
         for (uint32_t j = 0; j < t.nch; j++) {
-            // NBUF = 2: the DMA of chunk j + 1 (into the buffer the boundary barrier just freed) goes behind the slot's FIRST group of
-            // reads (their LDS latency covers its issue).  NBUF >= 3: the hand-off sits in the middle of the slot (below)
-            bool dma_due = NBUF == 2 && j + 1 < t.nch;
-            bool handoff_due = NBUF >= 3;
+            // boundary form (any ring): the DMA of chunk j + NBUF - 1 (into the buffer the boundary barrier just freed) goes behind the
+            // slot's FIRST group of reads (their LDS latency covers its issue; in front of them: 2.056 against 2.040 ms).
+            // mid-slot form (rings of >= 3 buffers): the hand-off sits in the middle of the slot (below)
+            bool dma_due = !mid && j + NBUF - 1 < t.nch;
+            bool handoff_due = mid;
             const uint32_t nb = plan.tok[at] >> LDS_HDR_SHIFT;
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
@@ -575,7 +584,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 pend.push_back(gcount % (NS + 1));
                 gcount++;
                 if (dma_due) {
-                    dma_chunk(j + 1);
+                    dma_chunk(j + NBUF - 1);
                     dma_due = false;
                 }
                 if (pend.size() >= NS) consume_oldest();            // frees the x-set the next group reads into
@@ -583,9 +592,9 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 gi++;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }
-            if (dma_due) dma_chunk(j + 1);                          // (a slot without entries for this wave)
+            if (dma_due) dma_chunk(j + NBUF - 1);                   // (a slot without entries for this wave)
             if (handoff_due) handoff();
-            if (NBUF == 2) {
+            if (!mid) {
                 // everybody's reads of this chunk have returned and everybody has landed the next before anybody goes on; the adds of
                 // the groups still in flight overlap the wait, the last group's adds cross the barrier
                 while (pend.size() > 1) consume_oldest();

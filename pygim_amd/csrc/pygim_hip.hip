@@ -111,6 +111,7 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_code_boundary = 0;      // rings of >= 3 buffers: 0 / 1 = the workgroup meets at the slot boundary (one more chunk in flight, the last group's adds cross the barrier), 2 = in the middle of a slot
     int64_t lds_code_exp = 0;           // (timing experiments, WRONG results) code streams without barriers (1) / without the chunk DMA (2)
     int64_t lds_fail = 0;               // (tests) force a step of the code-stream set-up to fail: 1 = code generation, 2 = executable memory, 4 = schedule build
     int64_t lds_ablate = 0;             // (timing experiments) 1..4: kernel variants with parts of the loop removed -- WRONG results
@@ -1483,6 +1484,9 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         while ((uint64_t)kc * geo.row_bytes * (uint64_t)nbuf > LDS_BYTES || kc * (uint32_t)nbuf > 640) kc -= kq;   // (the LDS; 10-bit LDS rows in a token)
         geo.KC = kc;
         geo.NBUF = (uint32_t)nbuf;
+        // measured (profiles/r04_lds_kernel.md): with five buffers the boundary form -- four chunks in flight -- is 1-2 % ahead of the mid-slot form on
+        // every shape tried (2.02-2.04 against 2.06 ms on the bench workload, DBL64 7.03 against 7.12): the default
+        geo.boundary = g_tune.lds_code_boundary == 2 ? 0u : 1u;
     }
     LdsPlanHost plan;
     try {
@@ -2301,6 +2305,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
     else if (n == "lds_fail") slot = &g_tune.lds_fail;
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
+    else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;

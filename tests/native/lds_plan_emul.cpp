@@ -139,7 +139,7 @@ extern "C" uint32_t lds_emul_rows_per_tile(uint32_t nrows, uint32_t rmax, uint32
 template <typename T>
 static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const T *X, uint32_t h, T *Cout,
                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const T *vals = nullptr, uint32_t col_splits = 1,
-                    uint32_t nw = 16, uint32_t gsize = 0, uint32_t nsets = 0, uint32_t rows_per_tile = 0) {
+                    uint32_t nw = 16, uint32_t gsize = 0, uint32_t nsets = 0, uint32_t rows_per_tile = 0, uint32_t boundary = 0) {
     const uint32_t nrows_real = nrows, S = col_splits ? col_splits : 1;
     std::vector<T> part;
     T *C = Cout;
@@ -156,6 +156,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     geo.row_bytes = WIDE ? 512 : 256;
     geo.BATCH = 8;
     geo.rows_per_tile = rows_per_tile;
+    geo.boundary = boundary;   // rings of >= 3 buffers: the workgroup meets at the slot boundary instead of in the middle of a slot
     geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
     geo.NBUF = nbuf;
     LdsPlanHost plan;
@@ -462,22 +463,22 @@ int lds_code_f32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, ui
 // ... with the geometry as arguments (round 4): waves per workgroup (16 x 96 or 8 x 228 accumulators), entries per group, x-register sets
 int lds_code_f32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const float *X, uint32_t h, float *C,
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const float *vals, uint32_t col_splits, uint32_t nw,
-                     uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
-    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits, nw, gsize, nsets, rows_per_tile);
+                     uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<float>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits, nw, gsize, nsets, rows_per_tile, boundary);
 }
 // 8-byte element types (INT64 / DBL64): the 8-wave geometry with 512-byte rows
 int lds_code_f64_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const double *X, uint32_t h, double *C,
-                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
-    return run_code<double>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile);
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<double>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile, boundary);
 }
 int lds_code_i64_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int64_t *X, uint32_t h, int64_t *C,
-                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile) {
-    return run_code<int64_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile);
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<int64_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, 8, gsize, nsets, rows_per_tile, boundary);
 }
 int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,
-                     uint32_t nsets, uint32_t rows_per_tile) {
-    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile);
+                     uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile, boundary);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits) {

@@ -77,6 +77,7 @@ int main(int argc, char **argv) {
         const auto &g = geos[rng() % (sizeof geos / sizeof geos[0])];
         const uint32_t splits = (rng() % 5 == 0) ? 2 + (uint32_t)(rng() % 3) : 1;
         const uint32_t rpt = (rng() % 4 == 0) ? 16 + (uint32_t)(rng() % 1500) : 0;
+        const uint32_t bnd = (uint32_t)(rng() % 2);   // rings of >= 3 buffers: meet in the middle of a slot, or at its boundary
         uint64_t stats[4];
         if (c % 2 == 0) {
             std::vector<float> x((size_t)ncols * h), out((size_t)nrows * h, 77.f), vals;
@@ -87,7 +88,7 @@ int main(int argc, char **argv) {
                 for (auto &v : vals) v = (float)((int64_t)(rng() % 5) - 2);
             }
             const int rc = lds_code_f32_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, g[1], g[2], valued ? vals.data() : nullptr,
-                                            splits, g[0], g[3], g[4], rpt);
+                                            splits, g[0], g[3], g[4], rpt, bnd);
             if (rc) { printf("case %d: interpreter code %d (geo %u %u %u %u %u, %u x %u, h %u)\n", c, rc, g[0], g[1], g[2], g[3], g[4], nrows, ncols, h); return 1; }
             if (out != reference<float>(m, nrows, x, h, valued ? vals.data() : nullptr)) { printf("case %d: result differs\n", c); return 2; }
             std::vector<float> out2((size_t)nrows * h, 77.f);
@@ -97,7 +98,7 @@ int main(int argc, char **argv) {
         } else {
             std::vector<int32_t> x((size_t)ncols * h), out((size_t)nrows * h, 77);
             for (auto &v : x) v = (int32_t)rng();
-            const int rc = lds_code_i32_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, g[1], g[2], splits, g[0], g[3], g[4], rpt);
+            const int rc = lds_code_i32_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, g[1], g[2], splits, g[0], g[3], g[4], rpt, bnd);
             if (rc) { printf("case %d: interpreter code %d (geo %u %u %u %u %u, %u x %u, h %u)\n", c, rc, g[0], g[1], g[2], g[3], g[4], nrows, ncols, h); return 1; }
             if (out != reference<int32_t>(m, nrows, x, h, nullptr)) { printf("case %d: result differs\n", c); return 2; }
         }

@@ -35,7 +35,7 @@ def lds_forced():
     _lib.set_tunable("lds_long_slots", 128)
     _lib.set_tunable("lds_round_tiles", 1)
     _lib.set_tunable("lds_code", 1)
-    for k in ("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets"):
+    for k in ("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets", "lds_code_boundary"):
         _lib.set_tunable(k, 0)
 
 
@@ -387,8 +387,9 @@ def test_short_row_shares_split_their_tiles_into_column_ranges(rng, lds_forced, 
 
 # (waves, ring buffers, columns per chunk, staged columns per group, x-register sets) -- the knobs of the code-stream plan, round 4:
 # 8 waves x 228 accumulators (k_lds_code8_*), rings of 3 / 4 / 5 buffers with the barrier in the middle of a slot, deeper read pipelines
-CODE_GEOS = [(16, 2, 0, 0, 0), (16, 3, 0, 0, 0), (16, 3, 192, 6, 3), (8, 2, 0, 0, 0), (8, 3, 0, 0, 0), (8, 4, 0, 0, 0), (8, 4, 160, 6, 3),
-             (8, 5, 0, 0, 0), (8, 6, 0, 0, 0), (8, 3, 64, 2, 2), (16, 4, 128, 8, 2)]
+# (+ where the workgroup meets when the ring has three or more buffers: 0 = at the slot boundary, the default; 2 = in the middle of a slot)
+CODE_GEOS = [(16, 2, 0, 0, 0, 0), (16, 3, 0, 0, 0, 0), (16, 3, 192, 6, 3, 2), (8, 2, 0, 0, 0, 0), (8, 3, 0, 0, 0, 2), (8, 4, 0, 0, 0, 0), (8, 4, 160, 6, 3, 2),
+             (8, 5, 0, 0, 0, 0), (8, 5, 0, 0, 0, 2), (8, 6, 0, 0, 0, 0), (8, 3, 64, 2, 2, 0), (16, 4, 128, 8, 2, 2), (8, 10, 64, 4, 3, 0)]
 
 
 @pytest.mark.parametrize("geo", CODE_GEOS)
@@ -396,7 +397,7 @@ def test_code_stream_geometries_are_bit_exact(rng, lds_forced, geo):
     """tests/test_lds_plan.py runs these plans through the CPU interpreter; here the same plans run on the GPU (k_lds_code_* / k_lds_code8_*)
     against the oracle's loop: FLT32 bit-identical (every row summed by one wave in stored order, whatever the geometry), INT32 modular,
     INT16 two features to a lane, and the valued FLT32 form"""
-    for k, v in zip(("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets"), geo):
+    for k, v in zip(("lds_code_waves", "lds_code_nbuf", "lds_code_kc", "lds_code_gsize", "lds_code_nsets", "lds_code_boundary"), geo):
         _lib.set_tunable(k, v)
     for dt in (np.float32, np.int32):
         for n, ncols, h, avg in ((1, 1, 64, 1), (300, 700, 64, 12), (3000, 2500, 100, 12), (1700, 5000, 256, 11), (5000, 300, 65, 40),

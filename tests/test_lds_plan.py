@@ -225,7 +225,7 @@ def test_column_split_tiles(emul, splits):
         assert got.tobytes() == ref.tobytes(), kc
 
 
-def _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize=0, nsets=0, rows_per_tile=0, threads=4, vals=None, splits=1):
+def _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize=0, nsets=0, rows_per_tile=0, threads=4, vals=None, splits=1, boundary=0):
     nrows = len(rowptr) - 1
     h = x.shape[1]
     out = np.full((nrows, h), 77, dtype=x.dtype)
@@ -236,7 +236,7 @@ def _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize=0, nsets=0, r
     rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
             out.ctypes.data_as(ctypes.c_void_p), threads, stats, kc, nbuf,
             *(() if x.dtype != np.float32 else (None if vals is None else np.ascontiguousarray(vals, np.float32).ctypes.data_as(ctypes.c_void_p),)),
-            splits, nw, gsize, nsets, rows_per_tile)
+            splits, nw, gsize, nsets, rows_per_tile, boundary)
     assert rc == 0, f"the interpreter rejected the code stream (code {rc}) for nw={nw} kc={kc} nbuf={nbuf} g={gsize} ns={nsets}"
     return out, list(stats)
 
@@ -262,9 +262,10 @@ def test_code_stream_geometries(emul, geo, dtype):
         else:
             x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
         want = oracle.spmm_csr(rowptr, col, None, x)
-        got, stats = _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize, nsets, rows_per_tile=rpt)
-        assert got.tobytes() == want.tobytes(), (geo, nrows)
-        assert stats[2] == len(col)
+        for boundary in ((0, 1) if nbuf >= 3 else (0,)):   # the workgroup meets in the middle of a slot, or at its boundary
+            got, stats = _run_code_geo(emul, rowptr, col, ncols, x, nw, kc, nbuf, gsize, nsets, rows_per_tile=rpt, boundary=boundary)
+            assert got.tobytes() == want.tobytes(), (geo, nrows, boundary)
+            assert stats[2] == len(col)
 
 
 @pytest.mark.parametrize("geo", [(8, 160, 4, 10, 2), (8, 192, 3, 6, 3), (16, 192, 3, 8, 2)])
@@ -321,7 +322,7 @@ def test_code_stream_of_8_byte_elements(emul, geo, dtype):
         stats = (ctypes.c_uint64 * 4)()
         rp, ci, xx = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32), np.ascontiguousarray(x)
         rc = fn(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, xx.ctypes.data_as(ctypes.c_void_p), h,
-                out.ctypes.data_as(ctypes.c_void_p), 4, stats, kc, nbuf, splits, gsize, nsets, rpt)
+                out.ctypes.data_as(ctypes.c_void_p), 4, stats, kc, nbuf, splits, gsize, nsets, rpt, nrows % 2)
         assert rc == 0, f"the interpreter rejected the code stream (code {rc}) for {geo} {nrows} x {ncols}"
         assert out.tobytes() == want.tobytes(), (geo, dtype, nrows)
         assert stats[2] == len(col)

@@ -63,7 +63,7 @@ def test_random_configurations(seed):
              # round 4: the code-stream geometries (8 waves x 228 / 16 x 96 accumulators, rings of 2..6 buffers, read pipeline depth) for every
              # element type that has the form (INT8 widened, INT64 / DBL64 as register pairs)
              "lds_code": int(rng.choice([0, 1, 1, 1])), "lds_code_waves": int(rng.choice([0, 0, 8, 16])), "lds_code_nbuf": int(rng.choice([0, 0, 2, 3, 4, 5, 6])),
-             "lds_code_gsize": int(rng.choice([0, 0, 2, 4, 6])), "lds_code_nsets": int(rng.choice([0, 0, 2, 3]))}
+             "lds_code_gsize": int(rng.choice([0, 0, 2, 4, 6])), "lds_code_nsets": int(rng.choice([0, 0, 2, 3])), "lds_code_boundary": int(rng.choice([0, 2]))}
     old = {k: _lib.set_tunable(k, v) for k, v in knobs.items()}
     try:
         x = driver_features(rng, ncols, h, npdt)
