@@ -46,11 +46,30 @@ LDS_READ_B32_TBS = 256 * 128 * 2.4e9 / 1e12  # ds_read_b32: 128 B/clk per CU (MI
 from pygim_amd.bench_plans import nnz_balanced_row_split  # noqa: E402,F401  (tests import it from here)
 
 
+def cpu_quota():
+    """CPUs this process may really use: the cgroup quota when there is one (the pool's GPU boxes show 256 CPUs and grant 16), else
+    the CPUs of its affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(rowptr, col, x, args):
     """The oracle's row-parallel loop (kind 'port') on a bounded row sample of the same graph."""
     import oracle
 
-    threads = oracle.max_threads()
+    threads = max(1, min(oracle.max_threads(), cpu_quota()))   # as many threads as the container has CPUs of quota (more only contend)
     nrows = rowptr.numel() - 1 if args.cpu_rows <= 0 else min(args.cpu_rows, rowptr.numel() - 1)
     rp = rowptr[: nrows + 1].cpu().numpy().astype(np.uint32)
     nnz = int(rp[-1])
@@ -89,7 +108,8 @@ def cpu_baseline(rowptr, col, x, args):
                 break
     except OSError:
         pass
-    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port", "cpu_model": model,
+    # "cores" = the threads the loop ran with; what they share is the container's CPU quota, stated beside it
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "cpu_quota_cpus": cpu_quota(), "kind": "port", "cpu_model": model,
             "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"), "library": lib,
             "sample": f"rows [0,{nrows}) of the same graph ({nnz} nnz, h={xh.shape[1]}), "
                       f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
@@ -107,7 +127,7 @@ def self_launch(n_gpus):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_gpus, 1))))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_quota() // max(n_gpus, 1))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "--max-restarts", "0", os.path.abspath(__file__)] + sys.argv[1:]
     # the children run in a process group of their own: a hung rank (a collective that never completes) is ended -- that group,
@@ -195,7 +215,7 @@ def main():
     if world > 1:
         # every rank builds its plans with its share of the host's cores: the schedule builder starts one thread per core by default,
         # which on an 8-rank node would be 8 x all cores at once, each rank holding its blobs
-        _lib.set_tunable("lds_threads", max(1, (os.cpu_count() or 8) // world))
+        _lib.set_tunable("lds_threads", max(1, cpu_quota() // world))
 
     class TimedLib:
         """pygim_amd._lib with group creation timed (what a rank paid for its plans, printed per rank below)"""
@@ -374,7 +394,7 @@ def main():
         return {"kernel": "k_csr_panel (L2 sweep)", "code_bytes": 0, "tiles": 0, "col_splits": 1, "note": _lib.group_lds_note(hd)}
 
     fams = [kernel_family(hd) for hd in handles]
-    mine = {"rank": rank, "groups_created": tlib.created, "group_create_ms": round(tlib.create_ms, 1), "plan_threads": max(1, (os.cpu_count() or 8) // world) if world > 1 else "all",
+    mine = {"rank": rank, "groups_created": tlib.created, "group_create_ms": round(tlib.create_ms, 1), "plan_threads": max(1, cpu_quota() // world) if world > 1 else f"all ({cpu_quota()} CPUs of quota)",
             "groups": fams}
     print(f"[bench] rank {rank}: {json.dumps(mine)}", file=sys.stderr, flush=True)
     per_rank = [mine]
@@ -597,7 +617,7 @@ def main():
                 nr = cpu_out.shape[0]
                 ref = np.zeros((nr, h), dtype=np.float32)
                 oracle.spmm_csr_rowpar(rowptr[: nr + 1].cpu().numpy().astype(np.uint32), col[: int(rowptr[nr])].cpu().numpy().astype(np.uint32),
-                                       None, xr.cpu().numpy(), nthreads=oracle.max_threads(), out=ref)
+                                       None, xr.cpu().numpy(), nthreads=max(1, min(oracle.max_threads(), cpu_quota())), out=ref)
                 got_r = cr[:nr].cpu().numpy().astype(np.float64)
                 err = np.abs(got_r - ref.astype(np.float64))
                 mag = np.abs(ref.astype(np.float64))

@@ -31,6 +31,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 #include <vector>
@@ -88,8 +91,32 @@ struct LdsPlanHost {
 
 // runs fn(i) for i in [0, n) on `threads` threads; an exception in a worker is carried to the caller (a std::thread body that
 // throws would end the process)
+// host threads worth starting: the hardware's, or the container's CPU quota when that is lower (cgroup v2 cpu.max / v1 cfs quota: the GPU
+// boxes of this pool show 256 CPUs and grant 16 -- 256 workers then take longer than 16)
+inline unsigned lds_default_threads() {
+    static const unsigned cached = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) != 1) period = 100000;
+                fclose(h);
+            }
+        }
+        if (quota > 0 && period > 0) hw = (unsigned)std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+        return hw;
+    }();
+    return cached;
+}
+
 template <typename F> inline void lds_parallel_for(uint32_t n, unsigned threads, F &&fn) {
-    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    if (threads == 0) threads = lds_default_threads();
     threads = std::min<unsigned>(threads, std::max(1u, n));
     std::atomic<uint32_t> next(0);
     std::atomic<bool> failed(false);
@@ -372,8 +399,21 @@ constexpr uint32_t LDS_CODE_AUTO_WAVES = 8, LDS_CODE8_AUTO_NBUF = 5;
 constexpr uint32_t LDS_CODE8_KA64 = 114;  // ... of its 8-byte form: a register pair per accumulator
 constexpr uint32_t LDS_CODE8_KA = 228;   // accumulators per wave of the 8-wave code-stream geometry (v28..v255)
 
+// a plain array of words that is NOT value-initialised (a std::vector would write the 1 GB of a Reddit-sized code blob once before the
+// streams are copied into it)
+struct LdsWords {
+    std::unique_ptr<uint32_t[]> p;
+    size_t n = 0;
+    void alloc(size_t words) { p.reset(new uint32_t[words]); n = words; }
+    uint32_t *data() { return p.get(); }
+    const uint32_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+    uint32_t &operator[](size_t i) { return p[i]; }
+    const uint32_t &operator[](size_t i) const { return p[i]; }
+};
+
 struct LdsCodeHost {
-    std::vector<uint32_t> code;          // all streams, each 256-byte aligned, + slack behind the last (the touches read ahead)
+    LdsWords code;                       // all streams, each 256-byte aligned, + slack behind the last (the touches read ahead)
     std::vector<uint64_t> start;         // [ntiles][NW]: byte offset of a (tile, wave) stream
     uint64_t entries = 0;                // stored entries compiled (no padding)
     uint64_t pairs = 0;                  // of which read two to an LDS instruction
@@ -413,12 +453,19 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     // 17.7 GB per product and an L2 hit rate of 80 %.)
     constexpr uint32_t TOUCH_EVERY_DW = 256;
 
+    // the instruction words of a stream go straight to their place in the final blob; a first pass with out == nullptr only counts them
+    // (two passes over the schedule instead of one: cheaper than 1 GB of per-stream vectors, their page faults and the copy)
     struct Emit {
-        std::vector<uint32_t> w;
+        uint32_t *out = nullptr;
+        size_t n = 0;
         uint32_t since_touch = 0;
         uint64_t vm_touch = 0;             // touches emitted (vector loads, counted into vmcnt)
-        void op(uint32_t a) { w.push_back(a); since_touch++; }
-        void op(uint32_t a, uint32_t b) { w.push_back(a); w.push_back(b); since_touch += 2; }
+        void put(uint32_t a) {
+            if (out) out[n] = a;
+            n++;
+        }
+        void op(uint32_t a) { put(a); since_touch++; }
+        void op(uint32_t a, uint32_t b) { put(a); put(b); since_touch += 2; }
     };
     struct Grp {                           // a group of up to GSIZE staged columns whose reads have been issued, and the entries they serve
         uint32_t nx = 0, nlds = 0, xb = 0;
@@ -504,6 +551,10 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             if (!(experiment & 1)) e.op(0xBF8A0000u);               // s_barrier
         }
         std::vector<uint64_t> toks;   // token | value << 32 (valued FLT32 matrices: the entry's value rides as a literal of its v_mul_f32)
+        std::vector<uint64_t> toks2;
+        std::vector<uint32_t> keys;
+        struct Col { uint32_t row, first, cnt; };
+        std::vector<Col> cols;        // (re-used: no allocation per slot -- 256 threads in malloc were most of the creation time)
         for (uint32_t j = 0; j < t.nch; j++) {
             // boundary form (any ring): the DMA of chunk j + NBUF - 1 (into the buffer the boundary barrier just freed) goes behind the
             // slot's FIRST group of reads (their LDS latency covers its issue; in front of them: 2.056 against 2.040 ms).
@@ -520,7 +571,18 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             // by staged column (stable): every row's entries are in column order already, so each row's order is kept; entries of
             // different rows of this wave that share a column now sit side by side and share ONE read (8 waves x 228 rows: a fifth of
             // the entries of a uniform Reddit-shaped slot), and neighbours are in the same 256-row LDS block: they pair up
-            std::stable_sort(toks.begin(), toks.end(), [](uint64_t a, uint64_t b) { return ((uint32_t)a >> 8) < ((uint32_t)b >> 8); });
+            // (std::stable_sort allocates a merge buffer per call -- 1.9 M calls from 256 threads; the order is made total instead: LDS row,
+            // then position in the list, in one 32-bit key, sorted in place)
+            if (toks.size() < 65536) {
+                keys.resize(toks.size());
+                for (uint32_t q = 0; q < toks.size(); q++) keys[q] = (((uint32_t)toks[q] >> 8) << 16) | q;
+                std::sort(keys.begin(), keys.end());
+                toks2.resize(toks.size());
+                for (uint32_t q = 0; q < toks.size(); q++) toks2[q] = toks[keys[q] & 0xFFFFu];
+                toks.swap(toks2);
+            } else {
+                std::stable_sort(toks.begin(), toks.end(), [](uint64_t a, uint64_t b) { return ((uint32_t)a >> 8) < ((uint32_t)b >> 8); });
+            }
             n_entries += toks.size();
             lds_this_slot = 0;
             older_reads = !pend.empty();
@@ -539,8 +601,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 handoff_due = false;
             };
             // the staged columns of the slot: (LDS row, first entry, entries); valued matrices: one per entry
-            struct Col { uint32_t row, first, cnt; };
-            std::vector<Col> cols;
+            cols.clear();
             for (uint32_t q = 0; q < toks.size(); q++) {
                 const uint32_t r = (uint32_t)toks[q] >> 8;
                 if (!valued && !cols.empty() && cols.back().row == r) cols.back().cnt++;
@@ -601,37 +662,44 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 wait_lgkm(0);
                 older_reads = false;
                 if (j + 1 < t.nch) wait_landed(j + 1);              // my pieces of the NEXT chunk have landed (younger loads may still fly)
-                if (!(experiment & 1)) e.op(0xBF8A0000u);           // s_barrier
+                if (!(experiment & 1)) e.op(0xBF8A0000u);           // s_barrier (timing experiments: only every 2nd / 4th / none: 1.97 / 1.93 / 1.81 ms against 2.04)
             }
         }
         while (!pend.empty()) consume_oldest();
         e.op(0xBF8C0F70u);                                          // s_waitcnt vmcnt(0): no touch is left in flight
         e.op(0xBE801D00u | Rr.s_ret);                               // s_setpc_b64 s[ret:ret+1]
-        while (e.w.size() % 64) e.w.push_back(0xBF800000u);         // streams start on 256-byte lines
+        while (e.n % 64) e.put(0xBF800000u);                         // streams start on 256-byte lines
     };
 
     const uint32_t nstreams = ntiles * NW;
-    std::vector<std::vector<uint32_t>> blobs(nstreams);
-    std::vector<uint64_t> ne(nstreams, 0), np(nstreams, 0), nsh(nstreams, 0);
-    lds_parallel_for(nstreams, threads, [&](uint32_t s) {
+    std::vector<uint64_t> ne(nstreams, 0), np(nstreams, 0), nsh(nstreams, 0), words(nstreams, 0);
+    // (one pass into per-stream vectors and a copy was measured at 1.8-2.0 s for the Reddit-sized graph against 0.72-0.78 s for the two
+    // passes below, on the pool's boxes: 16 CPUs of quota, and page faults on 1 GB of fresh vectors)
+    lds_parallel_for(nstreams, threads, [&](uint32_t s) {   // pass 1: sizes
         Emit e;
-        emit_stream(s / NW, s % NW, e, ne[s], np[s], nsh[s]);
-        blobs[s].swap(e.w);
+        uint64_t a = 0, b = 0, c = 0;
+        emit_stream(s / NW, s % NW, e, a, b, c);
+        words[s] = e.n;
     });
     out.start.assign(nstreams, 0);
     uint64_t total = 0;
     for (uint32_t s = 0; s < nstreams; s++) {
         out.start[s] = total * 4;
-        total += blobs[s].size();
+        total += words[s];
+    }
+    out.code.alloc((size_t)total + 8192);                           // (+ 32 KB of s_nop behind the last stream: touches read ahead)
+    std::fill(out.code.data() + total, out.code.data() + total + 8192, 0xBF800000u);
+    lds_parallel_for(nstreams, threads, [&](uint32_t s) {   // pass 2: the words, in place
+        Emit e;
+        e.out = out.code.data() + out.start[s] / 4;
+        emit_stream(s / NW, s % NW, e, ne[s], np[s], nsh[s]);
+        if (e.n != words[s]) throw std::runtime_error("lds code: the two passes over a stream disagree");
+    });
+    for (uint32_t s = 0; s < nstreams; s++) {
         out.entries += ne[s];
         out.pairs += np[s];
         out.shared += nsh[s];
     }
-    out.code.assign((size_t)total + 8192, 0xBF800000u);             // (+ 32 KB of s_nop behind the last stream: touches read ahead)
-    lds_parallel_for(nstreams, threads, [&](uint32_t s) {
-        std::copy(blobs[s].begin(), blobs[s].end(), out.code.begin() + out.start[s] / 4);
-        std::vector<uint32_t>().swap(blobs[s]);
-    });
 }
 
 }  // namespace pygim

@@ -1211,6 +1211,7 @@ void plan_long_rows(const uint32_t *rowptr, int64_t nrows, uint32_t thresh, uint
 // L2-blocked panel plan.  Replaces the reference's prepare_pim_csr/prepare_pim_coo balancing
 // (spmm_mul_csr.c:118-259) -- same purpose, different machine.
 int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint);
+double now_ms();
 static thread_local int t_plan_dtype = -1;   // element type of the group being created (the plan builders see the element SIZE only)
 
 int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0, bool allow_lds = true) {
@@ -1389,6 +1390,15 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
 
 static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint,
                                bool allow_code) {   // (es by value: INT8 plans are made as INT16 plans)
+    // PYGIM_PLAN_TIMING=1: where the creation time of an LDS-staged plan goes (stderr; the reference prints its own prepare / load times)
+    static const bool plan_timing = getenv("PYGIM_PLAN_TIMING") != nullptr;
+    double t_mark = now_ms();
+    auto lap = [&](const char *what) {
+        if (!plan_timing) return;
+        const double t = now_ms();
+        fprintf(stderr, "[pygim plan] %-34s %8.1f ms\n", what, t - t_mark);
+        t_mark = t;
+    };
     const bool int8_code = es == 1 && t_plan_dtype == PYGIM_INT8 && !p.vals && allow_code && g_tune.lds_code && g_tune.lds_waves == 16 && g_tune.lds_code_waves != 16;
     if (es == 1) {   // INT8: the 8-wave INT16 code stream on features widened to 16 bits (no token form, no 16-wave form)
         if (!int8_code) return 0;
@@ -1459,6 +1469,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     if (!p.cols_sorted) return 0;  // stored order inside a row must be column order for the chunk walk
     std::vector<uint32_t> h_col((size_t)p.nnz);
     if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
+    lap("sortedness check + column ids D2H");
     std::vector<uint32_t> h_val;
     if (p.vals) {
         h_val.resize((size_t)p.nnz);
@@ -1497,6 +1508,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         p.lds_note = std::string("the schedule of the LDS-staged product could not be built (") + e.what() + "): the L2 sweep serves this group";
         return 0;
     }
+    lap("schedule (tiles, tokens)");
     // long slots (a community-structured graph: a tile streams few chunks, a wave gets hundreds of tokens per chunk): the per-batch
     // bookkeeping is what is left to save -- the 16-token-batch geometry, when the tiles fit its 80 accumulators per wave
     if (geo.NW == 16 && !p.vals && !want_code && g_tune.lds_long_slots && plan.slots > 0 &&
@@ -1552,6 +1564,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
             p.lds_note = std::string("code-stream form not available: generating the instruction streams failed (") + e.what() + ")";
             return -1;
         }
+        lap("code generation");
         std::vector<uint32_t>().swap(plan.tok);
         std::string why_exec;
         void *code = (g_tune.lds_fail & 2) ? nullptr : exec_alloc_upload(ch.code.data(), ch.code.size() * 4, &why_exec);
@@ -1564,6 +1577,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
             (void)hsa_amd_memory_pool_free(code);
             return fail(PYGIM_ERR_HIP, "code-stream plan upload");
         }
+        lap("code + tables upload");
         p.lds_code = (char *)code;
         p.lds_code_bytes = ch.code.size() * 4;
         p.lds_code_pairs = ch.pairs;
