@@ -55,3 +55,18 @@ def test_missing_extension_is_an_import_error(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpygim_hip.so")
     with pytest.raises(ImportError):
         _lib.lib()
+
+
+def test_introspection_entry_points_reject_bad_arguments():
+    """the plan introspection added in round 4 (pygim_group_lds_geometry / _note): an unknown handle is an error with a message, never
+    a crash; a zero-capacity buffer is refused (no device needed: the handle table is empty either way)"""
+    import ctypes
+
+    L = _lib.lib()
+    out = (ctypes.c_int64 * 8)()
+    assert L.pygim_group_lds_geometry(ctypes.c_int64(123456789), out) != 0
+    assert b"handle" in L.pygim_last_error()
+    buf = ctypes.create_string_buffer(16)
+    assert L.pygim_group_lds_note(ctypes.c_int64(123456789), buf, ctypes.c_int64(16)) != 0
+    assert L.pygim_group_lds_note(ctypes.c_int64(123456789), buf, ctypes.c_int64(0)) != 0
+    assert _lib.set_tunable("lds_code_boundary", 0) >= 0 and _lib.set_tunable("lds_fail", 0) == 0 and _lib.set_tunable("no_such_knob", 1) == -1

@@ -522,3 +522,20 @@ def test_8_byte_elements_on_their_code_stream(rng, lds_forced, dt):
                         assert np.array_equal(wide[:, :h], (before[:, :h].astype(np.uint64) + want.astype(np.uint64)).astype(np.int64)) and np.array_equal(wide[:, h:], before[:, h:])
             finally:
                 _lib.group_free(hd)
+
+
+def test_the_note_is_truncated_to_the_callers_buffer(rng, lds_forced):
+    """pygim_group_lds_note writes at most cap - 1 characters and a terminating NUL"""
+    import ctypes
+
+    rowptr, col = random_csr(rng, 500, 400, 10)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rp.ctypes.data], [ci.ctypes.data], None, [500], [400], [len(ci)], [1], [64], 64)
+    try:
+        full = _lib.group_lds_note(hd)
+        assert full == "code-stream form"
+        buf = (ctypes.c_char * 8)(*([b"\xff"] * 8))
+        assert _lib.lib().pygim_group_lds_note(ctypes.c_int64(hd), buf, ctypes.c_int64(5)) == 0
+        assert buf.raw[:5] == b"code\x00" and buf.raw[5:] == b"\xff" * 3
+    finally:
+        _lib.group_free(hd)
