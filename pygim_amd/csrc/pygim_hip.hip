@@ -801,7 +801,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     constexpr uint32_t ROWB = EL8 ? 512 : 256;             // bytes of a staged row
     constexpr uint32_t EPS = WIDE8 ? 128 : ROWB / sizeof(T);   // elements of a slice
     constexpr int PVEC = WIDE8 ? 8 : 16 / (int)sizeof(T);
-    const uint32_t w_lanes = (WIDE8 || EL8) ? w : (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);   // (INT8: the kernel masks features one by one; 8-byte: a lane = a feature)
+    // (INT8, and the dequantising INT16 store: the kernel masks features one by one; 8-byte: a lane = a feature)
+    const uint32_t w_lanes = (WIDE8 || EL8 || (sizeof(T) == 2 && deq_amax)) ? w : (uint32_t)(((size_t)w * sizeof(T) + 3) / 4);
     const uint32_t nslices = (w + EPS - 1) / EPS;
     const uint64_t rows_pad = lds_rows_pad((uint64_t)p.ncols, p.lds_kc);
     const size_t need = (size_t)rows_pad * nslices * ROWB;
@@ -861,7 +862,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.xs = (const char *)xs_use;
     a.c = (char *)C;
     a.slice_stride = rows_pad * ROWB;
-    a.ldc_bytes = (uint32_t)((size_t)ldc * ((WIDE8 && deq_amax) ? 4 : sizeof(T)));   // (the dequantising store writes floats)
+    a.ldc_bytes = (uint32_t)((size_t)ldc * (((WIDE8 || sizeof(T) == 2) && deq_amax) ? 4 : sizeof(T)));   // (the dequantising store writes floats)
     a.w = w_lanes;
     a.nslices = nslices;
     a.ntiles = p.lds_ntiles;
@@ -901,8 +902,8 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             if (!w8 || accumulate || S > 1) return fail(PYGIM_ERR_INVALID, "internal: INT8 LDS-staged product on an unsupported plan");
             fn = deq_amax ? k_lds_code8_i8_deq : k_lds_code8_i8;   // (widened to 16 bits in the staged copy: the INT16 stream)
         } else if constexpr (sizeof(T) == 2) {
-            if (deq_amax) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
-            fn = w8 ? k_lds_code8_i16 : k_lds_code_i16;   // (two features to a lane: v_pk_add_u16)
+            if (deq_amax && (!w8 || S > 1)) return fail(PYGIM_ERR_INVALID, "internal: dequantising LDS-staged product on an unsupported plan");
+            fn = deq_amax ? k_lds_code8_i16_deq : (w8 ? k_lds_code8_i16 : k_lds_code_i16);   // (two features to a lane: v_pk_add_u16)
         } else if constexpr (std::is_same<T, float>::value) {
             fn = deq_amax ? (w8 ? k_lds_code8_f32_deq : k_lds_code_f32_deq) : (w8 ? k_lds_code8_f32 : k_lds_code_f32);
         } else {
@@ -2058,8 +2059,8 @@ static Part *fusable_part(Group *g) {
 // (INT32 / FLT32 adjacency types; the per-column epilogue, if any, is applied in the same store)
 template <typename T>
 static Part *lds_fusable_part(Group *g) {
-    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int8_t>::value)) return nullptr;
-    if (!g->all_ones || g_tune.lds_mode == 2 || (int64_t)g->h / (sizeof(T) == 1 ? 2 : 1) < g_tune.lds_min_width) return nullptr;
+    if constexpr (!(std::is_same<T, float>::value || std::is_same<T, int32_t>::value || std::is_same<T, int8_t>::value || std::is_same<T, int16_t>::value)) return nullptr;
+    if (!g->all_ones || g_tune.lds_mode == 2 || (int64_t)g->h / (sizeof(T) <= 2 ? 2 : 1) < g_tune.lds_min_width) return nullptr;
     if (g_tune.lds_mode == 0 && (g_tune.panel_mode != 0 || g_tune.csr_kernel != 0 || g_tune.force_vec_bytes != 0 || !g_tune.fuse_windows)) return nullptr;
     Part *p = nullptr;
     if (g->parts.size() == 1) p = &g->parts[0];
@@ -2067,7 +2068,7 @@ static Part *lds_fusable_part(Group *g) {
     if (!p || p->vals || p->extra || !p->lds_tiles || p->lds_wdelta || (p->lds_nw != 16 && !p->lds_is_code) || p->nrows == 0 || p->ncols == 0) return nullptr;
     if (p->lds_is_code && (!g_tune.lds_code || g_tune.lds_ablate)) return nullptr;
     if (p->lds_col_splits > 1) return nullptr;   // (partial sums per column range cannot be dequantised in the store)
-    if (sizeof(T) == 1 && (!p->lds_is_code || p->lds_nw != 8)) return nullptr;
+    if (sizeof(T) <= 2 && (!p->lds_is_code || p->lds_nw != 8)) return nullptr;   // (INT8 / INT16: the 8-wave code stream's dequantising stores)
     return p;
 }
 
@@ -2089,7 +2090,7 @@ static int quant_run_t(Group *g, const float *X, int64_t ldx, float *out, float 
     hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, amax);
     if (int rc = launch_absmax(X, ldx, rows, h, amax, st)) return rc;
     if (rows * h == 0 && scale_out) hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, st, (uint32_t *)scale_out);
-    if constexpr (sizeof(T) == 4 || sizeof(T) == 1) {
+    if constexpr (sizeof(T) == 4 || sizeof(T) <= 2) {
         if (Part *p = lds_fusable_part<T>(g)) {
             // FUSED on the LDS-staged kernel: the 256-byte-slice copy is written quantised from the float features, the kernel's
             // store dequantises (no quantised matrix, no integer result).  INT8 (the conv layers' own type, models/quantize.py:22-23):
@@ -2174,7 +2175,7 @@ template <typename T>
 static int dequant_run_t(Group *g, const void *Xq, int64_t ldx, float *out, const uint32_t *amax, int log2_range, hipStream_t st) {
     const uint64_t orows = (uint64_t)g->total_rows;
     const uint32_t h = (uint32_t)g->h;
-    if constexpr (sizeof(T) == 4 || sizeof(T) == 1) {
+    if constexpr (sizeof(T) == 4 || sizeof(T) <= 2) {
         if (Part *pl = lds_fusable_part<T>(g))  // the LDS-staged kernel packs the quantised rows itself and dequantises in its store
             return launch_lds<T>(g, *pl, (const T *)Xq, ldx, (T *)out, (int64_t)h, h, false, st, nullptr, amax, log2_range);
     }

@@ -375,7 +375,8 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
         a(f"s_mov_b64 exec, {EX}")
         a("s_waitcnt vmcnt(0)")
         return L
-    if out_kind in ("i8", "i8_deq"):
+    if out_kind in ("i8", "i8_deq", "i16_deq"):
+        # "i16_deq": the INT16 stream's own dequantising store (sign-extended 16-bit halves), same shape as "i8_deq"
         # INT8 through the INT16 stream (round 4): the slice-major copy holds the int8 features WIDENED to 16 bits (a slice = 128 features
         # = the same 256 bytes), the stream's v_pk_add_u16 sums wrap modulo 2^16, and the low byte of each half IS the modular int8 sum
         # (models/quantize.py:22-23 quantises to int8; torch's int8 sums wrap the same way).  A lane holds features 2l and 2l + 1:
@@ -397,7 +398,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
         a(f"s_mov_b64 {EXB}, vcc")
         a(f"s_mov_b64 {NP}, %[rowmap]")
         a(f"s_mov_b32 {KREG}, 0")
-        if out_kind == "i8_deq":
+        if out_kind in ("i8_deq", "i16_deq"):
             a("s_cmp_eq_u64 %[pmul], 0")
             a("s_cbranch_scc1 L_nopost_%=")
             a(f"s_mov_b64 exec, {EXA}")                        # (nothing is read past the last column's factor)
@@ -431,8 +432,9 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
                 a(f"global_store_byte_d16_hi {VL2}, {VT0}, {PA} offset:1")
                 a(f"s_mov_b64 exec, {EX}")
             else:
-                a(f"v_bfe_i32 {T2}, {VT0}, 0, 8")
-                a(f"v_bfe_i32 {T3}, {VT0}, 16, 8")
+                bits = 8 if out_kind == "i8_deq" else 16
+                a(f"v_bfe_i32 {T2}, {VT0}, 0, {bits}")
+                a(f"v_bfe_i32 {T3}, {VT0}, 16, {bits}")
                 a(f"v_cvt_f32_i32 {T2}, {T2}")
                 a(f"v_cvt_f32_i32 {T3}, {T3}")
                 a(f"v_mul_f32 {T2}, %[scale], {T2}")
@@ -655,6 +657,8 @@ def main():
                      "CODE-STREAM form, DBL64: 512-byte rows in LDS, one ds_read_b64 per staged column, a register pair per running sum (8 waves x 114 rows)", None, None, "f64"))
     variants.append(("k_lds_code8_i64", "v_add_co_u32", "C8W", 0,
                      "CODE-STREAM form, INT64: as DBL64, the add is v_add_co_u32 + v_addc_co_u32 (modular)", None, None, "i64"))
+    variants.append(("k_lds_code8_i16_deq", "v_pk_add_u16", "C8", 0,
+                     "CODE-STREAM form, INT16 quantised features, the store dequantises: out = float(int16 sum) * scale", None, "i16", "i16_deq"))
     variants.append(("k_lds_code8_i8", "v_pk_add_u16", "C8", 0,
                      "CODE-STREAM form, INT8: features widened to 16 bits in the staged copy, packed 16-bit sums, the store keeps each sum's low byte", None, None, "i8"))
     variants.append(("k_lds_code8_i8_deq", "v_pk_add_u16", "C8", 0,
@@ -670,7 +674,7 @@ def main():
         clob = ", ".join([f'"v{i}"' for i in range(g.T0, min(g.vmax, 256))] + [f'"s{i}"' for i in range(g.TOK0, 100)])
         is_code = "_code" in name
         out_kind = v[7] if len(v) > 7 else None
-        cslice, fps = {None: (256, 64), "i8": (128, 128), "i8_deq": (512, 128), "f64": (512, 64), "i64": (512, 64)}[out_kind]
+        cslice, fps = {None: (256, 64), "i8": (128, 128), "i8_deq": (512, 128), "i16_deq": (512, 128), "f64": (512, 64), "i64": (512, 64)}[out_kind]
         asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code, out_kind=out_kind))
         guard = "_ab" in name   # ablation builds (timing experiments, wrong results) only with -DPYGIM_LDS_ABLATE (make ablate)
         if guard:

@@ -304,13 +304,13 @@ def test_int16_two_features_to_a_lane(rng, lds_forced):
             assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (n, h, v is not None, code)
 
 
-@pytest.mark.parametrize("dt,code", [(np.int32, "INT32"), (np.float32, "FLT32"), (np.int8, "INT8")])
+@pytest.mark.parametrize("dt,code", [(np.int32, "INT32"), (np.float32, "FLT32"), (np.int8, "INT8"), (np.int16, "INT16")])
 def test_quantised_aggregation_with_the_dequantising_store(rng, lds_forced, dt, code):
     """the conv layers' quantise -> aggregate -> dequantise (models/quantize.py:20-42, pyg_gcn_conv.py:130-137) in one device call on
     the LDS-staged kernel: the slice-major copy is written quantised, the kernel's store writes float(sum) * scale -- equal to the
     oracle's statement of the three steps bit for bit.  INT8 (round 4, the type models/quantize.py:22-23 quantises to): the quantised
     features are staged as 16-bit numbers, summed by the INT16 code stream, and the store sign-extends each sum's low byte = the
-    modular int8 sum.  (INT16 keeps the sweep's fused store.)"""
+    modular int8 sum; INT16 likewise with 16-bit halves."""
     n, h = 3000, 256
     rowptr, col = random_csr(rng, n, n, 25, long_rows=[(5, 2500)])
     xf = rng.standard_normal((n, h)).astype(np.float32)
