@@ -402,10 +402,14 @@ def main():
         per_rank = [None] * dist.get_world_size()
         dist.all_gather_object(per_rank, mine)
     split_tiles = any(f["col_splits"] > 1 for pr in per_rank for f in pr["groups"])
+    headline_warning = None
     if world == 1 and not force and (args.shape, h) == ("reddit", 256) and not os.environ.get("PYGIM_TUNE") and not fams[0]["kernel"].startswith("k_lds_code"):
-        # the headline line names the code-stream kernel and prices its roofline against that kernel's traffic: a group that fell down
-        # the ladder (pygim_group_lds_note says why) must not produce a line that looks like the real thing
-        raise SystemExit(f"[bench] the headline group is not on the code-stream kernel: {fams[0]['kernel']}: {fams[0]['note']}")
+        # the group fell down the ladder (pygim_group_lds_note says why): the line below names the kernel that really ran (the roofline
+        # object takes the family from the library), says so in config.headline_kernel_warning, and PYGIM_BENCH_STRICT=1 makes it fatal
+        headline_warning = f"the headline group is NOT on the code-stream kernel but on {fams[0]['kernel']}: {fams[0]['note']}"
+        print(f"[bench] WARNING: {headline_warning}", file=sys.stderr, flush=True)
+        if os.environ.get("PYGIM_BENCH_STRICT", "0") == "1":
+            raise SystemExit(f"[bench] {headline_warning}")
     for hd in handles:
         _lib.group_kernel_events(hd, True)  # HIP events around the dominant kernel of every product, on its launch stream
     my_rows, my_nnz = plan.my_rows, plan.my_nnz
@@ -552,6 +556,7 @@ def main():
                    "model_prior": {"row_parts": prior.row_parts, "feat_parts": prior.feat_parts,
                                    "predicted_ms": round(prior.seconds * 1e3, 4)},
                    "per_rank": per_rank,
+                   **({"headline_kernel_warning": headline_warning} if headline_warning else {}),
                    **({"ms_per_step_products_only": products_only_ms} if products_only_ms is not None else {})},
         "roofline": roofline,
     }
