@@ -51,7 +51,7 @@ template <typename T> static std::vector<T> reference(const Csr &m, uint32_t nro
             for (uint32_t f = 0; f < h; f++) {
                 T xv = x[(size_t)m.col[e] * h + f];
                 T &a = c[(size_t)r * h + f];
-                if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)xv);
+                if constexpr (std::is_integral<T>::value) a = (T)((typename std::make_unsigned<T>::type)a + (typename std::make_unsigned<T>::type)xv);
                 else {
                     if (vals) {
                         volatile float prod = vals[e] * xv;
@@ -79,6 +79,25 @@ int main(int argc, char **argv) {
         const uint32_t rpt = (rng() % 4 == 0) ? 16 + (uint32_t)(rng() % 1500) : 0;
         const uint32_t bnd = (uint32_t)(rng() % 2);   // rings of >= 3 buffers: meet in the middle of a slot, or at its boundary
         uint64_t stats[4];
+        if (c % 5 == 4) {   // the 8-byte element form: 512-byte rows, register pairs (8 waves x 114 rows)
+            const uint32_t g8[][4] = {{64, 5, 5, 2}, {48, 6, 3, 3}, {96, 3, 2, 2}, {16, 5, 5, 2}, {32, 10, 4, 2}};
+            const auto &q = g8[rng() % 5];
+            if (c % 2) {
+                std::vector<double> x((size_t)ncols * h), out((size_t)nrows * h, 77.0);
+                for (auto &v : x) v = (double)((int64_t)(rng() % 17) - 8);
+                const int rc = lds_code_f64_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], splits, q[2], q[3], rpt, bnd);
+                if (rc) { printf("case %d: interpreter code %d (f64 geo %u %u %u %u)\n", c, rc, q[0], q[1], q[2], q[3]); return 1; }
+                if (out != reference<double>(m, nrows, x, h, nullptr)) { printf("case %d: f64 result differs\n", c); return 2; }
+            } else {
+                std::vector<int64_t> x((size_t)ncols * h), out((size_t)nrows * h, 77);
+                for (auto &v : x) v = (int64_t)rng();
+                const int rc = lds_code_i64_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], splits, q[2], q[3], rpt, bnd);
+                if (rc) { printf("case %d: interpreter code %d (i64 geo %u %u %u %u)\n", c, rc, q[0], q[1], q[2], q[3]); return 1; }
+                if (out != reference<int64_t>(m, nrows, x, h, nullptr)) { printf("case %d: i64 result differs\n", c); return 2; }
+            }
+            done++;
+            continue;
+        }
         if (c % 2 == 0) {
             std::vector<float> x((size_t)ncols * h), out((size_t)nrows * h, 77.f), vals;
             for (auto &v : x) v = (float)((int64_t)(rng() % 17) - 8);   // small integers: sums exact, so split plans compare too
