@@ -180,3 +180,17 @@ def test_a_rank_that_fails_in_set_up_ends_every_rank_promptly():
     assert len(d["config"]["per_rank"]) == 2 and all(pr["groups"] and pr["group_create_ms"] > 0 for pr in d["config"]["per_rank"])
     assert "contract verified" in d["check"]
     assert ok.stderr.count("[bench] rank ") >= 2
+
+
+def test_bench_eight_ranks_logic_check():
+    """the driver's largest launch, `--gpus 8`, as 8 ranks over gloo on this ONE GPU with the small shape (a logic check: eight processes
+    share the device): one JSON line, every rank reports what it built, the gathered C is exact on every rank.  (With the full
+    Reddit shape eight processes on one GPU starve one another for minutes -- profiles/r04_multirank.txt -- so the small shape here.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYGIM_BENCH_BACKEND="gloo", PYGIM_RANK_TIMEOUT="500", PYGIM_COLLECTIVE_TIMEOUT="400", PYGIM_LAUNCH_TIMEOUT="560")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--shape", "products-mini", "--partition", "pipelined"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 8 and len(d["config"]["per_rank"]) == 8 and d["check"].startswith("column-count checksum")
+    assert all(pr["plan_threads"] >= 1 and pr["groups"] for pr in d["config"]["per_rank"])
