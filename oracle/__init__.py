@@ -2,8 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py -- never from pygim_amd/.  Parity status is stated in
-the header of spmm_oracle.c ("parity unpinned" for the arithmetic, partitioning
-pinned against oracle/_ref).
+the header of spmm_oracle.c: PINNED -- arithmetic, merge helpers and group drivers against
+the reference's own host loops, partitioning against its partition.c, all compiled in place
+into oracle/_ref (oracle/Makefile, oracle/build_ref_host.sh).
 """
 import ctypes
 import os
@@ -35,6 +36,8 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(_HERE, "_ref", "libref_utils.so")) and os.path.isdir("/root/reference"):
         subprocess.call(["make", "-C", _HERE, "ref_utils"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if not have_ref_host() and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", _HERE, "ref_host"], stdout=subprocess.DEVNULL)
 
 
 _lib = None
@@ -208,6 +211,126 @@ def ref_partition_tsklt_by_nnz_coo(nnz, nparts):
     split = np.zeros(nparts + 2, dtype=np.uint32)
     ref.partition_tsklt_by_nnz_coo(ctypes.c_uint32(nnz), _p(split), ctypes.c_int(nparts))
     return split[: nparts + 1]
+
+
+# --------------------------------------------------------------------------- #
+# oracle/_ref/libref_host_<variant>_<DTYPE>.so : the reference's OWN host loops #
+# (spmm_host_coo, spmm_host_csr, grande's valued spmm_host_csr, spmv's           #
+# spmm_host, the merge helpers and the group drivers), cut out of the reference #
+# files by name at build time and compiled in place (oracle/build_ref_host.sh). #
+# This is what pins the arithmetic of the oracle.                               #
+# --------------------------------------------------------------------------- #
+REF_DTYPE_NAME = {
+    np.dtype(np.int8): "INT8", np.dtype(np.int16): "INT16", np.dtype(np.int32): "INT32",
+    np.dtype(np.int64): "INT64", np.dtype(np.float32): "FLT32", np.dtype(np.float64): "DBL64",
+}
+REF_HOST_PINNED_BY = ("reference spmm_host_coo (spmm_default/spmm_mul_coo.c:40-51), spmm_host_csr (spmm_grande/spmm_mul_csr.c:119-136, "
+                      "spmm_default/spmm_mul_csr.c:100-113) and spmm_host (spmv_sparseP/spmv_mul_coo.c:92-103) compiled in place "
+                      "(oracle/build_ref_host.sh)")
+_ref_host_libs = {}
+
+
+def _ref_host_path(variant, dtype):
+    return os.path.join(_HERE, "_ref", f"libref_host_{variant}_{REF_DTYPE_NAME[np.dtype(dtype)]}.so")
+
+
+def have_ref_host():
+    return all(os.path.exists(_ref_host_path(v, d)) for v in ("default", "grande", "spmv") for d in REF_DTYPE_NAME)
+
+
+def ref_host(variant, dtype):
+    key = (variant, np.dtype(dtype))
+    if key not in _ref_host_libs:
+        lib_ = ctypes.CDLL(_ref_host_path(variant, dtype))
+        assert lib_.ref_sizeof_val_dt() == np.dtype(dtype).itemsize
+        _ref_host_libs[key] = lib_
+    return _ref_host_libs[key]
+
+
+def _ones_like_nnz(values, n, dtype):
+    return np.ones(n, dtype=dtype) if values is None else np.ascontiguousarray(values, dtype=dtype)
+
+
+def ref_spmm_host_coo(row, col, values, x, nrows, variant="default"):
+    """The reference's COO host loop: spmm_host_coo (default) or spmm_host (spmv).  Accumulates into a zeroed y."""
+    x = np.ascontiguousarray(x)
+    row, col = _u32(row), _u32(col)
+    v = _ones_like_nnz(values, len(col), x.dtype)
+    m = _RefCOO(nrows, x.shape[0], len(col), None, row.ctypes.data, col.ctypes.data, v.ctypes.data, len(col))
+    y = np.zeros((nrows, x.shape[1]), dtype=x.dtype)
+    f = getattr(ref_host(variant, x.dtype), "spmm_host_coo" if variant == "default" else "spmm_host")
+    f(_p(y), ctypes.byref(m), _p(x), ctypes.c_uint32(x.shape[1]))
+    return y
+
+
+def ref_spmm_host_csr(rowptr, colind, values, x, variant="grande", ldx=None):
+    """The reference's CSR host loop.  variant "grande": the valued loop with a padded X stride
+    (spmm_grande/spmm_mul_csr.c:119-136); "default": the unit-weight loop that reads but ignores the
+    values (spmm_default/spmm_mul_csr.c:100-113)."""
+    x = np.ascontiguousarray(x)
+    rowptr, colind = _u32(rowptr), _u32(colind)
+    v = _ones_like_nnz(values, len(colind), x.dtype)
+    nrows = len(rowptr) - 1
+    m = _RefCSR(nrows, x.shape[0], len(colind), rowptr.ctypes.data, colind.ctypes.data, v.ctypes.data,
+                len(rowptr), len(colind), len(colind))
+    lib_ = ref_host(variant, x.dtype)
+    if variant == "grande":
+        ncols = x.shape[1] if ldx is None else ldx[0]
+        stride = x.shape[1] if ldx is None else ldx[1]
+        y = np.zeros((nrows, ncols), dtype=x.dtype)
+        lib_.spmm_host_csr(_p(y), ctypes.byref(m), _p(x), ctypes.c_uint32(ncols), ctypes.c_uint32(stride))
+    else:
+        y = np.zeros((nrows, x.shape[1]), dtype=x.dtype)
+        lib_.spmm_host_csr(_p(y), ctypes.byref(m), _p(x), ctypes.c_uint32(x.shape[1]))
+    return y
+
+
+def ref_group(is_coo, ptr_or_row, colind, values, nrows, ncols, x_parts, h, variant="default"):
+    """The reference's group driver (spmm_host_csr_group / spmm_host_coo_group, spmm_default/ops.hpp:42-62,97-118;
+    spmm_host_group, spmv_sparseP/spmv_mul_coo.c:128-148) on the reference's own structs; arguments as group()."""
+    n = len(colind)
+    dt = x_parts[0].dtype
+    pr = [_u32(a) for a in ptr_or_row]
+    ci = [_u32(a) for a in colind]
+    vals = None if values is None else [np.ascontiguousarray(v, dtype=dt) for v in values]
+    xs = [np.ascontiguousarray(x) for x in x_parts]
+    VP = ctypes.c_void_p
+    arr = lambda lst: (VP * len(lst))(*[a.ctypes.data for a in lst])
+    nnz = np.array([len(c) for c in ci], dtype=np.uint32)
+    nr = np.array(nrows, dtype=np.uint32)
+    nc = np.array(ncols, dtype=np.uint32)
+    dn = np.array([x.shape[1] for x in xs], dtype=np.uint32)
+    out = np.zeros((int(nr[0]), h), dtype=dt)
+    rc = ref_host(variant, dt).ref_group(
+        _p(out), ctypes.c_int(1 if is_coo else 0), ctypes.c_uint32(n), arr(pr), arr(ci),
+        None if vals is None else arr(vals), _p(nr), _p(nc), _p(nnz),
+        ctypes.c_uint32(len(xs)), arr(xs), _p(dn), ctypes.c_uint32(h))
+    assert rc == 0
+    return out
+
+
+def ref_merge(name, dest, src, off_x, off_y, len_x, len_y, variant="default"):
+    """add_2D / memadd_2D / memcpy_2D of the reference (spmm_default/spmm_mul_csr.c:41-86,
+    spmv_sparseP/spmv_mul_coo.c:54-115) on row-major 2-D arrays; dest is modified in place."""
+    assert dest.flags.c_contiguous and src.flags.c_contiguous and dest.dtype == src.dtype
+    getattr(ref_host(variant, dest.dtype), name)(
+        _p(dest), _p(src), ctypes.c_uint32(dest.shape[1]), ctypes.c_uint32(src.shape[1]),
+        ctypes.c_uint32(off_x), ctypes.c_uint32(off_y), ctypes.c_uint32(len_x), ctypes.c_uint32(len_y))
+    return dest
+
+
+def ref_matrix_add(a, b):
+    """matrix_add, spmm_default/spmm_mul_csr.c:55-60."""
+    getattr(ref_host("default", a.dtype), "matrix_add")(_p(a), _p(b), ctypes.c_uint32(a.shape[0]), ctypes.c_uint32(a.shape[1]))
+    return a
+
+
+def add_2d(dest, src, off_x, off_y, len_x, len_y):
+    """The oracle's own restatement of add_2D (oracle_add_2d_<T>)."""
+    getattr(lib(), "oracle_add_2d_" + SUFFIX[np.dtype(dest.dtype)])(
+        _p(dest), _p(src), ctypes.c_uint32(dest.shape[1]), ctypes.c_uint32(src.shape[1]),
+        ctypes.c_uint32(off_x), ctypes.c_uint32(off_y), ctypes.c_uint32(len_x), ctypes.c_uint32(len_y))
+    return dest
 
 
 _REF_UTILS_PATH = os.path.join(_HERE, "_ref", "libref_utils.so")

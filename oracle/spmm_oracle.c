@@ -5,26 +5,33 @@
  * this file; it is the checker used by tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py.
  *
- * PARITY STATUS: "parity unpinned" for the arithmetic entry points
- * (oracle_spmm_*, oracle_spmv_*, oracle_group_*): the reference holds no golden
- * vectors / known-answer tests for this path, its
- * version=cpu path lives in the un-vendored third-party package torch_sparse
- * (Libs/install_libs.sh:13, version unpinned) and its own host loops sit in
- * files that include the UPMEM SDK's dpu.h, which this image lacks, so they
- * cannot be compiled here.  The restatement below follows those loops line by
- * line (citations on every function) and is cross-checked in tests/ against two
- * independent libraries (torch.sparse.mm, scipy.sparse).
- * The absent dependency, for the record: torch_sparse (rusty1s/pytorch_sparse), whatever wheel
+ * PARITY STATUS: PINNED.  The reference holds no golden vectors / known-answer tests
+ * for this path and its version=cpu path lives in the un-vendored,
+ * version-unpinned third-party package torch_sparse (Libs/install_libs.sh:13).  What the
+ * reference does hold is its own host oracle: spmm_host_coo
+ * (spmm_default/spmm_mul_coo.c:40-51), spmm_host_csr (valued: spmm_grande/spmm_mul_csr.c:119-136;
+ * unit weights: spmm_default/spmm_mul_csr.c:100-113), spmm_host (spmv_sparseP/spmv_mul_coo.c:92-103),
+ * the merge helpers (spmm_default/spmm_mul_csr.c:41-86) and the group drivers
+ * (spmm_default/ops.hpp:42-62,97-118; spmv_sparseP/spmv_mul_coo.c:128-148).  The FILES that hold
+ * them include the UPMEM SDK's dpu.h (absent here) for their device code, but those FUNCTIONS need
+ * only the reference's own support/common.h + support/matrix.h: oracle/build_ref_host.sh cuts them
+ * out of the reference files BY NAME at build time, pipes them to gcc/g++ together with the
+ * reference's headers (read in place; no stand-in header, nothing copied into the repo) and
+ * builds oracle/_ref/libref_host_<variant>_<DTYPE>.so for the six val_dt types.
+ * tests/test_oracle.py compares every arithmetic entry point below with those libraries BYTE FOR
+ * BYTE (floats included, INT8/INT16 wrap included) on random valued / overflow cases and on every
+ * golden vector; tests/golden/make_golden.py accepts a vector only when the reference build
+ * produced the same bytes and stamps `pinned_by` into the fixture.
+ * For the record, the absent third-party dependency: torch_sparse (rusty1s/pytorch_sparse), whatever wheel
  * `pip install ... -f https://data.pyg.org/whl/torch-1.13.1+cpu.html` resolved to (Libs/install_libs.sh:13,
  * no version given; the 0.6.x line for torch 1.13).  Its published algorithm for the call the
  * driver makes -- torch_sparse.matmul(adj_t, x), reduce = "sum" (spmm_test.py:25) -- is
  * csrc/cpu/spmm_cpu.cpp: rows in parallel, and per row `for e in rowptr[r] .. rowptr[r+1]:
  * out[r, k] += value[e] * mat[col[e], k]` in the element type of `mat`: the stored-order row sum
- * that oracle_spmm_csr_* below computes.  tests/golden/make_golden.py checks the vectors against
- * the real package whenever it can be imported and records which in `pinned_by`.
- * PINNED: the partition functions (oracle_partition_*) are checked against the
- * reference's own support/partition.c, which compiles from its own sources with
- * plain gcc (oracle/Makefile target `ref` -> oracle/_ref/).
+ * that oracle_spmm_csr_* below (and the reference's own spmm_host_csr) computes.
+ * tests/golden/make_golden.py also checks the vectors against the real package whenever it can be imported.
+ * PINNED as well: the partition functions (oracle_partition_*) against the reference's own
+ * support/partition.c, and the MatrixMarket reader against utils.hpp (oracle/Makefile targets `ref`, `ref_utils`).
  *
  * Element type: the reference builds one library per val_dt
  * (spmm_default/support/common.h:39-60); here every function is instantiated for

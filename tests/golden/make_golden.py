@@ -3,12 +3,20 @@
 Sources of truth, in order:
   * partition_*.npz  -- outputs of the REFERENCE's own support/partition.c compiled in place
                         into oracle/_ref (oracle/Makefile target `ref`); needs /root/reference.
-  * spmm_*.npz       -- the reference holds no vectors for the arithmetic
-                        and its host loops cannot be compiled here (they include the UPMEM
-                        SDK's dpu.h), so expected outputs come from the oracle restatement and
-                        are accepted only when torch.sparse.mm AND scipy give the same answer
-                        (bit-exact for integers, exactly representable sums for the float cases
-                        that use the driver's integer-valued features).
+  * spmm_*.npz       -- the reference holds no vectors for the arithmetic.
+                        Expected outputs are those of the REFERENCE'S OWN host loops: spmm_host_coo
+                        (spmm_default/spmm_mul_coo.c:40-51), the valued spmm_host_csr
+                        (spmm_grande/spmm_mul_csr.c:119-136), the unit-weight spmm_host_csr
+                        (spmm_default/spmm_mul_csr.c:100-113) and spmv's spmm_host
+                        (spmv_sparseP/spmv_mul_coo.c:92-103), cut out of the reference files by name
+                        and compiled in place with the reference's own support headers
+                        (oracle/build_ref_host.sh -> oracle/_ref/libref_host_*).  A vector is accepted
+                        only when the oracle restatement gives the SAME BITS (all six types, floats
+                        included) and torch.sparse.mm / scipy agree (bit-exact for integers, 1e-5
+                        for the real-valued float cases).  `pinned_by` records it.
+  * group_*.npz      -- sp_parts x ds_parts group products from the reference's own group drivers
+                        (spmm_host_csr_group / spmm_host_coo_group, spmm_default/ops.hpp:42-62,
+                        97-118) on the reference's own structs (oracle/ref_host_glue.inc).
 Inputs follow the reference driver: graph shapes of SURVEY.md section 8c, features
 torch.randint(-8, 4) under torch.manual_seed (spmm_test.py:70).
 Usage: python tests/golden/make_golden.py
@@ -82,14 +90,31 @@ def torch_sparse_pin(fmt, rowptr, row, col, vals, x, y, exact):
     return f"torch_sparse {getattr(torch_sparse, '__version__', '?')}"
 
 
+def reference_pin(fmt, rowptr, row, col, vals, x, y):
+    """The reference's own host loops, compiled in place (oracle/build_ref_host.sh): the vector is accepted only when
+    they produce the SAME BITS as the oracle restatement -- integers and floats alike (same loop order, products and sums
+    rounded separately, no reassociation at -O2 without -ffast-math)."""
+    if not oracle.have_ref_host():
+        return None
+    same = lambda a: a.tobytes() == y.tobytes() and a.shape == y.shape
+    if fmt == "CSR":
+        assert same(oracle.ref_spmm_host_csr(rowptr, col, vals, x, variant="grande")), "oracle != reference spmm_host_csr (grande)"
+        if vals is None:  # the default variant's loop reads the values and ignores them: unit weights only
+            assert same(oracle.ref_spmm_host_csr(rowptr, col, None, x, variant="default")), "oracle != reference spmm_host_csr"
+    else:
+        assert same(oracle.ref_spmm_host_coo(row, col, vals, x, y.shape[0], variant="default")), "oracle != reference spmm_host_coo"
+        assert same(oracle.ref_spmm_host_coo(row, col, vals, x, y.shape[0], variant="spmv")), "oracle != reference spmm_host (spmv)"
+    return oracle.REF_HOST_PINNED_BY
+
+
 PINNED_BY = {"last": None}
 
 
 def save(name, **kw):
     path = os.path.join(HERE, name + ".npz")
-    if name.startswith("spmm_"):
-        kw["pinned_by"] = PINNED_BY["last"] or ("unpinned: torch_sparse not importable in the build container; accepted on "
-                                                 "agreement of the oracle with scipy.sparse and torch.sparse.mm")
+    if name.startswith("spmm_") or name.startswith("group_"):
+        kw["pinned_by"] = PINNED_BY["last"] or ("unpinned: neither oracle/_ref/libref_host_* nor torch_sparse available in the build "
+                                                 "container; accepted on agreement of the oracle with scipy.sparse and torch.sparse.mm")
     np.savez_compressed(path, **kw)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -99,7 +124,8 @@ def emit(name, fmt, rowptr, col, x, vals=None, exact=True):
     if fmt == "CSR":
         y = oracle.spmm_csr(rowptr, col, vals, x)
         cross_check("CSR", rowptr, None, col, vals, x, y, exact)
-        PINNED_BY["last"] = torch_sparse_pin("CSR", rowptr, None, col, vals, x, y, exact)
+        PINNED_BY["last"] = " + ".join(filter(None, [reference_pin("CSR", rowptr, None, col, vals, x, y),
+                                                      torch_sparse_pin("CSR", rowptr, None, col, vals, x, y, exact)])) or None
         kw = dict(fmt="CSR", rowptr=rowptr, col=col, x=x, y=y)
         if vals is not None:
             kw["vals"] = vals
@@ -109,9 +135,49 @@ def emit(name, fmt, rowptr, col, x, vals=None, exact=True):
             v = (v * 0 + 1).astype(npdt) * vals[: len(v)]
         y = oracle.spmm_coo(r, c, v, x, len(rowptr) - 1)
         cross_check("COO", None, r, c, v, x, y, exact)
-        PINNED_BY["last"] = torch_sparse_pin("COO", None, r, c, v, x, y, exact)
+        PINNED_BY["last"] = " + ".join(filter(None, [reference_pin("COO", None, r, c, v, x, y),
+                                                      torch_sparse_pin("COO", None, r, c, v, x, y, exact)])) or None
         kw = dict(fmt="COO", row=r, col=c, vals=v, x=x, y=y, nrows=len(rowptr) - 1)
     save(name, **kw)
+
+
+def group_vectors(rng):
+    """sp_parts x ds_parts (spmm.py:9-13,57-72,127-136) through spmm_host_csr_group / spmm_host_coo_group of the reference
+    (spmm_default/ops.hpp:42-62,97-118), non-divisible splits included; the oracle's group() must give the same bits."""
+    if not oracle.have_ref_host():
+        print("oracle/_ref/libref_host_* missing: group vectors NOT regenerated")
+        return
+    n, h = 180, 27
+    rowptr, col = random_csr(rng, n, n, 8, long_rows=[(3, 700)])
+    a = sp.csr_matrix((np.ones(len(col), dtype=np.int64), col.copy(), rowptr.copy()), shape=(n, n))
+    for fmt in ("CSR", "COO"):
+        for name, sp_parts, ds_parts in (("INT32", 1, 1), ("INT32", 2, 1), ("INT32", 3, 4), ("INT8", 8, 3), ("FLT32", 3, 8),
+                                         ("INT64", 2, 2), ("DBL64", 8, 1), ("INT16", 1, 4)):
+            npdt = NP_DTYPES[name]
+            x = rng.integers(-8, 4, size=(n, h)).astype(npdt) if np.issubdtype(npdt, np.integer) else \
+                (rng.random((n, h)) * 2 - 1).astype(npdt)
+            step = (n + sp_parts - 1) // sp_parts
+            idx0, cols, vals, ncols = [], [], [], []
+            for i in range(sp_parts):
+                blk = a[:, i * step:min(n, (i + 1) * step)].tocsr()
+                blk.sum_duplicates()
+                blk.sort_indices()
+                idx0.append((blk.indptr if fmt == "CSR" else blk.tocoo().row).astype(np.int32))
+                cols.append(blk.indices.astype(np.int32))
+                # CSR: the default variant's spmm_host_csr ignores the stored values (spmm_mul_csr.c:108-109): unit weights
+                vals.append(np.ones(blk.nnz, dtype=npdt) if fmt == "CSR" else blk.data.astype(npdt))
+                ncols.append(blk.shape[1])
+            xs = [np.ascontiguousarray(c) for c in np.array_split(x, ds_parts, axis=1) if c.shape[1] > 0]
+            y = oracle.ref_group(fmt == "COO", idx0, cols, vals, [n] * sp_parts, ncols, xs, h, variant="default")
+            mine = oracle.group(fmt == "COO", idx0, cols, vals, [n] * sp_parts, ncols, xs, h)
+            assert mine.tobytes() == y.tobytes(), "oracle.group != reference group driver"
+            if fmt == "COO":
+                assert oracle.ref_group(True, idx0, cols, vals, [n] * sp_parts, ncols, xs, h, variant="spmv").tobytes() == y.tobytes()
+            PINNED_BY["last"] = "reference spmm_host_csr_group / spmm_host_coo_group (spmm_default/ops.hpp:42-62,97-118) compiled in place"
+            kw = dict(fmt=fmt, x=x, y=y, n_parts=sp_parts, ds_parts=ds_parts, ncols=np.array(ncols, dtype=np.int32))
+            for i in range(sp_parts):
+                kw[f"idx0_{i}"], kw[f"col_{i}"], kw[f"vals_{i}"] = idx0[i], cols[i], vals[i]
+            save(f"group_{fmt.lower()}_{name}_sp{sp_parts}_ds{ds_parts}", **kw)
 
 
 def main():
@@ -154,6 +220,20 @@ def main():
         x = (rng.random((256, 48)) * 2 - 1).astype(npdt)
         vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
         emit(f"spmm_real_csr_{name}", "CSR", rowptr, col, x, vals=vals, exact=False)
+    # (5b) valued entries for every type (grande multiplies by the stored value, spmm_grande/spmm_mul_csr.c:131; integer
+    # products wrap at the element width), CSR and COO
+    rowptr, col = random_csr(rng, 400, 300, 10, long_rows=[(11, 900)])
+    for name, npdt in NP_DTYPES.items():
+        if np.issubdtype(npdt, np.integer):
+            lo, hi = (-128, 127) if name == "INT8" else (-3000, 3000)
+            vals = rng.integers(lo, hi, size=len(col)).astype(npdt)
+            x = rng.integers(lo, hi, size=(300, 20)).astype(npdt)
+        else:
+            vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+            x = (rng.random((300, 20)) * 2 - 1).astype(npdt)
+        emit(f"spmm_valued_csr_{name}", "CSR", rowptr, col, x, vals=vals, exact=np.issubdtype(npdt, np.integer))
+    # (5c) group products: sparse column blocks x dense feature blocks, outputs of the reference's OWN group drivers
+    group_vectors(rng)
     # partition vectors from the reference's own partition.c
     if oracle.have_ref():
         kw, k = {}, 0
