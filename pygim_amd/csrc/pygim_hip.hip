@@ -243,6 +243,7 @@ struct Context {
         size_t bytes = 0;
         const void *src = nullptr;  // what the buffer holds: X pointer, stride, rows, width, element size
         int64_t ld = 0, rows = 0, w = 0;
+        uint64_t rows_pad = 0;  // kind 1 / 3: rows of a slice in THIS copy (whole chunks of the part that packed it) -> its slice stride
         size_t es = 0;
         int kind = 0;  // 0 = 128-byte slices (sweep), 1 = 256-byte slices, rows padded to whole chunks (LDS-staged product)
         uint64_t stamp = 0;
@@ -817,8 +818,10 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             Context::XsBuf *hit = nullptr;
             for (auto &kv : g_ctx.xs_bufs) {
                 Context::XsBuf &b = kv.second;
+                // (the padded row count depends on the part's chunk size: a copy made for another ring geometry has another slice stride)
                 if (kv.first.first == dev && b.ptr && b.src == (const void *)X && b.ld == ldx && b.rows == p.ncols && b.w == (int64_t)w &&
-                    b.es == sizeof(T) && b.kind == (WIDE8 ? 3 : 1) && (!hit || b.stamp > hit->stamp))
+                    b.es == sizeof(T) && b.kind == (WIDE8 ? 3 : 1) && b.rows_pad == rows_pad && b.bytes >= need &&
+                    (!hit || b.stamp > hit->stamp))
                     hit = &b;
             }
             if (hit) {
@@ -839,6 +842,7 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
             b->w = (int64_t)w;
             b->es = sizeof(T);
             b->kind = WIDE8 ? 3 : 1;
+            b->rows_pad = rows_pad;
             const uint64_t threads = (uint64_t)p.ncols * nslices * 16;
             if constexpr (WIDE8) {
                 if (threads > 0)

@@ -213,6 +213,39 @@ def test_same_features_reuse_the_slice_major_copy(rng, lds_forced):
     assert torch.equal(a, b) and a.cpu().numpy().tobytes() == oracle.spmm_csr(rowptr, col, None, x.cpu().numpy()).tobytes()
 
 
+def test_shared_copy_is_not_reused_across_ring_geometries(rng, lds_forced):
+    """the staged copy's slice stride depends on the part's chunk size (rows padded to whole chunks).  Two
+    groups that share X with x_unchanged=True -- the first a code stream (128-column chunks), the second fallen to the token form
+    (320-column chunks, lds_fail = 2) -- must not read each other's copy: slices 1.. would come back wrong (or the DMA run past
+    the buffer).  ncols is chosen so that the two paddings differ."""
+    n, ncols, h = 2500, 2000, 256          # 2000 -> 2048 rows per slice (kc = 128) against 2240 (kc = 320)
+    rowptr, col = random_csr(rng, n, ncols, 40)
+    x = features(rng, ncols, h, np.float32)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    rp, ci = torch.from_numpy(rowptr.astype(np.int32)).cuda(), torch.from_numpy(col.astype(np.int32)).cuda()
+    xd = torch.from_numpy(x).cuda()
+    mk = lambda: _lib.group_create(_lib.CSR, _lib.FLT32, [rp.data_ptr()], [ci.data_ptr()], None, [n], [ncols], [len(col)], [1], [h], h)
+    h1 = mk()
+    old = _lib.set_tunable("lds_fail", 2)
+    try:
+        h2 = mk()
+    finally:
+        _lib.set_tunable("lds_fail", old)
+    try:
+        g1, g2 = _lib.group_lds_geometry(h1), _lib.group_lds_geometry(h2)
+        assert _lib.group_lds_code(h1)["active"] == 1 and _lib.group_lds_code(h2)["active"] == 0, (_lib.group_lds_note(h1), _lib.group_lds_note(h2))
+        assert g1["chunk_cols"] != g2["chunk_cols"], (g1, g2)
+        outs = [torch.full((n, h), 77.0, device="cuda") for _ in range(4)]
+        for hd, o, same in ((h1, outs[0], False), (h2, outs[1], True), (h1, outs[2], True), (h2, outs[3], True)):
+            _lib.spmm_run_group(hd, [xd.data_ptr()], o.data_ptr(), x_unchanged=same)
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert o.cpu().numpy().tobytes() == want.tobytes(), k
+    finally:
+        _lib.group_free(h1)
+        _lib.group_free(h2)
+
+
 @pytest.mark.parametrize("seed", range(max(12, int(os.environ.get("PYGIM_STRESS_SEEDS", "0")))))  # (a one-off soak: PYGIM_STRESS_SEEDS=500)
 def test_random_shapes(seed, lds_forced):
     rng = np.random.default_rng(1000 + seed)
