@@ -233,7 +233,8 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
  * buffers: 0 / 1 = the workgroup meets at every slot boundary with nbuf - 1 chunks in flight, 2 = once in the middle of a slot with nbuf - 2),
  * "lds_code_waves" (waves per workgroup of a code-stream plan: 16 x 96 accumulators, 8 x 228 = taller tiles and fewer rounds of workgroups, 0 = automatic),
  * "lds_code_kc" (columns per chunk, 0 = by the ring), "lds_code_gsize" / "lds_code_nsets" (staged columns per group of LDS reads / x-register sets: the
- * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_long_slots", "lds_ablate" (timing experiments, wrong results)};
+ * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_xcd_slices" (code-stream products: slices of X per XCD -- 0 = automatic (the default), 1 = an XCD streams one slice through
+ * its L2; 2 / 4 = the workgroups an XCD runs side by side are slices of the same tile and share its code stream in L2), "lds_long_slots", "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * READ AT GROUP CREATION (they shape the plan; changing them afterwards does not touch existing groups, and switching "lds_code" off
  * after a code-stream group was created sends that group's products to the sweep): panel_*, long_*, split_unit_pattern, narrow_vals,

@@ -111,6 +111,7 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_xcd_slices = 0;         // code-stream kernels: slices of X per XCD (0 = automatic; 1 = an XCD streams one slice; 2 / 4: a tile's slices side by side on one XCD share its code in L2)
     int64_t lds_code_boundary = 0;      // rings of >= 3 buffers: 0 / 1 = the workgroup meets at the slot boundary (one more chunk in flight, the last group's adds cross the barrier), 2 = in the middle of a slot
     int64_t lds_code_exp = 0;           // (timing experiments, WRONG results) code streams without barriers (1) / without the chunk DMA (2)
     int64_t lds_fail = 0;               // (tests) force a step of the code-stream set-up to fail: 1 = code generation, 2 = executable memory, 4 = schedule build
@@ -891,7 +892,25 @@ int launch_lds(Group *g, Part &p, const T *X, int64_t ldx, T *C, int64_t ldc, ui
     a.post_relu = deq_amax ? g->post_relu : 0;
     // (slice counts that do not divide 8 interleave the slices over the XCDs; a slice-major order measured the same: 2.86 vs 2.80 ms at h = 192)
     a.xcd_group = (nslices == 1 || nslices == 2 || nslices == 4 || nslices == 8) ? 8 / nslices : 0;
-    const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) : p.lds_ntiles * nslices;
+    a.xcd_sx = 1;
+    // round 5: sx slices per XCD -- the workgroups an XCD runs side by side are then the sx slices of ONE tile and
+    // share its code stream in that XCD's L2 (fetched from the fabric nslices / sx times instead of nslices), at the price of sx
+    // slices of X streamed through every L2 instead of one
+    if (a.xcd_group && p.lds_is_code && nslices > 1) {
+        // 0 = automatic (profiles/r05_exp_xcd.txt): two slices per XCD -- fabric traffic 5.28 -> 4.19 GB on the bench workload --
+        // and all (up to four) of them for plans whose tiles skip most chunks (little of X to un-share): 5.57 -> 3.72 GB, 1.05 -> 0.98 ms
+        uint32_t sx = (uint32_t)std::max<int64_t>(0, g_tune.lds_xcd_slices);
+        if (sx == 0) {
+            const uint64_t nchunks = ((uint64_t)p.ncols + p.lds_kc - 1) / std::max(1u, p.lds_kc);
+            const double fill = p.lds_ntiles && nchunks ? (double)p.lds_slots / ((double)p.lds_ntiles * (double)nchunks) : 1.0;
+            sx = fill < 0.3 ? std::min(nslices, 4u) : 2u;
+        }
+        if (sx > 1 && sx <= nslices && nslices % sx == 0) {
+            a.xcd_sx = sx;
+            a.xcd_group *= sx;
+        }
+    }
+    const uint32_t grid = a.xcd_group ? 8 * ((p.lds_ntiles + a.xcd_group - 1) / a.xcd_group) * a.xcd_sx : p.lds_ntiles * nslices;
     using KernelFn = void (*)(LdsArgs);
     KernelFn fn = nullptr;
     const bool long16 = p.lds_nw == 16 && p.lds_batch == LDS_L16_BATCH;   // the 16-token-batch geometry (no values)
@@ -2325,6 +2344,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_fail") slot = &g_tune.lds_fail;
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
     else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
+    else if (n == "lds_xcd_slices") slot = &g_tune.lds_xcd_slices;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;

@@ -566,6 +566,8 @@ struct LdsArgs {
     const char *code;                  // code-stream kernels: the compiled schedule (executable memory) and the byte offset of
     const uint64_t *code_start;        // every (tile, wave) stream in it
     uint32_t piece_bytes;              // code-stream kernels: bytes of a chunk that one wave DMAs (chunk bytes / 16: the plan's ring geometry)
+    uint32_t xcd_sx;                   // slices per XCD (round 5): 1 = an XCD streams ONE slice of X (X shared in its L2, a tile's code fetched by every
+                                       // slice's XCDs); 2 / 4 = consecutive workgroups of an XCD are slices of the SAME tile and share its code in L2
 };
 """
 
@@ -576,10 +578,11 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
     constexpr uint32_t NW = %(NW)d, KA = %(KA)d, BATCH = %(BATCH)d, PIECE = %(piece)du;
     const uint32_t b = blockIdx.x;
     uint32_t slice, ti;
-    if (a.xcd_group) {  // blocks b and b + 8 share an XCD: an XCD (or a group of them) streams ONE slice of X through its L2
-        const uint32_t xcd = b & 7, i = b >> 3;
-        slice = xcd / a.xcd_group;
-        ti = (xcd %% a.xcd_group) + a.xcd_group * i;
+    if (a.xcd_group) {  // blocks b and b + 8 share an XCD: a group of xcd_group XCDs streams xcd_sx slices of X through its L2s; with
+                        // xcd_sx > 1 workgroups i, i + 1 (.. i + 3) of an XCD are the slices of ONE tile: the same code stream, in step
+        const uint32_t xcd = b & 7, i = b >> 3, sx = a.xcd_sx ? a.xcd_sx : 1u;
+        slice = (xcd / a.xcd_group) * sx + i %% sx;
+        ti = (xcd %% a.xcd_group) + a.xcd_group * (i / sx);
     } else {
         slice = b %% a.nslices;
         ti = b / a.nslices;
