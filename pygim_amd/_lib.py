@@ -201,7 +201,7 @@ def group_lds_plan(handle):
 def group_lds_code(handle):
     out = (ctypes.c_int64 * 4)()
     check(lib().pygim_group_lds_code(int(handle), out))
-    return dict(zip(["code_bytes", "paired_entries", "active"], [int(v) for v in out[:3]]))
+    return dict(zip(["code_bytes", "paired_entries", "active", "device_generated"], [int(v) for v in out[:4]]))
 
 
 def group_lds_geometry(handle):

@@ -212,6 +212,20 @@ PYGIM_HD inline uint32_t cg_slot_of(const CgTables &T, uint32_t ti, uint32_t ch)
 PYGIM_HD inline uint32_t cg_key_stream(const CgParams &P, uint64_t key) { return (uint32_t)(key >> (P.col_bits + 8)); }
 PYGIM_HD inline uint32_t cg_key_col(const CgParams &P, uint64_t key) { return (uint32_t)((key >> 8) & ((1ull << P.col_bits) - 1)); }
 
+// (stream, slot) of a slot index (the device runs a thread per index)
+PYGIM_HD inline void cg_sj_decode(const CgParams &P, const CgTables &T, uint32_t sj, uint32_t *s, uint32_t *j) {
+    uint32_t lo = 0, hi = P.ntiles;   // last tile whose first slot index is <= sj (tiles without chunks own no index)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (P.NW * T.choff[mid] <= sj) lo = mid;
+        else hi = mid;
+    }
+    // (tiles with nch == 0 share their choff with the next: step to the one that owns sj)
+    while (lo + 1 < P.ntiles && T.nch[lo] == 0) lo++;
+    const uint32_t rel = sj - P.NW * T.choff[lo], n = T.nch[lo];
+    *s = lo * P.NW + rel / n;
+    *j = rel % n;
+}
 // D0 / D1: per row (the device runs a wave per row, lanes over its entries)
 PYGIM_HD inline void cg_mark_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
     const uint32_t ti = (T.rowinfo[row] >> 8) / P.NW;
@@ -525,9 +539,11 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
     T.nsj = (uint32_t)(P.NW * out.chunks.slots);
     std::vector<uint32_t> sfc((size_t)T.nsj + 2, 0), sng((size_t)T.nsj + 2, 0), sfg((size_t)T.nsj + 2, 0);
     T.slot_firstcol = sfc.data(); T.slot_ng = sng.data(); T.slot_firstgroup = sfg.data();
-    for (uint32_t s = 0; s < P.nstreams; s++) {
-        const uint32_t b = cg_sbase(P, T, s);
-        for (uint32_t j = 0; j < T.nch[s / P.NW]; j++) cg_slot_bounds(P, T, b + j, s, j);
+    for (uint32_t sj = 0; sj < T.nsj; sj++) {
+        uint32_t s = 0, j = 0;
+        cg_sj_decode(P, T, sj, &s, &j);
+        if (cg_sbase(P, T, s) + j != sj || j >= T.nch[s / P.NW]) throw std::runtime_error("lds codegen: slot index decode");
+        cg_slot_bounds(P, T, sj, s, j);
     }
     cg_slot_bounds(P, T, T.nsj, 0, 0);
     for (uint32_t sj = 0; sj < T.nsj; sj++) cg_slot_ngroups(P, T, sj);

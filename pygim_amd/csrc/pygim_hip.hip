@@ -17,6 +17,7 @@
 #include "lds_kernel_gen_ablate.hpp"   // (make ablate: the same kernels + round 3's timing-experiment variants; not committed)
 #else
 #include "lds_kernel_gen.hpp"
+#include "lds_codegen_dev.hpp"
 #endif
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -111,6 +112,7 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_codegen = 1;            // code streams: 1 = generated on the device from the resident CSR (lds_codegen_dev.hpp), 0 = by the host encoder, 2 = on the device AND checked word for word against the host encoder (tests)
     int64_t lds_xcd_slices = 0;         // code-stream kernels: slices of X per XCD (0 = automatic; 1 = an XCD streams one slice; 2 / 4: a tile's slices side by side on one XCD share its code in L2)
     int64_t lds_code_boundary = 0;      // rings of >= 3 buffers: 0 / 1 = the workgroup meets at the slot boundary (one more chunk in flight, the last group's adds cross the barrier), 2 = in the middle of a slot
     int64_t lds_code_exp = 0;           // (timing experiments, WRONG results) code streams without barriers (1) / without the chunk DMA (2)
@@ -169,6 +171,8 @@ struct Part {
     uint32_t lds_code_gsize = 0, lds_code_nsets = 0;
     uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
     std::string lds_note;                  // which form of the product this part got, and why not a faster one
+    bool lds_codegen_device = false;       // its code stream was generated on the device
+    std::string lds_codegen_why;           // ... or why not
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
     bool is_extra = false;  // widths of the dense parts paired with this part
@@ -409,7 +413,8 @@ static ExecPool *exec_pool_locked(int dev) {
     ep.ok = true;
     return &ep;
 }
-static void *exec_alloc_upload(const void *host, size_t bytes, std::string *why = nullptr) {
+// executable device memory from the HSA pool (hipMalloc memory faults on instruction fetch); nullptr + *why when there is none
+static void *exec_alloc(size_t bytes, std::string *why = nullptr) {
     auto say = [&](const char *m) { if (why) *why = m; };
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { say("no current HIP device"); return nullptr; }
@@ -419,14 +424,20 @@ static void *exec_alloc_upload(const void *host, size_t bytes, std::string *why 
         ep = exec_pool_locked(dev);
     }
     if (!ep) { say("the HSA runtime offers no executable device memory pool"); return nullptr; }
-    // the code goes up through HIP (a bounded staging buffer and a copy kernel: the executable allocation is a device address like any
-    // other inside a kernel); the HSA runtime is asked for the memory only
-    void *ptr = nullptr, *stage = nullptr;
-    const size_t piece = std::min<size_t>(bytes, (size_t)64 << 20);   // 64 MiB at a time: no second full-size allocation beside the code
+    void *ptr = nullptr;
     if (hsa_amd_memory_pool_allocate(ep->pool, bytes, HSA_AMD_MEMORY_POOL_EXECUTABLE_FLAG, &ptr) != HSA_STATUS_SUCCESS) {
         say("the executable pool could not allocate the code");
         return nullptr;
     }
+    return ptr;
+}
+static void *exec_alloc_upload(const void *host, size_t bytes, std::string *why = nullptr) {
+    auto say = [&](const char *m) { if (why) *why = m; };
+    // the code goes up through HIP (a bounded staging buffer and a copy kernel: the executable allocation is a device address like any
+    // other inside a kernel); the HSA runtime is asked for the memory only
+    const size_t piece = std::min<size_t>(bytes, (size_t)64 << 20);   // 64 MiB at a time: no second full-size allocation beside the code
+    void *ptr = exec_alloc(bytes, why), *stage = nullptr;
+    if (!ptr) return nullptr;
     if (hipMalloc(&stage, std::max<size_t>(piece, 256)) != hipSuccess) {
         (void)hipGetLastError();
         (void)hsa_amd_memory_pool_free(ptr);
@@ -1408,8 +1419,64 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
         p.lds_note = why + (p.lds_tiles ? "; products take the token form of the LDS-staged kernel (k_lds_spmm_*)" : "; no token plan either: the L2 sweep serves this group");
     }
     if (p.lds_note.empty())
-        p.lds_note = p.lds_tiles ? (p.lds_is_code ? "code-stream form" : "token form of the LDS-staged kernel") : "no LDS-staged plan (rule, type or width): the L2 sweep serves this group";
+        p.lds_note = p.lds_tiles ? (p.lds_is_code ? (p.lds_codegen_device || p.lds_codegen_why.empty() ? std::string("code-stream form")
+                                                                                                         : "code-stream form (written by the host encoder: " + p.lds_codegen_why + ")")
+                                                  : std::string("token form of the LDS-staged kernel")) : "no LDS-staged plan (rule, type or width): the L2 sweep serves this group";
     return rc;
+}
+
+// lds_codegen = 2: the device-generated code stream against the host encoder's, word for word (and the stream offsets, the row map, the
+// chunk counts of the tiles and the statistics).  "" = identical.
+static std::string codegen_verify(const Part &p, const LdsGeometry &geo, uint32_t code_op, const std::vector<uint32_t> &h_rowptr, const CgDeviceResult &dr) {
+    std::vector<uint32_t> h_col((size_t)p.nnz), h_val;
+    if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return "column ids D2H failed";
+    if (p.vals) {
+        h_val.resize((size_t)p.nnz);
+        if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return "values D2H failed";
+    }
+    LdsPlanHost plan;
+    LdsCodeHost ch;
+    try {
+        lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
+                       p.vals ? h_val.data() : nullptr);
+        lds_code_from_plan(plan, code_op, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
+                           (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets), 0);
+    } catch (const std::exception &e) {
+        return std::string("the host encoder failed: ") + e.what();
+    }
+    if (ch.code.size() * 4 != dr.code_bytes) return "code size " + std::to_string(dr.code_bytes) + " against " + std::to_string(ch.code.size() * 4) + " bytes";
+    if (plan.ntiles != dr.ntiles || plan.slots != dr.slots) return "tile / slot counts";
+    std::vector<uint32_t> d_code(ch.code.size());
+    void *stage = nullptr;   // (the executable allocation is read through a plain device buffer)
+    if (hipMalloc(&stage, std::max<size_t>(dr.code_bytes, 256)) != hipSuccess) return "out of device memory for the comparison";
+    const uint64_t n16 = dr.code_bytes / 16;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (const u32x4_t *)dr.code, (u32x4_t *)stage, n16);
+    const bool got = hipMemcpy(d_code.data(), stage, dr.code_bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(stage);
+    if (!got) return "code D2H failed";
+    if (memcmp(d_code.data(), ch.code.data(), dr.code_bytes) != 0) {
+        size_t at = 0;
+        while (d_code[at] == ch.code[at]) at++;
+        size_t s = 0;
+        while (s + 1 < ch.start.size() && ch.start[s + 1] / 4 <= at) s++;
+        char buf[160];
+        snprintf(buf, sizeof buf, "first difference at dword %zu (stream %zu + %zu): %08x against the host's %08x", at, s, at - (size_t)(ch.start[s] / 4), d_code[at], ch.code[at]);
+        return buf;
+    }
+    std::vector<uint64_t> d_start(ch.start.size());
+    std::vector<uint32_t> d_rowmap(plan.rowmap.size());
+    std::vector<LdsTile> d_tiles(plan.tiles.size());
+    if (hipMemcpy(d_start.data(), dr.d_start, d_start.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(d_rowmap.data(), dr.d_rowmap, d_rowmap.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(d_tiles.data(), dr.d_tiles, d_tiles.size() * sizeof(LdsTile), hipMemcpyDeviceToHost) != hipSuccess)
+        return "table D2H failed";
+    if (d_start != ch.start) return "stream offsets";
+    if (d_rowmap != plan.rowmap) return "row map";
+    for (size_t t = 0; t < d_tiles.size(); t++)
+        if (d_tiles[t].nch != plan.tiles[t].nch || d_tiles[t].row0 != plan.tiles[t].row0 || d_tiles[t].nnz != plan.tiles[t].nnz || d_tiles[t].chunk0 != plan.tiles[t].chunk0)
+            return "tile table";
+    if (dr.entries != ch.entries || dr.pairs != ch.pairs || dr.shared != ch.shared) return "statistics";
+    return std::string();
 }
 
 static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const std::vector<uint32_t> &h_rowptr, int64_t h_hint,
@@ -1479,32 +1546,6 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
             geo.rows_per_tile = 0;   // full-height tiles: the column ranges fill the chip
         }
     }
-    if (g_tune.lds_mode == 0 &&
-        lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
-        return 0;
-    if (p.cols_sorted < 0) {  // (the panel plan may have asked already)
-        int unsorted = 0;
-        if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
-        hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr, p.colind,
-                           (uint32_t)p.nrows, d_flag_sorted);
-        if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "sortedness check");
-        p.cols_sorted = unsorted ? 0 : 1;
-    }
-    if (!p.cols_sorted) return 0;  // stored order inside a row must be column order for the chunk walk
-    std::vector<uint32_t> h_col((size_t)p.nnz);
-    if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
-    lap("sortedness check + column ids D2H");
-    std::vector<uint32_t> h_val;
-    if (p.vals) {
-        h_val.resize((size_t)p.nnz);
-        if (es == 4) {
-            if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
-        } else {  // INT16: the value in both halves of its dword (packed multiply)
-            std::vector<uint16_t> v16((size_t)p.nnz);
-            if (hipMemcpy(v16.data(), p.vals, v16.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
-            for (size_t i = 0; i < v16.size(); i++) h_val[i] = (uint32_t)v16[i] * 0x10001u;
-        }
-    }
     if (want_code) {
         // the ring.  Two buffers of 320 columns: the workgroup meets at every slot boundary (round 3).  Three or more (round 4): one
         // barrier in the middle of a slot, NBUF - 2 chunks in flight beside the one being read, no drain at the boundary -- the DMA
@@ -1522,6 +1563,92 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         // measured (profiles/r04_lds_kernel.md): with five buffers the boundary form -- four chunks in flight -- is 1-2 % ahead of the mid-slot form on
         // every shape tried (2.02-2.04 against 2.06 ms on the bench workload, DBL64 7.03 against 7.12): the default
         geo.boundary = g_tune.lds_code_boundary == 2 ? 0u : 1u;
+    }
+    if (g_tune.lds_mode == 0 &&
+        lds_plan_uniform_reuse((uint64_t)p.nnz, (uint32_t)p.nrows, (uint32_t)p.ncols, geo) * 100.0 < (double)g_tune.lds_min_reuse_x100)
+        return 0;
+    if (p.cols_sorted < 0) {  // (the panel plan may have asked already)
+        int unsorted = 0;
+        if (hipMemsetAsync(d_flag_sorted, 0, sizeof(int), st) != hipSuccess) return fail(PYGIM_ERR_HIP, "flag reset");
+        hipLaunchKernelGGL(k_check_sorted_cols, dim3((unsigned)((p.nrows + 255) / 256)), dim3(256), 0, st, p.rowptr, p.colind,
+                           (uint32_t)p.nrows, d_flag_sorted);
+        if (hipMemcpy(&unsorted, d_flag_sorted, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "sortedness check");
+        p.cols_sorted = unsorted ? 0 : 1;
+    }
+    if (!p.cols_sorted) return 0;  // stored order inside a row must be column order for the chunk walk
+    const uint32_t code_op = t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : t_plan_dtype == PYGIM_INT32 ? 0x68000000u : t_plan_dtype == PYGIM_DBL64 ? LDS_CODE_ADD_F64 :
+                             t_plan_dtype == PYGIM_INT64 ? LDS_CODE_ADD_U64 : LDS_CODE_PK_ADD_U16;
+    // Round 5: the code stream GENERATED ON THE DEVICE (lds_codegen_dev.hpp) from the resident CSR -- the same bytes the host encoder
+    // below would write (lds_codegen = 2 checks that, word for word) without the graph ever visiting the host.  Plans it does not
+    // cover (column-split tiles, the mid-slot hand-off, timing experiments), or a failure on the way, take the host encoder.
+    std::string dev_why;
+    if (want_code && g_tune.lds_codegen && !(g_tune.lds_fail & 7) && !g_tune.lds_code_exp) {
+        CgDeviceResult dr;
+        std::string exec_why;
+        auto alloc_exec = [&](size_t bytes) -> void * { return exec_alloc(bytes, &exec_why); };
+        auto free_exec = [&](void *q) { (void)hsa_amd_memory_pool_free(q); };
+        dev_why = (es != 4 && p.vals) ? std::string("valued entries of this width") :
+                  cg_run_on_device(p.rowptr, p.colind, (const uint32_t *)p.vals, h_rowptr.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, code_op,
+                                   (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets), st, alloc_exec,
+                                   free_exec, dr, [] { return now_ms(); });
+        if (dev_why.empty()) {
+            if (plan_timing)
+                fprintf(stderr, "[pygim plan] device code generation: rows %.1f, chunk lists %.1f, keys + sort %.1f, columns %.1f, slots + groups %.1f, sizes %.1f, emission %.1f, "
+                                "whole %.1f ms (%.1f MB of code)\n", dr.ms[0], dr.ms[1], dr.ms[2], dr.ms[3], dr.ms[4], dr.ms[5], dr.ms[6], dr.ms[7], dr.code_bytes / 1e6);
+            if (g_tune.lds_codegen == 2) {   // the checker: the host encoder's blob against what the device wrote
+                std::string diff = codegen_verify(p, geo, code_op, h_rowptr, dr);
+                if (!diff.empty()) {
+                    (void)hsa_amd_memory_pool_free(dr.code);
+                    (void)hipFree(dr.d_start);
+                    (void)hipFree(dr.d_rowmap);
+                    (void)hipFree(dr.d_tiles);
+                    return fail(PYGIM_ERR_INVALID, ("lds_codegen = 2: the device-generated code stream differs from the host encoder's: " + diff).c_str());
+                }
+            }
+            p.lds_code = (char *)dr.code;
+            p.lds_code_bytes = dr.code_bytes;
+            p.lds_code_start = dr.d_start;
+            p.lds_rowmap = dr.d_rowmap;
+            p.lds_tiles = dr.d_tiles;
+            p.lds_code_pairs = dr.pairs;
+            p.lds_code_shared = dr.shared;
+            p.lds_is_code = true;
+            p.lds_code_piece = geo.KC * geo.row_bytes / geo.NW;
+            p.lds_code_gsize = dr.regs.gsize;
+            p.lds_code_nsets = dr.regs.nsets;
+            p.lds_col_splits = 1;
+            p.lds_kc = geo.KC;
+            p.lds_nbuf = geo.NBUF;
+            p.lds_row_bytes = geo.row_bytes;
+            p.lds_ka = geo.KA;
+            p.lds_ntiles = dr.ntiles;
+            p.lds_nw = geo.NW;
+            p.lds_batch = geo.BATCH;
+            p.lds_slots = dr.slots;
+            p.lds_tokens = dr.entries;   // (a code stream has no padding)
+            p.lds_codegen_device = true;
+            lap("code stream generated on the device");
+            return 0;
+        }
+        (void)hipGetLastError();
+        if (plan_timing) fprintf(stderr, "[pygim plan] device code generation not used: %s\n", dev_why.c_str());
+        p.lds_codegen_why = dev_why;
+    } else if (want_code) {
+        p.lds_codegen_why = !g_tune.lds_codegen ? "lds_codegen = 0" : (g_tune.lds_fail & 7) ? "lds_fail set" : "timing experiment";
+    }
+    std::vector<uint32_t> h_col((size_t)p.nnz);
+    if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "colind D2H");
+    lap("sortedness check + column ids D2H");
+    std::vector<uint32_t> h_val;
+    if (p.vals) {
+        h_val.resize((size_t)p.nnz);
+        if (es == 4) {
+            if (hipMemcpy(h_val.data(), p.vals, h_val.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+        } else {  // INT16: the value in both halves of its dword (packed multiply)
+            std::vector<uint16_t> v16((size_t)p.nnz);
+            if (hipMemcpy(v16.data(), p.vals, v16.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(PYGIM_ERR_HIP, "values D2H");
+            for (size_t i = 0; i < v16.size(); i++) h_val[i] = (uint32_t)v16[i] * 0x10001u;
+        }
     }
     LdsPlanHost plan;
     try {
@@ -2345,6 +2472,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
     else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
     else if (n == "lds_xcd_slices") slot = &g_tune.lds_xcd_slices;
+    else if (n == "lds_codegen") slot = &g_tune.lds_codegen;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
@@ -2670,7 +2798,7 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
     out[0] = p.lds_code ? (int64_t)p.lds_code_bytes : 0;
     out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
     out[2] = (p.lds_is_code && g_tune.lds_code) ? 1 : 0;
-    out[3] = 0;
+    out[3] = (p.lds_code && p.lds_codegen_device) ? 1 : 0;   // generated on the device (round 5), not by the host encoder
     return 0;
 }
 
