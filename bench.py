@@ -582,16 +582,44 @@ def main():
         torch.cuda.synchronize()
         ts_c = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
         cc = torch.bincount(col_c.long(), minlength=n).double()
-        # creation cost of the HEADLINE group (the reference's to_device / prepare step, paid once per graph) and how many products it
-        # takes to earn it back against the next form down the ladder: the token kernels need no code generation and no executable
-        # memory (measured on this workload in round 3: 3.91 ms per product), the sweep needs neither schedule (6.52 ms)
+        # creation cost of the HEADLINE group (the reference's to_device / prepare step, paid once per graph; spmm_default/spmm_mul_csr.c:118-330)
+        # and how many products it takes to earn it back against the next forms down the ladder -- MEASURED here on the same graph
+        # (ADVICE r04): the token kernels (lds_code = 0: no code generation, no executable memory) and the L2 sweep (lds_mode = 2)
         create_ms = mine["group_create_ms"]
+        alts = {}
+        for name, knob, val in (("token_kernels", "lds_code", 0), ("sweep", "lds_mode", 2)):
+            prev = _lib.set_tunable(knob, val)
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                hd_a = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+                torch.cuda.synchronize()
+                t_a = (time.perf_counter() - t0) * 1e3
+            finally:
+                _lib.set_tunable(knob, prev)
+            out_a = torch.empty((n, h), dtype=torch.float32, device=dev)
+            for _ in range(2):
+                _lib.spmm_run_group(hd_a, [x.data_ptr()], out_a.data_ptr(), stream)
+            torch.cuda.synchronize()
+            ea = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            for i in range(5):
+                ea[i].record(main_stream)
+                _lib.spmm_run_group(hd_a, [x.data_ptr()], out_a.data_ptr(), stream)
+            ea[5].record(main_stream)
+            torch.cuda.synchronize()
+            ms_a = sorted(ea[i].elapsed_time(ea[i + 1]) for i in range(5))[2]
+            gain = ms_a - ms_per_step
+            alts[name] = {"ms_per_product": round(ms_a, 3), "group_create_ms": round(t_a, 1), "lds_note": _lib.group_lds_note(hd_a),
+                          "break_even_products": (max(0, math.ceil((create_ms - t_a) / gain)) if gain > 0 else None)}
+            _lib.group_free(hd_a)
+            del out_a
         result["extra_headline"] = {
             "group_create_ms": create_ms, "code_bytes": fams[0]["code_bytes"], "lds_note": fams[0]["note"],
-            "break_even_products_vs_token_kernels": (math.ceil(create_ms / max(3.91 - ms_per_step, 1e-9)) if ms_per_step < 3.91 else None),
-            "break_even_products_vs_sweep": (math.ceil(create_ms / max(6.52 - ms_per_step, 1e-9)) if ms_per_step < 6.52 else None),
-            "note": "group_create_ms = pygim_group_create of the timed group (device-resident CSR in): validation, the sweep's plan, the LDS schedule and its "
-                    "compilation into machine code; the alternatives' creation is not free either (token plan ~0.6 s, sweep plan ~0.1 s), so the true break-even is lower"}
+            "code_generated_on_device": bool(_lib.group_lds_code(handles[0]).get("device_generated")),
+            "alternatives_measured": alts,
+            "note": "group_create_ms = pygim_group_create of the timed group (device-resident CSR in): validation, the sweep's plan beside it, and the code stream "
+                    "(round 5: generated on the device from the resident CSR, byte-identical to the host encoder); break_even_products = products after which "
+                    "this group's creation + products cost less than the alternative's (0 = from the first product)"}
         result["extra"] = {"clustered_ms_per_step": round(ts_c[len(ts_c) // 2], 4),
                            "clustered_GFLOPs": round(total_flops / (ts_c[len(ts_c) // 2] * 1e-3) / 1e9, 1),
                            "clustered_lds_plan": _lib.group_lds_plan(hd_c),

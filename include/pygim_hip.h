@@ -209,8 +209,13 @@ int pygim_group_plan(int64_t handle, int64_t out[8]);
 int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
 /* the same schedule compiled into gfx950 machine code (the code-stream form of the product, k_lds_code_*: one straight-line
  * instruction stream per (row tile, wave), 1.5 instructions per stored entry): bytes of code (0 = none), stored entries that share
- * an LDS instruction with a neighbour, 1 when products take this form (tunable "lds_code"), 0 */
+ * an LDS instruction with a neighbour, 1 when products take this form (tunable "lds_code"), 1 when the stream was generated on the
+ * device from the resident CSR (round 5, tunable "lds_codegen") rather than by the host encoder */
 int pygim_group_lds_code(int64_t handle, int64_t out[4]);
+/* which rows share a tile of that schedule (round 5; the reference hands a DPU consecutive rows, support/partition.c:51-99): 1 when the
+ * rows were ordered by similarity (label propagation over the graph, tunable "lds_tile_order") instead of by index, the number of labels
+ * the propagation ended with, the rows of the largest one, 0 */
+int pygim_group_lds_tiles(int64_t handle, int64_t out[4]);
 /* geometry of that schedule, as the library planned it (callers price staged bytes from THIS, not from assumed constants):
  * waves per workgroup, accumulators (rows) per wave, columns per chunk (chunk bytes = 256 x this), chunk buffers of the LDS ring,
  * staged columns per group of reads and x-register sets of a code stream (0 0 for a token plan), stored entries served by another
@@ -233,12 +238,14 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
  * buffers: 0 / 1 = the workgroup meets at every slot boundary with nbuf - 1 chunks in flight, 2 = once in the middle of a slot with nbuf - 2),
  * "lds_code_waves" (waves per workgroup of a code-stream plan: 16 x 96 accumulators, 8 x 228 = taller tiles and fewer rounds of workgroups, 0 = automatic),
  * "lds_code_kc" (columns per chunk, 0 = by the ring), "lds_code_gsize" / "lds_code_nsets" (staged columns per group of LDS reads / x-register sets: the
- * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_xcd_slices" (code-stream products: slices of X per XCD -- 0 = automatic (the default), 1 = an XCD streams one slice through
+ * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_codegen" (code streams: 1 = generated on the device from the resident CSR -- the default --, 0 = by
+ * the host encoder, 2 = on the device and checked word for word against the host encoder), "lds_tile_order" (which rows share a tile: 0 = consecutive
+ * rows, 1 = rows ordered by similarity, 2 = automatic: similarity for square parts of a million entries and more), "lds_lp_rounds", "lds_xcd_slices" (code-stream products: slices of X per XCD -- 0 = automatic (the default), 1 = an XCD streams one slice through
  * its L2; 2 / 4 = the workgroups an XCD runs side by side are slices of the same tile and share its code stream in L2), "lds_long_slots", "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * READ AT GROUP CREATION (they shape the plan; changing them afterwards does not touch existing groups, and switching "lds_code" off
  * after a code-stream group was created sends that group's products to the sweep): panel_*, long_*, split_unit_pattern, narrow_vals,
- * merge_parts, lds_code, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_code_boundary, lds_waves, lds_col_split,
+ * merge_parts, lds_code, lds_codegen, lds_tile_order, lds_lp_rounds, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_code_boundary, lds_waves, lds_col_split,
  * lds_col_split_f32, lds_round_tiles, lds_long_slots, lds_min_reuse_x100 and lds_mode (whether a plan is made at all), lds_threads.
  * The others are read per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

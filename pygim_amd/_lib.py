@@ -19,6 +19,7 @@ EXPORTS = [
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
     "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry", "pygim_group_lds_note",
+    "pygim_group_lds_tiles",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -73,6 +74,7 @@ def lib():
         L.pygim_group_lds_code.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_geometry.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_note.argtypes = [c_i64, ctypes.c_char_p, c_i64]
+        L.pygim_group_lds_tiles.argtypes = [c_i64, p_i64]
         L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
@@ -202,6 +204,13 @@ def group_lds_code(handle):
     out = (ctypes.c_int64 * 4)()
     check(lib().pygim_group_lds_code(int(handle), out))
     return dict(zip(["code_bytes", "paired_entries", "active", "device_generated"], [int(v) for v in out[:4]]))
+
+
+def group_lds_tiles(handle):
+    """which rows share a tile: similarity order (label propagation) or consecutive rows"""
+    out = (ctypes.c_int64 * 4)()
+    check(lib().pygim_group_lds_tiles(int(handle), out))
+    return dict(zip(["similarity", "labels", "largest_label_rows"], [int(v) for v in out[:3]]))
 
 
 def group_lds_geometry(handle):

@@ -107,14 +107,20 @@ struct CgRows {
     std::vector<uint32_t> rowmap;    // [ntiles][NW][ka_stride], sorted tile order (0xFFFFFFFF = none) -- what the kernel's store stage reads
     std::vector<uint32_t> tile_row0, tile_nnz;   // sorted tile order
 };
-inline void cg_deal_rows(const uint32_t *rowptr, const LdsGeometry &geo, const CgParams &P, CgRows &out) {
+inline void cg_deal_rows(const uint32_t *rowptr, const LdsGeometry &geo, const CgParams &P, CgRows &out, const uint32_t *rorder = nullptr) {
+    auto rid = [&](uint32_t pos) { return rorder ? rorder[pos] : pos; };   // (lds_plan_build: the row at a position of the tile order)
+    auto rlen = [&](uint32_t pos) { const uint32_t r = rid(pos); return rowptr[r + 1] - rowptr[r]; };
     const uint32_t NW = geo.NW, KA = geo.KA, KAS = geo.ka_stride(), RS = NW * KAS;
     const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, NW * KA) : NW * KA;
     const uint32_t nrows = P.nrows, ntiles = P.ntiles;
     std::vector<uint32_t> nnz(ntiles), ord(ntiles), pos(ntiles);
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R);
-        nnz[t] = rowptr[r1] - rowptr[r0];
+        if (!rorder) nnz[t] = rowptr[r1] - rowptr[r0];
+        else {
+            nnz[t] = 0;
+            for (uint32_t q = r0; q < r1; q++) nnz[t] += rlen(q);
+        }
         ord[t] = t;
     }
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return nnz[a] > nnz[b]; });
@@ -131,13 +137,13 @@ inline void cg_deal_rows(const uint32_t *rowptr, const LdsGeometry &geo, const C
         order.resize(nr);
         for (uint32_t i = 0; i < nr; i++) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
+            return rlen(r0 + a) > rlen(r0 + b);
         });
         for (uint32_t i = 0; i < nr; i++) {
             const uint32_t round = i / NW, p = i % NW;
             const uint32_t w = (round & 1) ? NW - 1 - p : p;
-            out.rowinfo[r0 + order[i]] = ((ti * NW + w) << 8) | round;
-            out.rowmap[((size_t)ti * NW + w) * KAS + round] = r0 + order[i];
+            out.rowinfo[rid(r0 + order[i])] = ((ti * NW + w) << 8) | round;
+            out.rowmap[((size_t)ti * NW + w) * KAS + round] = rid(r0 + order[i]);
         }
     }
 }
@@ -495,10 +501,10 @@ struct CgHostResult {
     uint64_t entries = 0, pairs = 0, shared = 0;
 };
 inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const uint32_t *vals, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
-                           uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0) {
+                           uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr) {
     const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets);
     const uint64_t nnz = rowptr[nrows];
-    cg_deal_rows(rowptr, geo, P, out.rows);
+    cg_deal_rows(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;
     std::vector<uint8_t> flags((size_t)P.ntiles * P.nchunks + 1, 0);

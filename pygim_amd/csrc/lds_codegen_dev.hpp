@@ -234,8 +234,10 @@ struct CgDeviceResult {
 };
 
 // alloc_exec(bytes) returns executable device memory or nullptr; free_exec(ptr) releases it.  Returns "" on success, else why not
-// (nothing is left allocated then).  h_rowptr: the row pointers on the host (the caller has them).
-inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_col, const uint32_t *d_vals, const uint32_t *h_rowptr, uint32_t nrows, uint32_t ncols,
+// (nothing is left allocated then).  h_rowptr: the row pointers on the host (the caller has them); h_rorder: the tile order of the rows
+// (similarity tiles, lds_reorder_dev.hpp) or nullptr for consecutive rows.
+inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_col, const uint32_t *d_vals, const uint32_t *h_rowptr, const uint32_t *h_rorder,
+                                    uint32_t nrows, uint32_t ncols,
                                     const LdsGeometry &geo, uint32_t opcode_add, uint32_t gsize, uint32_t nsets, hipStream_t st,
                                     const std::function<void *(size_t)> &alloc_exec, const std::function<void(void *)> &free_exec, CgDeviceResult &out,
                                     const std::function<double()> &now_ms) {
@@ -283,7 +285,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     // host: rows -> tiles / waves / accumulators (from the row pointers alone)
     CgRows rows;
     try {
-        cg_deal_rows(h_rowptr, geo, P, rows);
+        cg_deal_rows(h_rowptr, geo, P, rows, h_rorder);
     } catch (const std::exception &e) {
         return bail(e.what());
     }

@@ -144,8 +144,12 @@ template <typename F> inline void lds_parallel_for(uint32_t n, unsigned threads,
 
 // rowptr / col: CSR with sorted column ids inside every row (checked by the caller).
 // threads = 0: std::thread::hardware_concurrency().
+// rorder (round 5): a permutation of the rows -- tile t holds rows rorder[t * R .. (t + 1) * R) instead of R consecutive ones (rows with
+// similar neighbourhoods side by side share LDS reads); nullptr = consecutive rows.  Every row is still summed by one wave in stored order.
 inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
-                           LdsPlanHost &out, unsigned threads = 0, const uint32_t *vals = nullptr) {
+                           LdsPlanHost &out, unsigned threads = 0, const uint32_t *vals = nullptr, const uint32_t *rorder = nullptr) {
+    auto rid = [&](uint32_t pos) { return rorder ? rorder[pos] : pos; };   // row at position pos of the tile order
+    auto rlen = [&](uint32_t pos) { const uint32_t r = rid(pos); return rowptr[r + 1] - rowptr[r]; };
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, B = geo.BATCH;
     const uint32_t KAS = geo.ka_stride();
     const uint32_t RS = NW * KAS;                                                      // row-map stride of a tile
@@ -178,7 +182,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
         std::vector<uint32_t> order(nr);
         for (uint32_t i = 0; i < nr; i++) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
+            return rlen(r0 + a) > rlen(r0 + b);
         });
         tt.wave_of.resize(nr);
         tt.k_of.resize(nr);
@@ -187,13 +191,13 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
             const uint32_t w = (round & 1) ? NW - 1 - pos : pos;
             tt.wave_of[order[i]] = (uint8_t)w;
             tt.k_of[order[i]] = (uint16_t)round;
-            out.rowmap[((size_t)t * NW + w) * KAS + round] = r0 + order[i] + cs * nrows;   // (row of the partial-sum block of column range cs)
+            out.rowmap[((size_t)t * NW + w) * KAS + round] = rid(r0 + order[i]) + cs * nrows;   // (row of the partial-sum block of column range cs)
         }
         // token counts per (chunk, wave)
         std::vector<uint32_t> cnt((size_t)nchunks * NW, 0);
         for (uint32_t i = 0; i < nr; i++) {
             const uint32_t w = tt.wave_of[i];
-            for (uint32_t e = rowptr[r0 + i]; e < rowptr[r0 + i + 1]; e++) {
+            for (uint32_t e = rowptr[rid(r0 + i)]; e < rowptr[rid(r0 + i) + 1]; e++) {
                 const uint32_t ch = col[e] / KC;
                 if (ch >= ch_lo && ch < ch_hi) cnt[(size_t)ch * NW + w]++;
             }

@@ -18,6 +18,7 @@
 #else
 #include "lds_kernel_gen.hpp"
 #include "lds_codegen_dev.hpp"
+#include "lds_reorder_dev.hpp"
 #endif
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -112,6 +113,8 @@ struct Tunables {
     int64_t lds_code_gsize = 0;         // staged columns per group of reads of a code stream (0 = lds_plan.hpp lds_code_regs)
     int64_t lds_code_nsets = 0;         // x-register sets of a code stream: the reads run nsets - 1 groups ahead of the adds (0 = default)
     int64_t lds_round_tiles = 1;        // 1 = tile height chosen so that tiles x slices fill whole rounds of workgroups
+    int64_t lds_tile_order = 2;         // code-stream plans: which rows share a tile -- 0 = consecutive rows, 1 = similarity order (label propagation, lds_reorder_dev.hpp), 2 = automatic (similarity for square parts of >= 1 M entries)
+    int64_t lds_lp_rounds = 6;          // rounds of the label propagation
     int64_t lds_codegen = 1;            // code streams: 1 = generated on the device from the resident CSR (lds_codegen_dev.hpp), 0 = by the host encoder, 2 = on the device AND checked word for word against the host encoder (tests)
     int64_t lds_xcd_slices = 0;         // code-stream kernels: slices of X per XCD (0 = automatic; 1 = an XCD streams one slice; 2 / 4: a tile's slices side by side on one XCD share its code in L2)
     int64_t lds_code_boundary = 0;      // rings of >= 3 buffers: 0 / 1 = the workgroup meets at the slot boundary (one more chunk in flight, the last group's adds cross the barrier), 2 = in the middle of a slot
@@ -172,6 +175,7 @@ struct Part {
     uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
     std::string lds_note;                  // which form of the product this part got, and why not a faster one
     bool lds_codegen_device = false;       // its code stream was generated on the device
+    uint32_t lds_tile_labels = 0, lds_tile_largest = 0;   // similarity tiles: labels the propagation ended with, rows of the largest (0 = consecutive rows)
     std::string lds_codegen_why;           // ... or why not
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
     uint64_t lds_slots = 0, lds_tokens = 0;   // 80 KiB chunk fills per slice and product; tokens incl. padding
@@ -1427,7 +1431,8 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
 
 // lds_codegen = 2: the device-generated code stream against the host encoder's, word for word (and the stream offsets, the row map, the
 // chunk counts of the tiles and the statistics).  "" = identical.
-static std::string codegen_verify(const Part &p, const LdsGeometry &geo, uint32_t code_op, const std::vector<uint32_t> &h_rowptr, const CgDeviceResult &dr) {
+static std::string codegen_verify(const Part &p, const LdsGeometry &geo, uint32_t code_op, const std::vector<uint32_t> &h_rowptr, const uint32_t *rorder,
+                                  const CgDeviceResult &dr) {
     std::vector<uint32_t> h_col((size_t)p.nnz), h_val;
     if (hipMemcpy(h_col.data(), p.colind, h_col.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return "column ids D2H failed";
     if (p.vals) {
@@ -1438,7 +1443,7 @@ static std::string codegen_verify(const Part &p, const LdsGeometry &geo, uint32_
     LdsCodeHost ch;
     try {
         lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
-                       p.vals ? h_val.data() : nullptr);
+                       p.vals ? h_val.data() : nullptr, rorder);
         lds_code_from_plan(plan, code_op, ch, (unsigned)std::max<int64_t>(0, g_tune.lds_threads), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize),
                            (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets), 0);
     } catch (const std::exception &e) {
@@ -1578,6 +1583,25 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     if (!p.cols_sorted) return 0;  // stored order inside a row must be column order for the chunk walk
     const uint32_t code_op = t_plan_dtype == PYGIM_FLT32 ? 0x02000000u : t_plan_dtype == PYGIM_INT32 ? 0x68000000u : t_plan_dtype == PYGIM_DBL64 ? LDS_CODE_ADD_F64 :
                              t_plan_dtype == PYGIM_INT64 ? LDS_CODE_ADD_U64 : LDS_CODE_PK_ADD_U16;
+    // Round 5: similarity tiles (lds_reorder_dev.hpp) -- rows with similar neighbourhoods share a tile: shared LDS reads, skipped chunks.
+    // The result does not depend on the order (each row is summed by one wave in stored order whichever tile holds it).
+    std::vector<uint32_t> rorder;
+    if (want_code && geo.col_splits == 1 && p.nrows == p.ncols &&
+        (g_tune.lds_tile_order == 1 || (g_tune.lds_tile_order == 2 && p.nnz >= (1 << 20)))) {
+        uint32_t n_labels = 0, largest = 0;
+        const std::string why = lds_similarity_order(p.rowptr, p.colind, (uint32_t)p.nrows, (int)std::min<int64_t>(std::max<int64_t>(g_tune.lds_lp_rounds, 0), 64), st, rorder,
+                                                     &n_labels, &largest);
+        if (!why.empty()) {
+            rorder.clear();
+            (void)hipGetLastError();
+        }
+        p.lds_tile_labels = n_labels;
+        p.lds_tile_largest = largest;
+        if (plan_timing) fprintf(stderr, "[pygim plan] similarity order: %u labels, the largest holds %u of %lld rows%s\n", n_labels, largest, (long long)p.nrows,
+                                 why.empty() ? "" : (" -- NOT used: " + why).c_str());
+        lap("similarity order (label propagation)");
+    }
+    const uint32_t *ro = rorder.empty() ? nullptr : rorder.data();
     // Round 5: the code stream GENERATED ON THE DEVICE (lds_codegen_dev.hpp) from the resident CSR -- the same bytes the host encoder
     // below would write (lds_codegen = 2 checks that, word for word) without the graph ever visiting the host.  Plans it does not
     // cover (column-split tiles, the mid-slot hand-off, timing experiments), or a failure on the way, take the host encoder.
@@ -1588,7 +1612,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
         auto alloc_exec = [&](size_t bytes) -> void * { return exec_alloc(bytes, &exec_why); };
         auto free_exec = [&](void *q) { (void)hsa_amd_memory_pool_free(q); };
         dev_why = (es != 4 && p.vals) ? std::string("valued entries of this width") :
-                  cg_run_on_device(p.rowptr, p.colind, (const uint32_t *)p.vals, h_rowptr.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, code_op,
+                  cg_run_on_device(p.rowptr, p.colind, (const uint32_t *)p.vals, h_rowptr.data(), ro, (uint32_t)p.nrows, (uint32_t)p.ncols, geo, code_op,
                                    (uint32_t)std::max<int64_t>(0, g_tune.lds_code_gsize), (uint32_t)std::max<int64_t>(0, g_tune.lds_code_nsets), st, alloc_exec,
                                    free_exec, dr, [] { return now_ms(); });
         if (dev_why.empty()) {
@@ -1596,7 +1620,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
                 fprintf(stderr, "[pygim plan] device code generation: rows %.1f, chunk lists %.1f, keys + sort %.1f, columns %.1f, slots + groups %.1f, sizes %.1f, emission %.1f, "
                                 "whole %.1f ms (%.1f MB of code)\n", dr.ms[0], dr.ms[1], dr.ms[2], dr.ms[3], dr.ms[4], dr.ms[5], dr.ms[6], dr.ms[7], dr.code_bytes / 1e6);
             if (g_tune.lds_codegen == 2) {   // the checker: the host encoder's blob against what the device wrote
-                std::string diff = codegen_verify(p, geo, code_op, h_rowptr, dr);
+                std::string diff = codegen_verify(p, geo, code_op, h_rowptr, ro, dr);
                 if (!diff.empty()) {
                     (void)hsa_amd_memory_pool_free(dr.code);
                     (void)hipFree(dr.d_start);
@@ -1654,7 +1678,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     try {
         if (g_tune.lds_fail & 4) throw std::runtime_error("lds_fail: forced failure of the schedule build");
         lds_plan_build(h_rowptr.data(), h_col.data(), (uint32_t)p.nrows, (uint32_t)p.ncols, geo, plan, (unsigned)std::max<int64_t>(0, g_tune.lds_threads),
-                       p.vals ? h_val.data() : nullptr);
+                       p.vals ? h_val.data() : nullptr, ro);
     } catch (const std::exception &e) {   // host memory, threads: no LDS-staged plan, the sweep serves the group
         p.lds_note = std::string("the schedule of the LDS-staged product could not be built (") + e.what() + "): the L2 sweep serves this group";
         return 0;
@@ -2473,6 +2497,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
     else if (n == "lds_xcd_slices") slot = &g_tune.lds_xcd_slices;
     else if (n == "lds_codegen") slot = &g_tune.lds_codegen;
+    else if (n == "lds_tile_order") slot = &g_tune.lds_tile_order;
+    else if (n == "lds_lp_rounds") slot = &g_tune.lds_lp_rounds;
     else if (n == "lds_code_kc") slot = &g_tune.lds_code_kc;
     else if (n == "lds_code_gsize") slot = &g_tune.lds_code_gsize;
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
@@ -2799,6 +2825,17 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
     out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
     out[2] = (p.lds_is_code && g_tune.lds_code) ? 1 : 0;
     out[3] = (p.lds_code && p.lds_codegen_device) ? 1 : 0;   // generated on the device (round 5), not by the host encoder
+    return 0;
+}
+
+int pygim_group_lds_tiles(int64_t handle, int64_t out[4]) {
+    Group *g = lookup(handle);
+    if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
+    out[0] = p.lds_tile_labels ? 1 : 0;
+    out[1] = p.lds_tile_labels;
+    out[2] = p.lds_tile_largest;
+    out[3] = 0;
     return 0;
 }
 

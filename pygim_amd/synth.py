@@ -75,9 +75,76 @@ def make_csr(n, nnz, d_max, seed=0, device="cpu", clustered=False, ncols=None, s
     return rowptr.to(torch.int32), col
 
 
-def make_shape(name, seed=0, device="cpu", clustered=False):
+def _csr_from_pairs(row, col, n, ncols):
+    key = row * ncols + col
+    del row, col
+    key, _ = torch.sort(key)
+    r = torch.div(key, ncols, rounding_mode="floor")
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return rowptr.to(torch.int32), torch.remainder(key, ncols).to(torch.int32)
+
+
+def shuffle_ids(rowptr, col, seed=0):
+    """The same graph under a random relabelling of its nodes (rows and columns alike): whatever locality the generator's id order
+    carried is gone, the structure (who shares neighbours with whom) stays -- what a dataset with arbitrary node ids looks like."""
+    n = rowptr.numel() - 1
+    dev = col.device
+    perm = torch.randperm(n, generator=_gen(seed + 7, dev), device=dev)
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    row = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), deg)
+    return _csr_from_pairs(perm[row], perm[col.to(torch.int64)], n, n)
+
+
+def make_sbm(n, nnz, d_max, blocks, p_in=0.8, seed=0, device="cpu", sigma=1.0, shuffle=True):
+    """Degree-corrected stochastic block model in a dataset's shape: ``blocks`` communities of equal size (consecutive ids before the
+    shuffle), a row's degree from the same log-normal as make_csr, a fraction ``p_in`` of its entries inside its own community (uniform
+    over its members), the rest uniform over all nodes.  ``shuffle``: node ids relabelled at random afterwards (shuffle_ids)."""
+    assert nnz < 2 ** 31 and n < 2 ** 31 and 1 <= blocks <= n
+    deg = degrees(n, nnz, d_max, seed, device, sigma)
+    g = _gen(seed + 1, device)
+    row = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
+    size = (n + blocks - 1) // blocks
+    b0 = torch.div(row, size, rounding_mode="floor") * size                      # first id of the row's community
+    bs = torch.clamp(n - b0, max=size)                                             # its size (the last one may be short)
+    inside = torch.rand(nnz, generator=g, device=device) < p_in
+    u = torch.rand(nnz, generator=g, device=device, dtype=torch.float64)
+    col = torch.where(inside, b0 + (u * bs).to(torch.int64), (u * n).to(torch.int64)).clamp_(max=n - 1)
+    rowptr, colind = _csr_from_pairs(row, col, n, n)
+    return shuffle_ids(rowptr, colind, seed) if shuffle else (rowptr, colind)
+
+
+def make_rmat(n, nnz, a=0.57, b=0.19, c=0.19, seed=0, device="cpu", shuffle=True):
+    """R-MAT (Chakrabarti et al.) edges in a dataset's shape: ids drawn bit by bit with quadrant probabilities (a, b, c, 1 - a - b - c) in
+    the smallest power-of-two id space >= n and folded into [0, n) -- skewed degrees on BOTH sides (hub rows and hub columns), weak
+    community structure.  Multi-edges kept (CSR does not coalesce, backend_pim/spmm.py:44-55)."""
+    assert nnz < 2 ** 31 and n < 2 ** 31
+    bits = max(1, (n - 1).bit_length())
+    g = _gen(seed + 1, device)
+    row = torch.zeros(nnz, dtype=torch.int64, device=device)
+    col = torch.zeros(nnz, dtype=torch.int64, device=device)
+    for _ in range(bits):
+        u = torch.rand(nnz, generator=g, device=device)
+        rbit = (u >= a + b).to(torch.int64)                                        # quadrants c, d: lower half of the rows
+        cbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)       # quadrants b, d: right half of the columns
+        row = row * 2 + rbit
+        col = col * 2 + cbit
+    rowptr, colind = _csr_from_pairs(torch.remainder(row, n), torch.remainder(col, n), n, n)
+    return shuffle_ids(rowptr, colind, seed) if shuffle else (rowptr, colind)
+
+
+# communities of the structured stand-ins: Reddit has 41 labelled subreddit classes and far finer communities; products 47 categories
+SBM_BLOCKS = {"reddit": 50, "ogbn-products": 1200, "reddit-mini": 8, "products-mini": 40, "cora": 7}
+
+
+def make_shape(name, seed=0, device="cpu", clustered=False, kind=None, shuffle=True):
+    """kind: None / "uniform", "clustered" (columns near the row id), "sbm" (communities, ids shuffled unless shuffle=False), "rmat"."""
     n, nnz, d_max = SHAPES[name]
-    return make_csr(n, nnz, d_max, seed, device, clustered)
+    if kind == "sbm":
+        return make_sbm(n, nnz, d_max, SBM_BLOCKS.get(name, max(1, n // 4000)), seed=seed, device=device, shuffle=shuffle)
+    if kind == "rmat":
+        return make_rmat(n, nnz, seed=seed, device=device, shuffle=shuffle)
+    return make_csr(n, nnz, d_max, seed, device, clustered or kind == "clustered")
 
 
 def csr_to_coo_coalesced(rowptr, col, dtype):
@@ -120,5 +187,5 @@ def flops(nnz, h):
     return 2 * nnz * h
 
 
-__all__ = ["SHAPES", "degrees", "make_csr", "make_shape", "csr_to_coo_coalesced", "features",
+__all__ = ["SHAPES", "degrees", "make_csr", "make_sbm", "make_rmat", "shuffle_ids", "make_shape", "csr_to_coo_coalesced", "features",
            "algorithmic_bytes", "gather_bytes", "flops"]

@@ -72,14 +72,22 @@ int main(int argc, char **argv) {
             vals.resize(m.col.size());
             for (auto &v : vals) v = (uint32_t)rng();
         }
+        // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)
+        std::vector<uint32_t> rorder;
+        if (rng() % 3 == 0) {
+            rorder.resize(nrows);
+            for (uint32_t i = 0; i < nrows; i++) rorder[i] = i;
+            std::shuffle(rorder.begin(), rorder.end(), rng);
+        }
+        const uint32_t *ro = rorder.empty() ? nullptr : rorder.data();
         // the host encoder
         LdsPlanHost plan;
-        lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : nullptr);
+        lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : nullptr, ro);
         LdsCodeHost ch;
         lds_code_from_plan(plan, op, ch, 2, q[4], q[5]);
         // the data-parallel form
         CgHostResult r;
-        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5]);
+        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5], ro);
         auto bad = [&](const char *what) {
             printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, op %08x, valued %d, dups %d, clustered %d)\n", c, what, q[0], q[1], q[2], q[3],
                    q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, op, (int)valued, (int)dups, (int)clustered);
