@@ -475,6 +475,11 @@ def main():
                 traffic = None  # the committed counter run is of the other kernel family: nothing to replay
             traffic_source = {"replayed_from": os.path.relpath(args.traffic_json, ROOT), "collected": tj.get("collected"),
                               "box": tj.get("box"), "command": tj.get("command"), "kernel_ms_then": tj.get("kernel_ms")}
+            # a counter run of another kernel than the one just timed (its time differs by more than 10 %) is not replayed
+            then = tj.get("kernel_ms")
+            if traffic is not None and then and k_ms and abs(k_ms - then) / then > 0.10:
+                traffic_source["not_replayed"] = f"the counter run's kernel took {then:.3f} ms, this run's {k_ms:.3f} ms: more than 10 % apart"
+                traffic = None
         except Exception:
             traffic = None
     plan_info = _lib.group_plan(handles[0])

@@ -214,7 +214,8 @@ int pygim_group_lds_plan(int64_t handle, int64_t out[4]);
 int pygim_group_lds_code(int64_t handle, int64_t out[4]);
 /* which rows share a tile of that schedule (round 5; the reference hands a DPU consecutive rows, support/partition.c:51-99): 1 when the
  * rows were ordered by similarity (label propagation over the graph, tunable "lds_tile_order") instead of by index, the number of labels
- * the propagation ended with, the rows of the largest one, 0 */
+ * the propagation ended with, the rows of the largest one; and whether the L2 sweep's work items are in locality order (0 = by length alone,
+ * 1 = blocks of consecutive rows: the stored ids are local, 2 = blocks of the propagated order; tunable "panel_locality") */
 int pygim_group_lds_tiles(int64_t handle, int64_t out[4]);
 /* geometry of that schedule, as the library planned it (callers price staged bytes from THIS, not from assumed constants):
  * waves per workgroup, accumulators (rows) per wave, columns per chunk (chunk bytes = 256 x this), chunk buffers of the LDS ring,
@@ -227,7 +228,7 @@ int pygim_group_lds_geometry(int64_t handle, int64_t out[8]);
 int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
 /* Kernel tunables (for A/B runs): name in {"long_row_threshold", "long_segment", "force_vec_bytes",
  * "csr_kernel", "coo_chunk", "coo_via_rowptr", "panel_mode", "panel_bytes", "panel_min_seg",
- * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_col16", "slice_group_bytes", "fuse_windows",
+ * "panel_coop", "panel_block", "panel_lds_pad", "panel_pack", "panel_locality", "panel_col16", "slice_group_bytes", "fuse_windows",
  * "split_unit_pattern", "narrow_vals" (INT64 / DBL64 values that all fit int32 / float exactly are streamed in 4 bytes), "merge_parts", "vec_kernel", "vec_lds", "vec_lds_min_seg", "kernel_events",
  * "lds_mode" (LDS-staged product: 0 = by the reuse rule, 1 = whenever planned, 2 = never), "lds_min_reuse_x100",
  * "lds_min_width", "lds_threads", "lds_waves" (8 | 16 waves per workgroup of the kernel the plan is made for),

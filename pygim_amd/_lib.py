@@ -210,7 +210,7 @@ def group_lds_tiles(handle):
     """which rows share a tile: similarity order (label propagation) or consecutive rows"""
     out = (ctypes.c_int64 * 4)()
     check(lib().pygim_group_lds_tiles(int(handle), out))
-    return dict(zip(["similarity", "labels", "largest_label_rows"], [int(v) for v in out[:3]]))
+    return dict(zip(["similarity", "labels", "largest_label_rows", "sweep_locality"], [int(v) for v in out[:4]]))
 
 
 def group_lds_geometry(handle):

@@ -73,14 +73,55 @@ __global__ __launch_bounds__(256) void k_lp_iter(const uint32_t *rowptr, const u
         if (lane == 0) lab_out[row] = e1 > e0 ? out : lab_in[row];
     }
 }
+// how good the labels are: the number of stored entries whose column carries its row's label (of nnz: ~p_in for a planted partition, ~0
+// for labels that mean nothing)
+__global__ __launch_bounds__(256) void k_lp_agree(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, const uint32_t *lab, unsigned long long *acc) {
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned long long same = 0;
+    if (row < nrows) {
+        const uint32_t mine = lab[row], e1 = rowptr[row + 1];
+        for (uint32_t e = rowptr[row] + (threadIdx.x & 63); e < e1; e += 64) same += lab[col[e]] == mine ? 1u : 0u;
+    }
+    for (int d = 32; d; d >>= 1) same += __shfl_xor((long long)same, d, 64);
+    if ((threadIdx.x & 63) == 0 && same) atomicAdd(acc, same);
+}
 __global__ __launch_bounds__(256) void k_lp_keys(const uint32_t *lab, uint32_t nrows, uint64_t *keys) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r < nrows) keys[r] = ((uint64_t)lab[r] << 32) | r;
 }
 
+// how local the stored column ids already are: the mean over non-empty rows of (last column - first column) / ncols (rows are column-sorted).
+// ~1 for ids without locality (uniform, shuffled), small when a row's neighbours sit near each other in id order
+__global__ __launch_bounds__(256) void k_row_span(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, unsigned long long *acc) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long span = 0, cnt = 0;
+    if (r < nrows) {
+        const uint32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        if (e1 > e0) { span = col[e1 - 1] - col[e0]; cnt = 1; }
+    }
+    for (int d = 32; d; d >>= 1) {
+        span += __shfl_xor((long long)span, d, 64);
+        cnt += __shfl_xor((long long)cnt, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&acc[0], span);
+        atomicAdd(&acc[1], cnt);
+    }
+}
+inline double lds_mean_row_span(const uint32_t *d_rowptr, const uint32_t *d_col, uint32_t nrows, uint32_t ncols, hipStream_t st) {
+    unsigned long long *acc = nullptr, h[2] = {0, 0};
+    if (hipMalloc((void **)&acc, 64) != hipSuccess) { (void)hipGetLastError(); return 1.0; }
+    (void)hipMemsetAsync(acc, 0, 64, st);
+    hipLaunchKernelGGL(k_row_span, dim3((nrows + 255) / 256), dim3(256), 0, st, d_rowptr, d_col, nrows, acc);
+    const bool ok = hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFree(acc);
+    if (!ok || !h[1] || !ncols) { (void)hipGetLastError(); return 1.0; }
+    return (double)h[0] / (double)h[1] / (double)ncols;
+}
+
 // rows ordered by (label, id) after `rounds` rounds; "" on success.  labels_out (optional): number of distinct labels, largest label's rows
 inline std::string lds_similarity_order(const uint32_t *d_rowptr, const uint32_t *d_col, uint32_t nrows, int rounds, hipStream_t st, std::vector<uint32_t> &rorder,
-                                        uint32_t *n_labels = nullptr, uint32_t *largest = nullptr) {
+                                        uint32_t *n_labels = nullptr, uint32_t *largest = nullptr, uint64_t *agree = nullptr) {
     if (nrows == 0) return "no rows";
     uint32_t *lab_a = nullptr, *lab_b = nullptr, *hist = nullptr, *scan = nullptr;
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
@@ -102,6 +143,14 @@ inline std::string lds_similarity_order(const uint32_t *d_rowptr, const uint32_t
     for (int r = 0; r < rounds; r++) {
         hipLaunchKernelGGL(k_lp_iter, dim3(rb), dim3(256), 0, st, d_rowptr, d_col, nrows, (const uint32_t *)lab_a, lab_b, (uint32_t)r);
         std::swap(lab_a, lab_b);
+    }
+    unsigned long long h_agree = 0;
+    if (agree) {   // (keys_b is free until the sort: its first word takes the count)
+        (void)hipMemsetAsync(keys_b, 0, 8, st);
+        hipLaunchKernelGGL(k_lp_agree, dim3(rb), dim3(256), 0, st, d_rowptr, d_col, nrows, (const uint32_t *)lab_a, (unsigned long long *)keys_b);
+        (void)hipMemcpyAsync(&h_agree, keys_b, 8, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        *agree = h_agree;
     }
     hipLaunchKernelGGL(k_lp_keys, dim3((nrows + 255) / 256), dim3(256), 0, st, (const uint32_t *)lab_a, nrows, keys_a);
     uint32_t bits = 1;

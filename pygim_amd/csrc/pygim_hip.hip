@@ -95,6 +95,7 @@ struct Tunables {
     int64_t merge_parts = 1;            // 1 = groups of several sparse parts also get the merged matrix (used by the run entry points)
     int64_t narrow_vals = 1;            // 1 = INT64 / DBL64 values that are all exactly 4-byte representable are streamed as int32 / float by the sweep
     int64_t split_unit_pattern = 1;     // 1 = integer weights that are 1 almost everywhere: unit pattern + a small correction part
+    int64_t panel_locality = 1;         // (2 = always, whatever the size or the labels' quality: tests) 1 = the sweep's work items in LOCALITY order (blocks of 2048 rows of the similarity / id order, longest first inside a block) when the graph has structure; 0 = by length alone
     int64_t panel_col16 = 1;            // 1 = the sweep reads 16-bit panel-local column ids (built with the plan)
     int64_t fuse_windows = 1;           // 1 = the dense windows of a sparse part become ONE block product of the full width
     int64_t kernel_events = 0;          // 1 = bracket the dominant kernel of every block product with HIP events
@@ -175,6 +176,13 @@ struct Part {
     uint64_t lds_code_shared = 0;          // entries of the code stream served by another entry's read
     std::string lds_note;                  // which form of the product this part got, and why not a faster one
     bool lds_codegen_device = false;       // its code stream was generated on the device
+    // which rows are alike (round 5, lds_reorder_dev.hpp): found once per part, used by the LDS plan's tiles and by the sweep's item order
+    bool panel_locality_used = false;      // the sweep's items are in locality order
+    int sim_kind = -1;                     // -1 = not looked at, 0 = no structure found, 1 = the stored ids are local already (consecutive order), 2 = label propagation
+    std::vector<uint32_t> sim_order;       // kind 2: the rows ordered by (label, id)
+    uint32_t sim_labels = 0, sim_largest = 0;
+    double sim_agree = 0.0;                // kind 2: share of the stored entries whose column carries its row's label
+    std::string sim_why;
     uint32_t lds_tile_labels = 0, lds_tile_largest = 0;   // similarity tiles: labels the propagation ended with, rows of the largest (0 = consecutive rows)
     std::string lds_codegen_why;           // ... or why not
     bool lds_is_code = false;              // the LDS plan of this part is in the code-stream geometry (three 192-column buffers): k_lds_code_* only
@@ -1253,6 +1261,44 @@ int build_lds_plan(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, const
 double now_ms();
 static thread_local int t_plan_dtype = -1;   // element type of the group being created (the plan builders see the element SIZE only)
 
+// Which rows are alike: once per part (square parts of a million entries and more).  sim_kind 1: a row's columns span a small part of
+// the id range -- the ids carry the locality themselves; 2: label propagation found communities (more than one label, none holding half
+// of the rows); 0: neither.
+static void find_similarity(Part &p, hipStream_t st, bool force_lp) {
+    if (p.sim_kind >= 0 && !(force_lp && p.sim_kind != 2)) return;
+    p.sim_kind = 0;
+    p.sim_order.clear();
+    p.sim_why.clear();
+    if (p.nrows != p.ncols || p.nrows == 0 || (!force_lp && p.nnz < (1 << 20))) { p.sim_why = "not a square part of a million entries and more"; return; }
+    if (p.cols_sorted == 0) { p.sim_why = "rows not stored in column order"; return; }
+    const double t0 = now_ms();
+    const double span = force_lp ? 1.0 : lds_mean_row_span(p.rowptr, p.colind, (uint32_t)p.nrows, (uint32_t)p.ncols, st);
+    if (span < 0.5) {
+        p.sim_kind = 1;
+        p.sim_why = "the stored ids are local already (mean row span " + std::to_string(span) + " of the id range)";
+    } else {
+        uint64_t agree = 0;
+        std::string why = lds_similarity_order(p.rowptr, p.colind, (uint32_t)p.nrows, (int)std::min<int64_t>(std::max<int64_t>(g_tune.lds_lp_rounds, 0), 64), st, p.sim_order,
+                                               &p.sim_labels, &p.sim_largest, &agree);
+        p.sim_agree = p.nnz ? (double)agree / (double)p.nnz : 0.0;
+        // communities: more than one label, none holding half of the rows, and the labels MEAN something -- at least 30 % of the stored
+        // entries join two rows of one label (a planted partition: its inside fraction; labels of a graph without structure: ~0, and
+        // ordering by them only costs the sweep its balance: products-shaped uniform 19.8 -> 22.6 ms)
+        if (why.empty() && !force_lp && (p.sim_labels < 2 || (uint64_t)p.sim_largest * 2 > (uint64_t)p.nrows || p.sim_agree < 0.3))
+            why = "the propagation found no communities (" + std::to_string(p.sim_labels) + " labels, " + std::to_string(p.sim_agree) + " of the entries inside one)";
+        if (!why.empty()) {
+            p.sim_order.clear();
+            p.sim_why = why;
+            (void)hipGetLastError();
+        } else {
+            p.sim_kind = 2;
+        }
+    }
+    if (getenv("PYGIM_PLAN_TIMING"))
+        fprintf(stderr, "[pygim plan] similarity: kind %d, %u labels, the largest holds %u of %lld rows%s%s  (%.1f ms)\n", p.sim_kind, p.sim_labels, p.sim_largest,
+                (long long)p.nrows, p.sim_why.empty() ? "" : " -- ", p.sim_why.c_str(), now_ms() - t0);
+}
+
 int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t h_hint = 0, bool allow_lds = true) {
     std::vector<uint32_t> h_rowptr((size_t)p.nrows + 1);
     if (hipMemcpy(h_rowptr.data(), p.rowptr, h_rowptr.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
@@ -1334,6 +1380,19 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
             }
             if (!build_long(p.lp_panel, base_thresh, &heavy)) return fail(PYGIM_ERR_HIP, "long-row plan upload");
             std::vector<uint32_t> rows_v, beg_v, len_v, order;
+            // rank of every row in the locality order (empty = items by length alone): the SpMV end keeps its length classes
+            std::vector<uint32_t> loc_rank;
+            if (g_tune.panel_locality && !(h_hint >= 1 && h_hint <= 4) && !p.is_extra) {
+                find_similarity(p, st, g_tune.panel_locality == 2);   // (2: propagation whatever the size -- tests)
+                if (p.sim_kind == 1) {
+                    loc_rank.resize(nr);
+                    for (size_t r = 0; r < nr; r++) loc_rank[r] = (uint32_t)r;
+                } else if (p.sim_kind == 2) {
+                    loc_rank.resize(nr);
+                    for (size_t k = 0; k < nr; k++) loc_rank[p.sim_order[k]] = (uint32_t)k;
+                }
+                p.panel_locality_used = !loc_rank.empty();
+            }
             p.panel_off.assign(1, 0);
             p.panel_coop.clear();
             p.panel_long128.clear();
@@ -1360,6 +1419,18 @@ int build_plans(Part &p, size_t es, int *d_flag_sorted, hipStream_t st, int64_t 
                 }
                 uint32_t nco = 0;
                 for (uint32_t r : order) nco += (hi[r] - lo[r] > coop_cap) ? 1u : 0u;  // sorted: a prefix
+                if (!loc_rank.empty() && order.size() > nco) {
+                    // LOCALITY order (round 5) behind the wave-cooperative prefix: blocks of 2048 rows of the similarity (or id) order,
+                    // longest first inside a block (a stable counting sort by block of the length-sorted list).  Workgroups that run side
+                    // by side on an XCD then gather the same community's rows of X out of its L2 instead of 8 x 32 unrelated ones
+                    const uint32_t nblk = (uint32_t)((nr + 2047) / 2048);
+                    std::vector<size_t> bstart((size_t)nblk + 1, 0);
+                    for (size_t k = nco; k < order.size(); k++) bstart[(size_t)(loc_rank[order[k]] >> 11) + 1]++;
+                    for (size_t k = 1; k < bstart.size(); k++) bstart[k] += bstart[k - 1];
+                    std::vector<uint32_t> byblk(order.size() - nco);
+                    for (size_t k = nco; k < order.size(); k++) byblk[bstart[loc_rank[order[k]] >> 11]++] = order[k];
+                    std::copy(byblk.begin(), byblk.end(), order.begin() + nco);
+                }
                 p.panel_coop.push_back(nco);
                 uint32_t n256 = 0, n128 = 0, n64 = 0, n32 = 0;
                 uint64_t pn = 0;
@@ -1588,17 +1659,15 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     std::vector<uint32_t> rorder;
     if (want_code && geo.col_splits == 1 && p.nrows == p.ncols &&
         (g_tune.lds_tile_order == 1 || (g_tune.lds_tile_order == 2 && p.nnz >= (1 << 20)))) {
-        uint32_t n_labels = 0, largest = 0;
-        const std::string why = lds_similarity_order(p.rowptr, p.colind, (uint32_t)p.nrows, (int)std::min<int64_t>(std::max<int64_t>(g_tune.lds_lp_rounds, 0), 64), st, rorder,
-                                                     &n_labels, &largest);
-        if (!why.empty()) {
-            rorder.clear();
-            (void)hipGetLastError();
+        // automatic: ids that are local already (a row's columns span a small part of the id range: tiles of consecutive rows skip most
+        // chunks as they are) keep consecutive tiles; otherwise the propagation decides -- it must have found communities (more than
+        // one label, none holding half of the rows), else its order is the consecutive one anyway (profiles/r05_structured.txt)
+        find_similarity(p, st, g_tune.lds_tile_order == 1);
+        if (p.sim_kind == 2) {
+            rorder = p.sim_order;
+            p.lds_tile_labels = p.sim_labels;
+            p.lds_tile_largest = p.sim_largest;
         }
-        p.lds_tile_labels = n_labels;
-        p.lds_tile_largest = largest;
-        if (plan_timing) fprintf(stderr, "[pygim plan] similarity order: %u labels, the largest holds %u of %lld rows%s\n", n_labels, largest, (long long)p.nrows,
-                                 why.empty() ? "" : (" -- NOT used: " + why).c_str());
         lap("similarity order (label propagation)");
     }
     const uint32_t *ro = rorder.empty() ? nullptr : rorder.data();
@@ -2475,6 +2544,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "slice_group_bytes") slot = &g_tune.slice_group_bytes;
     else if (n == "fuse_windows") slot = &g_tune.fuse_windows;
     else if (n == "panel_col16") slot = &g_tune.panel_col16;
+    else if (n == "panel_locality") slot = &g_tune.panel_locality;
     else if (n == "split_unit_pattern") slot = &g_tune.split_unit_pattern;
     else if (n == "narrow_vals") slot = &g_tune.narrow_vals;
     else if (n == "merge_parts") slot = &g_tune.merge_parts;
@@ -2835,7 +2905,7 @@ int pygim_group_lds_tiles(int64_t handle, int64_t out[4]) {
     out[0] = p.lds_tile_labels ? 1 : 0;
     out[1] = p.lds_tile_labels;
     out[2] = p.lds_tile_largest;
-    out[3] = 0;
+    out[3] = p.panel_locality_used ? p.sim_kind : 0;   // the sweep's items in locality order: 1 = by id (local ids), 2 = by propagated label
     return 0;
 }
 

@@ -17,6 +17,7 @@ ap.add_argument("--kinds", default="uniform,clustered,rmat,sbm,sbm-sorted")
 ap.add_argument("--mode", type=int, default=1, help="lds_mode: 1 = LDS-staged product whenever planned, 0 = by the reuse rule")
 ap.add_argument("--orders", default="0,1")
 ap.add_argument("--reps", type=int, default=7)
+ap.add_argument("--locality", default="", help="panel_locality values to try per graph (the sweep's item order), e.g. 0,1")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 _lib.init_ranks(1)
@@ -27,15 +28,16 @@ x = synth.features(n, args.h, dt, seed=0, device=dev)
 out = torch.empty((n, args.h), dtype=dt, device=dev)
 _lib.set_tunable("lds_mode", args.mode)
 print(f"# {args.shape}-shaped (N = {n}, nnz = {nnz}), {args.dtype} h = {args.h}, lds_mode = {args.mode}; ids of rmat / sbm graphs shuffled, sbm-sorted = the same SBM with its communities in id order")
-print(f"# {'graph':12s} {'tiles':>12s} {'ms':>8s} {'median':>8s} {'kernel':>22s} {'chunk fills':>12s} {'of all':>7s} {'shared reads':>13s} {'labels':>7s} {'largest':>8s} {'create ms':>10s}  check")
+print(f"# {'graph':12s} {'tiles':>12s} {'ms':>8s} {'median':>8s} {'kernel':>30s} {'chunk fills':>12s} {'of all':>7s} {'shared reads':>13s} {'labels':>7s} {'largest':>8s} {'create ms':>10s}  check")
 for kind in args.kinds.split(","):
     if kind == "sbm-sorted":
         rowptr, col = synth.make_shape(args.shape, seed=0, device=dev, kind="sbm", shuffle=False)
     else:
         rowptr, col = synth.make_shape(args.shape, seed=0, device=dev, kind=None if kind == "uniform" else kind)
     want = torch.bincount(col.long(), minlength=n).double() @ x.double()
-    for order in (int(v) for v in args.orders.split(",")):
+    for order, loc in [(int(v), int(w)) for v in args.orders.split(",") for w in (args.locality.split(",") if args.locality else ["1"])]:
         _lib.set_tunable("lds_tile_order", order)
+        _lib.set_tunable("panel_locality", loc)
         torch.cuda.synchronize()
         t0 = time.time()
         hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [args.h], args.h)
@@ -52,10 +54,10 @@ for kind in args.kinds.split(","):
             ts.append(a.elapsed_time(b))
         ok = "OK" if torch.equal(out.double().sum(0), want) else "MISMATCH"
         lp, lc, geo, lt = _lib.group_lds_plan(hd), _lib.group_lds_code(hd), _lib.group_lds_geometry(hd), _lib.group_lds_tiles(hd)
-        kern = "code stream" if lc["active"] else ("token kernels" if lp["tiles"] else "L2 sweep")
+        kern = "code stream" if lc["active"] else ("token kernels" if lp["tiles"] else ("L2 sweep" + ("" if not lt["sweep_locality"] else (", items by id block" if lt["sweep_locality"] == 1 else ", items by label"))))
         nchunks = (n + max(geo["chunk_cols"], 1) - 1) // max(geo["chunk_cols"], 1)
         fills = lp["chunk_fills"]
-        print(f"  {kind:12s} {'similarity' if lt['similarity'] else 'consecutive':>12s} {min(ts):8.3f} {sorted(ts)[len(ts) // 2]:8.3f} {kern:>22s} {fills:12d} "
+        print(f"  {kind:12s} {'similarity' if lt['similarity'] else 'consecutive':>12s} {min(ts):8.3f} {sorted(ts)[len(ts) // 2]:8.3f} {kern:>30s} {fills:12d} "
               f"{(fills / max(lp['tiles'] * nchunks, 1)):7.3f} {(geo['shared_entries'] / max(lp['nnz'], 1)):13.3f} {lt['labels']:7d} {lt['largest_label_rows']:8d} {t_create:10.1f}  {ok}",
               flush=True)
         _lib.group_free(hd)

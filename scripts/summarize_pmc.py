@@ -8,6 +8,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 agg = defaultdict(lambda: [0.0, 0])
+dur = defaultdict(lambda: [0.0, 0])   # kernel -> [sum of (End - Start) ns, dispatches] of the counter passes (one row per dispatch and counter)
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
@@ -18,6 +19,9 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
             key = (name, row["Counter_Name"])
             agg[key][0] += float(row["Counter_Value"])
             agg[key][1] += 1
+            if row["Counter_Name"] == "FETCH_SIZE" and row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                dur[name][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                dur[name][1] += 1
 lines = []
 for (k, c), (tot, n) in sorted(agg.items()):
     lines.append(f"{k:40s} {c:34s} avg/dispatch {tot / n:18.1f}  dispatches {n}")
@@ -48,7 +52,9 @@ if dom and (dom, "WRITE_SIZE") in agg:
     rec = {"collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "box": socket.gethostname(),
            "command": "rocprofv3 --pmc <one counter group per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
                       "(scripts/profile_pmc.sh)",
-           "kernel": dom, "hbm_bytes_per_launch": per_launch, "launches_per_product": launches_per_product,
+           "kernel": dom, "kernel_ms": (dur[dom][0] / dur[dom][1] * 1e-6 if dur[dom][1] else None),   # of the FETCH_SIZE pass: bench.py replays the
+           # traffic only when its own kernel time is within 10 % of this
+           "hbm_bytes_per_launch": per_launch, "launches_per_product": launches_per_product,
            "hbm_bytes_per_product": per_launch * launches_per_product,
            "fetch_size_kib_avg": f_tot / f_n, "write_size_kib_avg": w_tot / w_n,
            "l2_hit_rate": hit[0] / max(hit[0] + miss[0], 1),

@@ -75,3 +75,22 @@ def test_the_propagation_finds_planted_communities_and_tiles_share_reads(forced)
             assert 30 <= tiles["labels"] <= 80 and tiles["largest_label_rows"] <= 1500, tiles
         assert got.tobytes() == oracle.spmm_csr(rowptr.cpu().numpy(), col.cpu().numpy(), None, x.cpu().numpy()).tobytes()
     assert shared[1] > 2 * shared[0] and shared[1] > 0.3, shared
+
+
+@pytest.mark.parametrize("kind", ["sbm", "clustered", None])
+def test_sweep_items_in_locality_order_give_the_same_product(kind):
+    """the L2 sweep with its work items in locality order (panel_locality: blocks of the propagated / id order behind the wave-cooperative
+    prefix) -- the same rows, the same stored order inside each: integers exact, floats bit-identical wherever they were before"""
+    dev = torch.device("cuda", 0)
+    rowptr, col = synth.make_shape("products-mini", seed=4, device=dev, kind=kind)
+    n = rowptr.numel() - 1
+    old = _lib.set_tunable("lds_mode", 2), _lib.set_tunable("panel_locality", 2)
+    try:
+        for dt, code in ((torch.int32, _lib.INT32), (torch.float32, _lib.FLT32)):
+            x = synth.features(n, 100, dt, seed=6, device=dev)
+            got, (tiles, code_info, geo, plan) = _product(rowptr, col, x, code)
+            assert plan["tiles"] == 0 and tiles["sweep_locality"] in (1, 2), (tiles, plan)
+            assert got.tobytes() == oracle.spmm_csr(rowptr.cpu().numpy(), col.cpu().numpy(), None, x.cpu().numpy()).tobytes(), (kind, dt)
+    finally:
+        _lib.set_tunable("lds_mode", old[0])
+        _lib.set_tunable("panel_locality", old[1])
