@@ -206,8 +206,28 @@ def main():
 
     n, nnz, d_max = synth.SHAPES[args.shape]
     h = args.hidden
-    # every rank builds the same seeded graph and features on its own device
-    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered)
+    # every rank builds the same seeded graph and features on its own device.  Ranks that SHARE a device (the N > 1 logic checks on one
+    # GPU, scripts/check_multirank.sh: never a measurement) would run world x the 115 M-entry generation on it at once -- in round 4 that
+    # alone starved the row / feature runs past their time-outs: there rank 0 generates, the others read its arrays from /dev/shm
+    shared_dev = multi and torch.cuda.device_count() < world
+    if shared_dev:
+        shm = os.path.join("/dev/shm", f"pygim_bench_{os.environ.get('MASTER_PORT', '0')}_{args.shape}_{int(args.clustered)}")
+        if rank == 0:
+            rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered)
+            os.makedirs(shm, exist_ok=True)
+            np.save(os.path.join(shm, "rowptr.npy"), rowptr.cpu().numpy())
+            np.save(os.path.join(shm, "col.npy"), col.cpu().numpy())
+        dist.barrier()
+        if rank != 0:
+            rowptr = torch.from_numpy(np.load(os.path.join(shm, "rowptr.npy"))).to(dev)
+            col = torch.from_numpy(np.load(os.path.join(shm, "col.npy"))).to(dev)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+
+            shutil.rmtree(shm, ignore_errors=True)
+    else:
+        rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev, clustered=args.clustered)
     x = synth.features(n, h, torch.float32, seed=0, device=dev)
     torch.cuda.synchronize()
 

@@ -48,6 +48,7 @@ struct CgParams {
     uint32_t opcode_add = 0x02000000u, addw = 1;   // dwords per accumulate
     uint32_t pieces = 4, chunk_bytes = 32768;
     uint32_t nrows = 0, ncols = 0, nchunks = 0, ntiles = 0, nstreams = 0;
+    uint32_t S = 1, row_tiles = 0;                  // column ranges per row tile (col_splits); ntiles = row_tiles * S
     uint32_t col_bits = 1;                          // key = stream << (col_bits + 8) | col << 8 | k
     // register map (LdsCodeRegs)
     uint32_t x0 = 6, acc0 = 28, vbase0 = 1, vbase1 = 2, vbase2 = 3, vl16 = 4, vtouch = 4, vjunk = 5;
@@ -58,7 +59,6 @@ struct CgParams {
 constexpr uint32_t CG_TOUCH_EVERY_DW = 256;   // (lds_code_from_plan: TOUCH_EVERY_DW)
 
 inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valued, uint32_t nrows, uint32_t ncols, uint32_t gsize = 0, uint32_t nsets = 0) {
-    if (geo.col_splits > 1) throw std::runtime_error("lds codegen: column-split plans take the host encoder");
     if (geo.NBUF >= 3 && !geo.boundary) throw std::runtime_error("lds codegen: the mid-slot hand-off takes the host encoder");
     CgParams P;
     const bool wide = geo.row_bytes == 512;
@@ -80,8 +80,11 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
     P.nrows = nrows; P.ncols = ncols;
     P.nchunks = (ncols + geo.KC - 1) / geo.KC;
     const uint32_t R_rows = geo.rows_per_tile ? std::min(geo.rows_per_tile, geo.NW * geo.KA) : geo.NW * geo.KA;
-    P.ntiles = (nrows + R_rows - 1) / R_rows;
+    P.S = std::max(1u, geo.col_splits);
+    P.row_tiles = (nrows + R_rows - 1) / R_rows;
+    P.ntiles = P.row_tiles * P.S;
     P.nstreams = P.ntiles * geo.NW;
+    if ((uint64_t)nrows * P.S >= (1ull << 32)) throw std::runtime_error("lds codegen: rows x column ranges beyond 32 bits");
     P.col_bits = 1;
     while (P.col_bits < 32 && (1ull << P.col_bits) < (uint64_t)ncols) P.col_bits++;
     uint32_t sb = 1;
@@ -103,47 +106,62 @@ inline uint32_t cg_key_bits(const CgParams &P) {
 // serpentine over the waves; tiles heaviest first), for one column range per row tile
 // ------------------------------------------------------------------------------------------------------------------------------------
 struct CgRows {
-    std::vector<uint32_t> rowinfo;   // per row: stream << 8 | k   (stream = sorted tile index * NW + wave)
-    std::vector<uint32_t> rowmap;    // [ntiles][NW][ka_stride], sorted tile order (0xFFFFFFFF = none) -- what the kernel's store stage reads
-    std::vector<uint32_t> tile_row0, tile_nnz;   // sorted tile order
+    std::vector<uint32_t> rowinfo;   // per row: (row tile * NW + wave) << 8 | k
+    std::vector<uint32_t> rowmap_rt; // [row_tiles][NW][ka_stride]: the row at (row tile, wave, accumulator) (0xFFFFFFFF = none)
+    std::vector<uint32_t> tnnz;      // [row_tiles * S]: stored entries of (row tile, column range), unsorted tile order
+    std::vector<uint32_t> tile_pos;  // [row_tiles * S]: position of (row tile, column range) in the launch order (heaviest first)
+    std::vector<uint32_t> rowmap;    // [ntiles][NW][ka_stride], launch order -- what the kernel's store stage reads (row + range * nrows)
+    std::vector<uint32_t> tile_row0, tile_nnz;   // launch order
 };
-inline void cg_deal_rows(const uint32_t *rowptr, const LdsGeometry &geo, const CgParams &P, CgRows &out, const uint32_t *rorder = nullptr) {
+// phase a (row pointers alone): every row's tile, wave and accumulator.  One column range per tile: the tiles' entry counts as well
+inline void cg_deal_rows_a(const uint32_t *rowptr, const LdsGeometry &geo, const CgParams &P, CgRows &out, const uint32_t *rorder = nullptr) {
     auto rid = [&](uint32_t pos) { return rorder ? rorder[pos] : pos; };   // (lds_plan_build: the row at a position of the tile order)
     auto rlen = [&](uint32_t pos) { const uint32_t r = rid(pos); return rowptr[r + 1] - rowptr[r]; };
     const uint32_t NW = geo.NW, KA = geo.KA, KAS = geo.ka_stride(), RS = NW * KAS;
     const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, NW * KA) : NW * KA;
-    const uint32_t nrows = P.nrows, ntiles = P.ntiles;
-    std::vector<uint32_t> nnz(ntiles), ord(ntiles), pos(ntiles);
-    for (uint32_t t = 0; t < ntiles; t++) {
-        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R);
-        if (!rorder) nnz[t] = rowptr[r1] - rowptr[r0];
-        else {
-            nnz[t] = 0;
-            for (uint32_t q = r0; q < r1; q++) nnz[t] += rlen(q);
-        }
-        ord[t] = t;
-    }
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return nnz[a] > nnz[b]; });
-    for (uint32_t i = 0; i < ntiles; i++) pos[ord[i]] = i;
+    const uint32_t nrows = P.nrows, nrt = P.row_tiles;
     out.rowinfo.assign(nrows, 0);
-    out.rowmap.assign((size_t)ntiles * RS, 0xFFFFFFFFu);
-    out.tile_row0.assign(ntiles, 0);
-    out.tile_nnz.assign(ntiles, 0);
+    out.rowmap_rt.assign((size_t)nrt * RS, 0xFFFFFFFFu);
+    out.tnnz.assign((size_t)nrt * P.S, 0);
     std::vector<uint32_t> order;
-    for (uint32_t t = 0; t < ntiles; t++) {
-        const uint32_t r0 = t * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0, ti = pos[t];
-        out.tile_row0[ti] = r0;
-        out.tile_nnz[ti] = nnz[t];
+    for (uint32_t rt = 0; rt < nrt; rt++) {
+        const uint32_t r0 = rt * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0;
+        if (P.S == 1) {
+            if (!rorder) out.tnnz[rt] = rowptr[r1] - rowptr[r0];
+            else
+                for (uint32_t q = r0; q < r1; q++) out.tnnz[rt] += rlen(q);
+        }
         order.resize(nr);
         for (uint32_t i = 0; i < nr; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return rlen(r0 + a) > rlen(r0 + b);
-        });
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rlen(r0 + a) > rlen(r0 + b); });
         for (uint32_t i = 0; i < nr; i++) {
             const uint32_t round = i / NW, p = i % NW;
             const uint32_t w = (round & 1) ? NW - 1 - p : p;
-            out.rowinfo[rid(r0 + order[i])] = ((ti * NW + w) << 8) | round;
-            out.rowmap[((size_t)ti * NW + w) * KAS + round] = rid(r0 + order[i]);
+            out.rowinfo[rid(r0 + order[i])] = ((rt * NW + w) << 8) | round;
+            out.rowmap_rt[((size_t)rt * NW + w) * KAS + round] = rid(r0 + order[i]);
+        }
+    }
+}
+// phase b (the tiles' entry counts known -- S > 1: counted on the device): launch order (heaviest first, stable), row map, tile table
+inline void cg_deal_rows_b(const LdsGeometry &geo, const CgParams &P, CgRows &out) {
+    const uint32_t NW = geo.NW, KAS = geo.ka_stride(), RS = NW * KAS;
+    const uint32_t R = geo.rows_per_tile ? std::min(geo.rows_per_tile, NW * geo.KA) : NW * geo.KA;
+    const uint32_t ntiles = P.ntiles;
+    std::vector<uint32_t> ord(ntiles);
+    for (uint32_t t = 0; t < ntiles; t++) ord[t] = t;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tnnz[a] > out.tnnz[b]; });
+    out.tile_pos.assign(ntiles, 0);
+    for (uint32_t i = 0; i < ntiles; i++) out.tile_pos[ord[i]] = i;
+    out.rowmap.assign((size_t)ntiles * RS, 0xFFFFFFFFu);
+    out.tile_row0.assign(ntiles, 0);
+    out.tile_nnz.assign(ntiles, 0);
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint32_t rt = t / P.S, cs = t % P.S, ti = out.tile_pos[t];
+        out.tile_row0[ti] = rt * R;
+        out.tile_nnz[ti] = out.tnnz[t];
+        for (uint32_t q = 0; q < RS; q++) {
+            const uint32_t r = out.rowmap_rt[(size_t)rt * RS + q];
+            if (r != 0xFFFFFFFFu) out.rowmap[(size_t)ti * RS + q] = r + cs * P.nrows;
         }
     }
 }
@@ -175,6 +193,8 @@ struct CgTables {
     // inputs
     const uint32_t *rowptr = nullptr, *colind = nullptr, *vals_in = nullptr;   // CSR (vals: raw bits of 4-byte values, valued only)
     const uint32_t *rowinfo = nullptr;                                          // per row
+    const uint32_t *tile_pos = nullptr;                                         // [row_tiles * S] -> launch position of the tile
+    uint32_t *tnnz = nullptr;                                                   // [row_tiles * S] stored entries (counted when S > 1)
     const uint32_t *nch = nullptr, *choff = nullptr, *chunks = nullptr;         // per tile
     uint8_t *flags = nullptr;                                                   // [ntiles][nchunks]
     // per entry
@@ -218,6 +238,19 @@ PYGIM_HD inline uint32_t cg_slot_of(const CgTables &T, uint32_t ti, uint32_t ch)
 PYGIM_HD inline uint32_t cg_key_stream(const CgParams &P, uint64_t key) { return (uint32_t)(key >> (P.col_bits + 8)); }
 PYGIM_HD inline uint32_t cg_key_col(const CgParams &P, uint64_t key) { return (uint32_t)((key >> 8) & ((1ull << P.col_bits) - 1)); }
 
+// column range of a chunk: range c holds chunks [nchunks * c / S, nchunks * (c + 1) / S)   (lds_plan_build: ch_lo, ch_hi)
+PYGIM_HD inline uint32_t cg_range_of(const CgParams &P, uint32_t ch) {
+    if (P.S == 1) return 0;
+    uint32_t c = (uint32_t)((uint64_t)ch * P.S / P.nchunks);
+    while (c > 0 && ch < (uint32_t)((uint64_t)P.nchunks * c / P.S)) c--;
+    while (c + 1 < P.S && ch >= (uint32_t)((uint64_t)P.nchunks * (c + 1) / P.S)) c++;
+    return c;
+}
+// the stream of an entry: its row's (row tile, wave), its column's range -> the tile's launch position
+PYGIM_HD inline uint32_t cg_stream_of(const CgParams &P, const CgTables &T, uint32_t ri, uint32_t col) {
+    const uint32_t rw = ri >> 8, rt = rw / P.NW, w = rw % P.NW;
+    return T.tile_pos[rt * P.S + cg_range_of(P, col / P.KC)] * P.NW + w;
+}
 // (stream, slot) of a slot index (the device runs a thread per index)
 PYGIM_HD inline void cg_sj_decode(const CgParams &P, const CgTables &T, uint32_t sj, uint32_t *s, uint32_t *j) {
     uint32_t lo = 0, hi = P.ntiles;   // last tile whose first slot index is <= sj (tiles without chunks own no index)
@@ -233,13 +266,16 @@ PYGIM_HD inline void cg_sj_decode(const CgParams &P, const CgTables &T, uint32_t
     *j = rel % n;
 }
 // D0 / D1: per row (the device runs a wave per row, lanes over its entries)
+PYGIM_HD inline uint32_t cg_tile_of_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {   // (row tile, column range), unsorted index
+    return ((T.rowinfo[row] >> 8) / P.NW) * P.S + cg_range_of(P, T.colind[e] / P.KC);
+}
 PYGIM_HD inline void cg_mark_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
-    const uint32_t ti = (T.rowinfo[row] >> 8) / P.NW;
+    const uint32_t ti = cg_stream_of(P, T, T.rowinfo[row], T.colind[e]) / P.NW;
     T.flags[(size_t)ti * P.nchunks + T.colind[e] / P.KC] = 1;
 }
 PYGIM_HD inline void cg_key_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
-    const uint32_t ri = T.rowinfo[row];
-    T.keys[e] = ((uint64_t)(ri >> 8) << (P.col_bits + 8)) | ((uint64_t)T.colind[e] << 8) | (ri & 255u);
+    const uint32_t ri = T.rowinfo[row], c = T.colind[e];
+    T.keys[e] = ((uint64_t)cg_stream_of(P, T, ri, c) << (P.col_bits + 8)) | ((uint64_t)c << 8) | (ri & 255u);
     if (P.valued) T.vals[e] = T.vals_in[e];
 }
 // D3: per sorted entry
@@ -504,9 +540,14 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
                            uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr) {
     const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets);
     const uint64_t nnz = rowptr[nrows];
-    cg_deal_rows(rowptr, geo, P, out.rows, rorder);
+    cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;
+    if (P.S > 1)   // (the device counts these with one atomic per (row, range))
+        for (uint32_t r = 0; r < nrows; r++)
+            for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; e++) out.rows.tnnz[cg_tile_of_entry(P, T, r, e)]++;
+    cg_deal_rows_b(geo, P, out.rows);
+    T.tile_pos = out.rows.tile_pos.data();
     std::vector<uint8_t> flags((size_t)P.ntiles * P.nchunks + 1, 0);
     T.flags = flags.data();
     for (uint32_t r = 0; r < nrows; r++)

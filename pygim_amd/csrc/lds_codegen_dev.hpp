@@ -166,12 +166,29 @@ inline void cg_radix_sort(uint64_t **keys_a, uint64_t **keys_b, uint32_t **vals_
 // ------------------------------------------------------------------------------------------------------------------------------------
 // the bodies of lds_codegen.hpp as kernels
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <int WHAT>   // 0 = mark chunks, 1 = keys: a wave per row, lanes over its entries
+template <int WHAT>   // 0 = mark chunks, 1 = keys, 2 = entries per (row tile, column range): a wave per row, lanes over its entries
 __global__ __launch_bounds__(256) void k_cg_rows(CgParams P, CgTables T) {
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= P.nrows) return;
-    const uint32_t e1 = T.rowptr[row + 1];
-    for (uint32_t e = T.rowptr[row] + (threadIdx.x & 63); e < e1; e += 64) {
+    const uint32_t e0 = T.rowptr[row], e1 = T.rowptr[row + 1], lane = threadIdx.x & 63;
+    if (WHAT == 2) {
+        // one atomic per (row, range) and wave step: the lanes that hold the same tile find each other (a row's ranges are runs: sorted columns)
+        for (uint32_t base = e0; base < e1; base += 64) {
+            const uint32_t e = base + lane;
+            const bool valid = e < e1;
+            const uint32_t t = valid ? cg_tile_of_entry(P, T, (uint32_t)row, e) : 0u;
+            uint64_t todo = __ballot(valid);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t tl = (uint32_t)__shfl((int)t, leader, 64);
+                const uint64_t same = __ballot(valid && t == tl);
+                if ((int)lane == leader) atomicAdd(&T.tnnz[tl], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+        }
+        return;
+    }
+    for (uint32_t e = e0 + lane; e < e1; e += 64) {
         if (WHAT == 0) cg_mark_entry(P, T, (uint32_t)row, e);
         else cg_key_entry(P, T, (uint32_t)row, e);
     }
@@ -282,10 +299,11 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     int phase = 0;
     auto lap = [&]() { const double t = now_ms(); out.ms[phase++] = t - t_mark; t_mark = t; };
 
-    // host: rows -> tiles / waves / accumulators (from the row pointers alone)
+    // host: rows -> tiles / waves / accumulators (from the row pointers alone); column-split plans: the entries of every (row tile, column
+    // range) are counted on the device before the tiles are put in launch order (heaviest first)
     CgRows rows;
     try {
-        cg_deal_rows(h_rowptr, geo, P, rows, h_rorder);
+        cg_deal_rows_a(h_rowptr, geo, P, rows, h_rorder);
     } catch (const std::exception &e) {
         return bail(e.what());
     }
@@ -293,15 +311,25 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     T.rowptr = d_rowptr; T.colind = d_col; T.vals_in = d_vals; T.nnz = nnz;
     uint32_t *d_rowinfo = (uint32_t *)dalloc((size_t)nrows * 4);
     uint8_t *d_flags = (uint8_t *)dalloc((size_t)P.ntiles * P.nchunks + 1);
+    uint32_t *d_tile_pos = (uint32_t *)dalloc((size_t)P.ntiles * 4), *d_tnnz = (uint32_t *)dalloc((size_t)P.ntiles * 4);
     if (failed) return bail("lds codegen: out of device memory (row tables)");
     if (!ok(hipMemcpyAsync(d_rowinfo, rows.rowinfo.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, st)) ||
-        !ok(hipMemsetAsync(d_flags, 0, (size_t)P.ntiles * P.nchunks + 1, st)))
+        !ok(hipMemsetAsync(d_flags, 0, (size_t)P.ntiles * P.nchunks + 1, st)) || !ok(hipMemsetAsync(d_tnnz, 0, (size_t)P.ntiles * 4, st)))
         return bail("lds codegen: row table upload");
     T.rowinfo = d_rowinfo;
     T.flags = d_flags;
+    T.tnnz = d_tnnz;
+    const unsigned row_blocks = (unsigned)(((uint64_t)nrows + 3) / 4);
+    if (P.S > 1) {
+        hipLaunchKernelGGL((k_cg_rows<2>), dim3(row_blocks), dim3(256), 0, st, P, T);
+        if (!ok(hipMemcpyAsync(rows.tnnz.data(), d_tnnz, (size_t)P.ntiles * 4, hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st)))
+            return bail("lds codegen: entries per (row tile, column range)");
+    }
+    cg_deal_rows_b(geo, P, rows);
+    if (!ok(hipMemcpyAsync(d_tile_pos, rows.tile_pos.data(), (size_t)P.ntiles * 4, hipMemcpyHostToDevice, st))) return bail("lds codegen: tile order upload");
+    T.tile_pos = d_tile_pos;
     lap();
     // D0: chunks present per tile -> chunk lists (host)
-    const unsigned row_blocks = (unsigned)(((uint64_t)nrows + 3) / 4);
     hipLaunchKernelGGL((k_cg_rows<0>), dim3(row_blocks), dim3(256), 0, st, P, T);
     std::vector<uint8_t> h_flags((size_t)P.ntiles * P.nchunks + 1);
     if (!ok(hipMemcpyAsync(h_flags.data(), d_flags, h_flags.size(), hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) return bail("lds codegen: chunk flags");

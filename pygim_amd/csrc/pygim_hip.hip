@@ -1657,7 +1657,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
     // Round 5: similarity tiles (lds_reorder_dev.hpp) -- rows with similar neighbourhoods share a tile: shared LDS reads, skipped chunks.
     // The result does not depend on the order (each row is summed by one wave in stored order whichever tile holds it).
     std::vector<uint32_t> rorder;
-    if (want_code && geo.col_splits == 1 && p.nrows == p.ncols &&
+    if (want_code && p.nrows == p.ncols &&
         (g_tune.lds_tile_order == 1 || (g_tune.lds_tile_order == 2 && p.nnz >= (1 << 20)))) {
         // automatic: ids that are local already (a row's columns span a small part of the id range: tiles of consecutive rows skip most
         // chunks as they are) keep consecutive tiles; otherwise the propagation decides -- it must have found communities (more than
@@ -1709,7 +1709,7 @@ static int build_lds_plan_form(Part &p, size_t es, int *d_flag_sorted, hipStream
             p.lds_code_piece = geo.KC * geo.row_bytes / geo.NW;
             p.lds_code_gsize = dr.regs.gsize;
             p.lds_code_nsets = dr.regs.nsets;
-            p.lds_col_splits = 1;
+            p.lds_col_splits = geo.col_splits;
             p.lds_kc = geo.KC;
             p.lds_nbuf = geo.NBUF;
             p.lds_row_bytes = geo.row_bytes;

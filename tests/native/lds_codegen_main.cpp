@@ -63,10 +63,11 @@ int main(int argc, char **argv) {
         geo.NW = q[0]; geo.KA = q[1]; geo.KC = q[2]; geo.NBUF = q[3]; geo.row_bytes = q[6]; geo.BATCH = 8;
         geo.boundary = 1;
         geo.rows_per_tile = (rng() % 4 == 0) ? 16 + (uint32_t)(rng() % 1500) : 0;
+        geo.col_splits = (rng() % 4 == 0) ? 2 + (uint32_t)(rng() % 7) : 1;   // tiles split into column ranges (short row shares on N GPUs)
         const bool wide = q[6] == 512;
         const uint32_t ops4[] = {0x02000000u, 0x68000000u, LDS_CODE_PK_ADD_U16};
         const uint32_t op = wide ? ((rng() & 1) ? LDS_CODE_ADD_F64 : LDS_CODE_ADD_U64) : ops4[rng() % 3];
-        const bool valued = !wide && op == 0x02000000u && rng() % 3 == 0;
+        const bool valued = !wide && op == 0x02000000u && geo.col_splits == 1 && rng() % 3 == 0;
         std::vector<uint32_t> vals;
         if (valued) {
             vals.resize(m.col.size());
@@ -89,8 +90,8 @@ int main(int argc, char **argv) {
         CgHostResult r;
         cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5], ro);
         auto bad = [&](const char *what) {
-            printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, op %08x, valued %d, dups %d, clustered %d)\n", c, what, q[0], q[1], q[2], q[3],
-                   q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, op, (int)valued, (int)dups, (int)clustered);
+            printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, splits %u, op %08x, valued %d, dups %d, clustered %d)\n", c, what, q[0], q[1], q[2], q[3],
+                   q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, geo.col_splits, op, (int)valued, (int)dups, (int)clustered);
             return 1;
         };
         if (r.rows.rowmap != plan.rowmap) return bad("row map");

@@ -33,7 +33,6 @@ def backend():
 @pytest.fixture()
 def checked():
     old = _lib.set_tunable("lds_mode", 1), _lib.set_tunable("lds_codegen", 2)
-    _lib.set_tunable("lds_col_split", 1)   # (never: short integer shares would otherwise be split into column ranges -- the host encoder's)
     yield
     _lib.set_tunable("lds_mode", old[0])
     _lib.set_tunable("lds_codegen", old[1])
@@ -99,14 +98,33 @@ def test_device_stream_equals_host_stream_every_geometry(rng, checked, geo):
         assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (geo, dt, n, ncols, h)
 
 
+@pytest.mark.parametrize("splits", [2, 3, 8])
+def test_column_split_tiles(rng, checked, splits):
+    """short row shares (a rank's share on N GPUs): every row tile becomes `splits` workgroup tiles, each with a range of the chunks, partial
+    sums reduced in range order -- generated on the device like the rest (the entries of every (row tile, range) are counted there before
+    the tiles are put in launch order), word for word the host encoder's"""
+    old = _lib.set_tunable("lds_col_split", splits), _lib.set_tunable("lds_col_split_f32", 1)
+    try:
+        for dt in (np.int32, np.float32):
+            n, ncols, h = int(rng.integers(500, 4000)), int(rng.integers(2000, 9000)), int(rng.integers(64, 260))
+            rowptr, col = random_csr(rng, n, ncols, float(rng.uniform(5, 40)), empty_frac=0.2, long_rows=[(3, 4000)])
+            x = feats(rng, ncols, h, dt) if dt == np.int32 else rng.integers(-8, 4, size=(ncols, h)).astype(np.float32)   # (exact float sums: the ranges reorder them)
+            got, info, note = run(rowptr, col, x)
+            assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+            assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (splits, dt)
+    finally:
+        _lib.set_tunable("lds_col_split", old[0])
+        _lib.set_tunable("lds_col_split_f32", old[1])
+
+
 def test_plans_the_device_form_does_not_cover_say_so(rng):
-    """column-split tiles and the mid-slot hand-off are written by the host encoder, and the group says it (nothing silent)"""
+    """the mid-slot hand-off (and lds_codegen = 0) is written by the host encoder, and the group says it (nothing silent)"""
     old = _lib.set_tunable("lds_mode", 1)
     try:
         rowptr, col = random_csr(rng, 3000, 2500, 20)
         x = feats(rng, 2500, 128, np.int32)
         want = oracle.spmm_csr(rowptr, col, None, x)
-        for knob, val, why in (("lds_code_boundary", 2, "mid-slot"), ("lds_col_split", 3, "column-split"), ("lds_codegen", 0, "lds_codegen = 0")):
+        for knob, val, why in (("lds_code_boundary", 2, "mid-slot"), ("lds_codegen", 0, "lds_codegen = 0")):
             prev = _lib.set_tunable(knob, val)
             prev_split = _lib.set_tunable("lds_col_split", 1) if knob != "lds_col_split" else None   # (no automatic column ranges)
             try:
