@@ -116,36 +116,10 @@ def cpu_baseline(rowptr, col, x, args):
 
 
 def self_launch(n_gpus):
-    """`python bench.py --gpus N` as a plain command: start the N ranks as CHILD processes (torch.distributed.run, one per
-    GPU, rendezvous on 127.0.0.1), relay their output and return their exit code.  Nothing in this process has touched the
-    GPU yet, and nothing is exec'ed: a failing rank makes the launcher (max-restarts 0) and this process exit non-zero."""
-    import socket
-    import subprocess
+    """`python bench.py --gpus N` as a plain command (pygim_amd/launch.py: the N ranks as CHILD processes of torch.distributed.run)"""
+    from pygim_amd.launch import self_launch as _launch
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_quota() // max(n_gpus, 1))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "--max-restarts", "0", os.path.abspath(__file__)] + sys.argv[1:]
-    # the children run in a process group of their own: a hung rank (a collective that never completes) is ended -- that group,
-    # by its id, nothing else -- when the launch outlives PYGIM_LAUNCH_TIMEOUT seconds, instead of hanging the caller for good
-    limit = float(os.environ.get("PYGIM_LAUNCH_TIMEOUT", "2400"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        return child.wait(timeout=limit)
-    except subprocess.TimeoutExpired:
-        import signal
-
-        print(f"[bench] the {n_gpus}-rank launch did not finish within {limit:.0f} s: ending its process group", file=sys.stderr)
-        try:
-            os.killpg(child.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        child.wait()
-        return 124
+    return _launch(os.path.abspath(__file__), n_gpus, sys.argv[1:], threads_per_rank=max(1, cpu_quota() // max(n_gpus, 1)), tag="bench")
 
 
 def main():
@@ -297,6 +271,7 @@ def main():
         autotune.LDS_COL_SPLIT = True
 
     prior, table = autotune.choose(n, n, nnz, h, 4, max(world, 1))
+    prior_1, _ = autotune.choose(n, n, nnz, h, 4, 1)
     cands = []
     if args.partition == "pipelined":
         cands.append((PipelinedRows, 1))
@@ -578,8 +553,15 @@ def main():
                    "columns": "clustered" if args.clustered else "uniform",
                    "partition": plan.describe(), "candidate": f"{type(plan).__name__}:{plan.K}",
                    "candidates_timed_ms": timed, "rccl_world": rccl_world, "backend": backend if multi else None,
+                   # the chooser's forecast beside the measurement (pygim_amd/autotune.py: a rank's product + the exchange that re-assembles
+                   # C over xGMI; its link terms have never met real xGMI): the candidate it prefers, every (row parts x feature parts)
+                   # grid it priced, and the speed-up over its own 1-GPU price -- a measured SCALE run compares with THIS at once
                    "model_prior": {"row_parts": prior.row_parts, "feat_parts": prior.feat_parts,
-                                   "predicted_ms": round(prior.seconds * 1e3, 4)},
+                                   "predicted_ms": round(prior.seconds * 1e3, 4),
+                                   "predicted_product_ms": round(prior.product_s * 1e3, 4), "predicted_collective_ms": round(prior.collective_s * 1e3, 4),
+                                   "predicted_1gpu_ms": round(prior_1.seconds * 1e3, 4),
+                                   "predicted_speedup_vs_1gpu": round(prior_1.seconds / prior.seconds, 3) if prior.seconds > 0 else None,
+                                   "grids_priced_ms": {f"{c.row_parts}x{c.feat_parts}": round(c.seconds * 1e3, 4) for c in table}},
                    "per_rank": per_rank,
                    **({"headline_kernel_warning": headline_warning} if headline_warning else {}),
                    **({"ms_per_step_products_only": products_only_ms} if products_only_ms is not None else {})},

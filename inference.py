@@ -2,8 +2,8 @@
 """Counterpart of the reference's inference.py: end-to-end GNN inference (GCN / GIN / SAGE, random
 weights, eval mode) with the aggregation on the MI355X backend, timed as ``[DATA]infer_time(ms)``.
 
-Same flags as the reference (inference.py:96-124) plus ``--device`` and multi-GPU through
-``python -m torch.distributed.run --nproc-per-node N inference.py --version spmm ...`` (row split of A,
+Same flags as the reference (inference.py:96-124) plus ``--device`` and multi-GPU through ``--gpus N`` (the plain command starts its
+ranks itself) or ``python -m torch.distributed.run --nproc-per-node N inference.py --version spmm ...`` (row split of A,
 RCCL all-gather between layers: BASELINE config 4).  Datasets are seeded synthetic graphs with the
 named dataset's node / edge counts (no network); labels are random, so the accuracy print only keeps
 the reference's log shape (its model is untrained too, inference.py:154-163).
@@ -91,6 +91,8 @@ def get_args():
     ap.add_argument("--nr_dpus", type=int, default=0)
     ap.add_argument("--group_per_rank", type=int, default=1)  # what the harness passes to the multigroup backend (experiment.py:434); no meaning here
     ap.add_argument("--device", type=str, default="cuda" if torch.cuda.is_available() else "cpu")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 as a plain command: the N ranks are started as child processes of "
+                    "torch.distributed.run (pygim_amd/launch.py), one per GPU, row split of A with RCCL all-gathers between the layers")
     ap.add_argument("--graph", type=int, default=0, help="1 = capture the forward pass into a HIP graph after two warm-up runs and "
                     "replay it (one launch per inference: pays on small graphs, where a forward pass is ~40 short kernels)")
     ap.add_argument("--fuse_post", type=int, default=0, help="1 = GCN: bias + BatchNorm(eval) + ReLU folded into the "
@@ -172,4 +174,11 @@ def main(args):
 
 if __name__ == "__main__":
     os.environ.setdefault("PYGIM_DATA_LOG", "1")  # the reference's per-run [DATA] timer lines
-    main(get_args())
+    _args = get_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+
+        from pygim_amd.launch import self_launch
+
+        raise SystemExit(self_launch(os.path.abspath(__file__), _args.gpus, sys.argv[1:], threads_per_rank=max(1, (os.cpu_count() or 8) // _args.gpus), tag="inference"))
+    main(_args)

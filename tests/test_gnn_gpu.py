@@ -149,6 +149,14 @@ def _run_inference(world, extra, env_extra=None):
     return sums, accs
 
 
+def test_inference_gpus_flag_starts_its_own_ranks():
+    """`python inference.py --gpus 2 ...` as a plain command (round 5, as bench.py --gpus N: the ranks are child processes of
+    torch.distributed.run started by pygim_amd/launch.py) gives what the same command under an explicit launcher gives"""
+    plain, _ = _run_inference(1, ["--data_type=INT32", "--gpus=2"], {"PYGIM_BENCH_BACKEND": "gloo"})
+    launched, _ = _run_inference(2, ["--data_type=INT32"], {"PYGIM_BENCH_BACKEND": "gloo"})
+    assert plain == launched, (plain, launched)
+
+
 @pytest.mark.parametrize("dtype", ["INT8", "INT32"])
 def test_row_sharded_inference_two_ranks_equals_one_rank(dtype):
     """inference.py under torch.distributed.run with 2 ranks (gloo, both on this one GPU: a logic check of the N > 1 path --
