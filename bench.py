@@ -97,9 +97,25 @@ def cpu_baseline(rowptr, col, x, args):
         y = a @ xt
         dl = time.perf_counter() - t1
         lib = {"kind": "torch.sparse_csr @ dense (MKL)", "value": round(2.0 * nnz * xh.shape[1] / dl / 1e9, 3), "unit": "GFLOP/s",
-               "threads": torch.get_num_threads(), "seconds": round(dl, 3), "equal_to_port": bool(np.array_equal(y.numpy(), out))}
+               # (threads the pool was set to, and what the container's quota lets run at once: the second is what the rate reflects)
+               "threads": torch.get_num_threads(), "threads_effective": min(torch.get_num_threads(), cpu_quota()), "seconds": round(dl, 3),
+               "equal_to_port": bool(np.array_equal(y.numpy(), out))}
     except Exception as e:  # not every build has the CSR kernels
         lib = {"kind": "torch.sparse_csr @ dense (MKL)", "error": str(e)[:120]}
+    # the REFERENCE's own host loop (spmm_grande/spmm_mul_csr.c:119-136, compiled in place into oracle/_ref, one thread: row -> feature ->
+    # entry, as written) on the first rows -- the port's result there must be its bytes
+    ref_leg = None
+    try:
+        if oracle.have_ref_host():
+            nr_ref = int(min(nrows, 1500))
+            t2 = time.perf_counter()
+            y_ref = oracle.ref_spmm_host_csr(rp[: nr_ref + 1], cl[: int(rp[nr_ref])], None, xh, variant="grande")
+            dr = time.perf_counter() - t2
+            ref_leg = {"kind": "reference spmm_host_csr (spmm_grande/spmm_mul_csr.c:119-136), 1 thread", "rows": nr_ref,
+                       "value": round(2.0 * int(rp[nr_ref]) * xh.shape[1] / dr / 1e9, 3), "unit": "GFLOP/s", "seconds": round(dr, 3),
+                       "port_bit_identical": bool(y_ref.tobytes() == out[:nr_ref].tobytes())}
+    except Exception as e:  # noqa: BLE001
+        ref_leg = {"error": str(e)[:120]}
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -110,7 +126,7 @@ def cpu_baseline(rowptr, col, x, args):
         pass
     # "cores" = the threads the loop ran with; what they share is the container's CPU quota, stated beside it
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": threads, "cpu_quota_cpus": cpu_quota(), "kind": "port", "cpu_model": model,
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"), "library": lib,
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"), "library": lib, "reference_1thread": ref_leg,
             "sample": f"rows [0,{nrows}) of the same graph ({nnz} nnz, h={xh.shape[1]}), "
                       f"{dt:.2f} s wall, oracle row-parallel CSR loop, os.cpu_count()={os.cpu_count()}"}, out
 
@@ -314,8 +330,9 @@ def main():
         best = None
         for cls, kk in cands:
             # a candidate that cannot be set up on some rank (e.g. IPC refused, out of memory) is dropped on ALL ranks: every rank
-            # reports a status word and the MIN decides -- no rank sits in a fence while another has raised.  The only candidate
-            # failing ends every rank with the same non-zero exit
+            # reports a status word and the MIN decides -- no rank sits in a fence while another has raised.  Constructors WITH a
+            # collective inside (the push plans' IPC handle exchange) take part in it whatever their local half did and raise the
+            # same error on every rank (bench_plans.ipc_exchange).  The only candidate failing ends every rank with the same non-zero exit
             try:
                 if rank == fail_rank:
                     raise RuntimeError("PYGIM_BENCH_FAIL_RANK: forced set-up failure on this rank")

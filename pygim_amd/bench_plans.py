@@ -179,6 +179,34 @@ def build(env):
         if other != dev.index and not torch.cuda.can_device_access_peer(dev.index, other):
             raise RuntimeError(f"device {dev.index} has no peer access to device {other}")
 
+    def ipc_exchange(plan, local, reduce_tensor):
+        """The local half of a push plan's set-up (its group, its result matrices), then the IPC handle exchange -- in which EVERY rank takes
+        part whatever happened to its local half (a rank whose group_create raised used to skip the all_gather_object its peers
+        sat in).  A rank that failed sends an error marker; every rank then frees what it made and raises the same error."""
+        err, mine = None, None
+        try:
+            local()
+            if multi and world > 1:
+                mine = [reduce_tensor(c) for c in plan.C]  # (rebuild function, IPC handle + geometry) per buffer
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {str(e)[:200]}"
+        if not (multi and world > 1):
+            if err:
+                raise RuntimeError(err)
+            return
+        everyone = [None] * world
+        dist.all_gather_object(everyone, ("ERR", err) if err else ("OK", mine))
+        bad = [(r, m[1]) for r, m in enumerate(everyone) if m[0] == "ERR"]
+        if bad:
+            for hd in plan.handles:
+                _lib.group_free(hd)
+            plan.handles, plan.C = [], []
+            raise RuntimeError(f"push plan set-up failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
+        for r in range(world):
+            if r != rank:
+                plan.peer[r] = [fn(*a) for fn, a in everyone[r][1]]
+                check_peer(plan.peer[r][0])
+
     class PushRows:
         """sp_parts = world as an nnz-balanced row split whose exchange is a PUSH over xGMI by the copy engines: every rank
         writes its result block straight into its place in every peer's [N, h] matrix (the peers' buffers are opened through
@@ -196,18 +224,15 @@ def build(env):
             rp_c = (rowptr[c0:c1 + 1] - lo).contiguous()
             col_c = col[lo:hi].contiguous()
             self.keep = [rp_c, col_c]
-            self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None, [c1 - c0], [n],
-                                              [hi - lo], [1], [h], h)]
-            self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.handles, self.C = [], []
+
+            def local():   # (may raise on THIS rank only: out of memory, say)
+                self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rp_c.data_ptr()], [col_c.data_ptr()], None, [c1 - c0], [n],
+                                                  [hi - lo], [1], [h], h)]
+                self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+
             self.peer = [[None, None] for _ in range(world)]
-            if multi and world > 1:
-                mine = [reduce_tensor(c) for c in self.C]  # (rebuild function, IPC handle + geometry) per buffer
-                everyone = [None] * world
-                dist.all_gather_object(everyone, mine)
-                for r in range(world):
-                    if r != rank:
-                        self.peer[r] = [fn(*a) for fn, a in everyone[r]]
-                        check_peer(self.peer[r][0])
+            ipc_exchange(self, local, reduce_tensor)
             self.copy_streams = [env.Stream() for _ in range(world)]
             self.sync_stream = env.Stream()
             self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -406,18 +431,15 @@ def build(env):
             self.hip.hipMemcpy2DAsync.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                                   ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
             self.hip.hipMemcpy2DAsync.restype = ctypes.c_int
-            self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz],
-                                              [1], [self.hw], self.hw)]
-            self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.handles, self.C = [], []
+
+            def local():
+                self.handles = [_lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz],
+                                                  [1], [self.hw], self.hw)]
+                self.C = [torch.zeros((n, h), dtype=torch.float32, device=dev) for _ in range(2)]
+
             self.peer = [[None, None] for _ in range(world)]
-            if multi and world > 1:
-                mine = [reduce_tensor(c) for c in self.C]
-                everyone = [None] * world
-                dist.all_gather_object(everyone, mine)
-                for r in range(world):
-                    if r != rank:
-                        self.peer[r] = [fn(*a) for fn, a in everyone[r]]
-                        check_peer(self.peer[r][0])
+            ipc_exchange(self, local, reduce_tensor)
             self.copy_streams = [env.Stream() for _ in range(world)]
             self.sync_stream = env.Stream()
             self.flags = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2)]

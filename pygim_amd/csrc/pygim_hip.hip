@@ -2893,7 +2893,10 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]) {
     const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
     out[0] = p.lds_code ? (int64_t)p.lds_code_bytes : 0;
     out[1] = p.lds_code ? (int64_t)p.lds_code_pairs : 0;
-    out[2] = (p.lds_is_code && g_tune.lds_code) ? 1 : 0;
+    bool all_code = p.lds_is_code && g_tune.lds_code;
+    if (!(g->merged && g_tune.merge_parts && g->parts.size() > 1))
+        for (const Part &q : g->parts) all_code = all_code && q.lds_is_code;   // (1 only when EVERY part that serves products is a code stream)
+    out[2] = all_code ? 1 : 0;
     out[3] = (p.lds_code && p.lds_codegen_device) ? 1 : 0;   // generated on the device (round 5), not by the host encoder
     return 0;
 }
@@ -2930,9 +2933,18 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     if (!out || cap <= 0) return fail(PYGIM_ERR_INVALID, "no buffer");
-    const Part &p = (g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0];
-    const size_t n = std::min<size_t>(p.lds_note.size(), (size_t)cap - 1);
-    std::memcpy(out, p.lds_note.data(), n);
+    // the parts that serve the group's products: the merged matrix, or -- several parts run one by one -- every part: a later part that
+    // took a lower rung of the ladder than part 0 is named too (nothing falls back silently)
+    std::string text;
+    if ((g->merged && g_tune.merge_parts && g->parts.size() > 1) || g->parts.size() == 1) {
+        text = ((g->merged && g_tune.merge_parts && g->parts.size() > 1) ? *g->merged : g->parts[0]).lds_note;
+    } else {
+        text = g->parts[0].lds_note;
+        for (size_t i = 1; i < g->parts.size(); i++)
+            if (g->parts[i].lds_note != g->parts[0].lds_note) text += "; part " + std::to_string(i) + ": " + g->parts[i].lds_note;
+    }
+    const size_t n = std::min<size_t>(text.size(), (size_t)cap - 1);
+    std::memcpy(out, text.data(), n);
     out[n] = 0;
     return 0;
 }
