@@ -60,3 +60,14 @@ def coalesce(rowptr, col, np_dtype):
 @pytest.fixture
 def rng():
     return np.random.default_rng(1234)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _codegen_soak():
+    """PYGIM_CODEGEN_VERIFY=1 (a one-off soak on the GPU box): every code stream the suite creates is generated on the device AND compared
+    word for word with the host encoder inside the library (lds_codegen = 2); a difference fails the group's creation."""
+    if os.environ.get("PYGIM_CODEGEN_VERIFY", "0") == "1":
+        from pygim_amd import _lib
+
+        _lib.set_tunable("lds_codegen", 2)
+    yield
