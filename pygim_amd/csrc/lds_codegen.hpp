@@ -45,6 +45,8 @@ struct CgParams {
     // geometry
     uint32_t NW = 8, KA = 228, KC = 128, NBUF = 5, RB = 256, RPB = 256, G = 10, NS = 2, XW = 1;
     uint32_t wide = 0, valued = 0;
+    uint32_t mulw = 0;                              // valued: dwords of an entry's multiply -- 2 (v_mul_f32 literal; v_mul_lo_u32 inline value), 4 (s_mov_b32 + v_mul_lo_u32)
+    uint32_t int_inline = 0;                        // valued INT32: every value lies in [-16, 64] (lds_int_values_inline)
     uint32_t opcode_add = 0x02000000u, addw = 1;   // dwords per accumulate
     uint32_t pieces = 4, chunk_bytes = 32768;
     uint32_t nrows = 0, ncols = 0, nchunks = 0, ntiles = 0, nstreams = 0;
@@ -58,7 +60,8 @@ struct CgParams {
 
 constexpr uint32_t CG_TOUCH_EVERY_DW = 256;   // (lds_code_from_plan: TOUCH_EVERY_DW)
 
-inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valued, uint32_t nrows, uint32_t ncols, uint32_t gsize = 0, uint32_t nsets = 0) {
+inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valued, uint32_t nrows, uint32_t ncols, uint32_t gsize = 0, uint32_t nsets = 0,
+                          bool int_inline = false) {
     if (geo.NBUF >= 3 && !geo.boundary) throw std::runtime_error("lds codegen: the mid-slot hand-off takes the host encoder");
     CgParams P;
     const bool wide = geo.row_bytes == 512;
@@ -71,6 +74,9 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
         throw std::runtime_error("lds codegen: the geometry does not fit the register map");
     if (P.KA > 255) throw std::runtime_error("lds codegen: more than 255 accumulators per wave");
     P.opcode_add = opcode_add;
+    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u) throw std::runtime_error("lds codegen: valued entries of this element type");
+    P.int_inline = (valued && opcode_add == 0x68000000u && int_inline) ? 1 : 0;
+    P.mulw = !valued ? 0 : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
     if (P.pieces * geo.NW * 1024 != geo.KC * geo.row_bytes) throw std::runtime_error("lds codegen: a chunk is not a whole number of pieces per wave");
@@ -426,7 +432,7 @@ PYGIM_HD inline void cg_stream_pass(const CgParams &P, const CgTables &T, uint32
         wait_lgkm(younger);
         const uint32_t g = pend_g[0];
         if (write) T.g_apos[g] = (uint32_t)(base_dw + e.n);
-        e.skip(T.g_nent[g] * ((P.valued ? 2u : 0u) + P.addw));
+        e.skip(T.g_nent[g] * (P.mulw + P.addw));
         for (uint32_t q = 1; q < npend; q++) {
             pend_g[q - 1] = pend_g[q];
             pend_nlds[q - 1] = pend_nlds[q];
@@ -506,9 +512,21 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
     const uint32_t vx = P.x0 + P.G * P.XW * T.g_xset[g] + u * P.XW, vk = P.acc0 + k * P.XW;
     uint32_t *w = T.code + T.g_apos[g];
     if (P.valued) {
-        w[2 * q] = 0x0A0000FFu | (vx << 17) | (vx << 9);
-        w[2 * q + 1] = T.vals[i];
-        w += 2 * T.g_nent[g];
+        if (P.opcode_add == 0x68000000u) {   // INT32: the value inline, or through an SGPR
+            if (P.int_inline) {
+                w[2 * q] = 0xD2850000u | vx;
+                w[2 * q + 1] = lds_inline_int((int32_t)T.vals[i]) | ((256 + vx) << 9);
+            } else {
+                w[4 * q] = 0xBE8000FFu | (LDS_CODE_S_VAL << 16);
+                w[4 * q + 1] = T.vals[i];
+                w[4 * q + 2] = 0xD2850000u | vx;
+                w[4 * q + 3] = LDS_CODE_S_VAL | ((256 + vx) << 9);
+            }
+        } else {
+            w[2 * q] = 0x0A0000FFu | (vx << 17) | (vx << 9);
+            w[2 * q + 1] = T.vals[i];
+        }
+        w += P.mulw * T.g_nent[g];
     }
     w += q * P.addw;
     if (P.opcode_add == LDS_CODE_PK_ADD_U16) {
@@ -538,8 +556,9 @@ struct CgHostResult {
 };
 inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const uint32_t *vals, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
                            uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr) {
-    const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets);
     const uint64_t nnz = rowptr[nrows];
+    const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets,
+                                 vals != nullptr && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz));
     cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;

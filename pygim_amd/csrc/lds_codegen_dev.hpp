@@ -227,6 +227,14 @@ __global__ __launch_bounds__(256) void k_cg_reads(CgParams P, CgTables T) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < T.ngroups) cg_emit_reads(P, T, (uint32_t)g);
 }
+// valued INT32: does every value lie in the inline-constant range [-16, 64]?  flag[0] is set when one does not (lds_int_values_inline)
+__global__ __launch_bounds__(256) void k_cg_int_outside(const uint32_t *vals, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int32_t v = (int32_t)vals[i];
+        if (v < -16 || v > 64) flag[0] = 1u;
+    }
+}
 __global__ __launch_bounds__(256) void k_cg_fill_words(uint32_t *p, uint64_t n, uint32_t word) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = word;
@@ -258,14 +266,25 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
                                     const LdsGeometry &geo, uint32_t opcode_add, uint32_t gsize, uint32_t nsets, hipStream_t st,
                                     const std::function<void *(size_t)> &alloc_exec, const std::function<void(void *)> &free_exec, CgDeviceResult &out,
                                     const std::function<double()> &now_ms) {
+    const uint64_t nnz = h_rowptr[nrows];
+    if (nnz == 0 || nnz >= (1ull << 31)) return "lds codegen: no entries, or 2^31 and more";
+    bool int_inline = false;
+    if (d_vals && opcode_add == 0x68000000u) {   // valued INT32: inline constants when every value allows it (one pass over the values)
+        uint32_t *d_flag = nullptr, h_flag = 1;
+        if (hipMalloc((void **)&d_flag, 64) != hipSuccess) { (void)hipGetLastError(); return "lds codegen: out of device memory"; }
+        (void)hipMemsetAsync(d_flag, 0, 64, st);
+        hipLaunchKernelGGL(k_cg_int_outside, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, d_vals, nnz, d_flag);
+        const bool got = hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        (void)hipFree(d_flag);
+        if (!got) { (void)hipGetLastError(); return "lds codegen: value range check failed"; }
+        int_inline = h_flag == 0;
+    }
     CgParams P;
     try {
-        P = cg_params(geo, opcode_add, d_vals != nullptr, nrows, ncols, gsize, nsets);
+        P = cg_params(geo, opcode_add, d_vals != nullptr, nrows, ncols, gsize, nsets, int_inline);
     } catch (const std::exception &e) {
         return e.what();
     }
-    const uint64_t nnz = h_rowptr[nrows];
-    if (nnz == 0 || nnz >= (1ull << 31)) return "lds codegen: no entries, or 2^31 and more";
     std::vector<void *> tmp;           // device temporaries, freed on every way out
     bool failed = false;
     auto dalloc = [&](size_t bytes) -> void * {

@@ -28,6 +28,11 @@
 // Pure C++ (no HIP): built here for the device, and by the CPU tests against an emulator.
 #pragma once
 #include <stdint.h>
+#if defined(__HIPCC__)
+#define PYGIM_LDS_HD_INLINE __host__ __device__ inline
+#else
+#define PYGIM_LDS_HD_INLINE inline
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -432,6 +437,18 @@ constexpr uint32_t LDS_CODE_PK_ADD_U16 = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CODE_ADD_F64 = 0xFFFFFFFEu, LDS_CODE_ADD_U64 = 0xFFFFFFFDu;
 // experiment (timing only, WRONG results): bit 0 = no workgroup barriers, bit 1 = no chunk DMA (what the hand-offs / the fill cost:
 // 2.09 -> 1.81 / 1.63 / both 1.49 ms on the bench workload, profiles/r04_lds_kernel.md)
+// Valued matrices: FLT32 -- the value is the literal of a v_mul_f32 (VOP2).  INT32 (round 5): gfx9's VOP3 takes no literal, so v_mul_lo_u32 gets the value
+// as an INLINE CONSTANT when every value of the matrix lies in [-16, 64] (lds_int_values_inline: 8 bytes of code per multiply), else through an
+// SGPR (s_mov_b32 s94, <literal>; v_mul_lo_u32 x, s94, x: 16 bytes).  Products wrap modulo 2^32 like the CPU loop's.
+constexpr uint32_t LDS_CODE_S_VAL = 94;   // the SGPR a general integer value travels in (free between the kernel's set-up and its store stage)
+inline bool lds_int_values_inline(const uint32_t *vals, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
+        const int32_t v = (int32_t)vals[i];
+        if (v < -16 || v > 64) return false;
+    }
+    return true;
+}
+PYGIM_LDS_HD_INLINE uint32_t lds_inline_int(int32_t v) { return v >= 0 ? 128u + (uint32_t)v : 192u + (uint32_t)(-v); }   // VOP3 source field of an inline integer
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
                                uint32_t nsets = 0, uint32_t experiment = 0) {
     const LdsGeometry &geo = plan.geo;
@@ -476,6 +493,8 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
         std::vector<uint32_t> k, xr, v;    // per entry: accumulator, x register, value (valued matrices)
     };
     const LdsCodeRegs Rr = R;
+    // (padding tokens carry the value 0: inside the inline range)
+    const bool int_inline = opcode_add == 0x68000000u && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
     auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs, uint64_t &n_shared) {
         const LdsTile &t = plan.tiles[ti];
         auto s_add_lit = [&](uint32_t sdst, uint32_t ssrc, uint32_t lit) { e.op(0x80000000u | (sdst << 16) | (0xFFu << 8) | ssrc, lit); };
@@ -534,7 +553,15 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             wait_lgkm(younger);
             if (younger <= lds_this_slot) older_reads = false;      // (LDS reads return in order)
             const Grp &g = ring[pend.front()];
-            if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the products first (every entry has
+            if (valued && opcode_add == 0x68000000u) {   // INT32: x = val * x (wrapping), the value inline or through an SGPR
+                for (size_t q = 0; q < g.k.size(); q++) {
+                    if (int_inline) e.op(0xD2850000u | g.xr[q], lds_inline_int((int32_t)g.v[q]) | ((256 + g.xr[q]) << 9));
+                    else {
+                        e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), g.v[q]);                            // s_mov_b32 s94, <literal value>
+                        e.op(0xD2850000u | g.xr[q], LDS_CODE_S_VAL | ((256 + g.xr[q]) << 9));          // v_mul_lo_u32 x, s94, x
+                    }
+                }
+            } else if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the products first (every entry has
                           // its own x register here: the multiply overwrites it)
                 for (size_t q = 0; q < g.k.size(); q++) e.op(0x0A0000FFu | (g.xr[q] << 17) | (g.xr[q] << 9), g.v[q]);   // v_mul_f32 x, <literal value>, x
             for (size_t q = 0; q < g.k.size(); q++) {

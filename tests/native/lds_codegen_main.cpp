@@ -67,11 +67,12 @@ int main(int argc, char **argv) {
         const bool wide = q[6] == 512;
         const uint32_t ops4[] = {0x02000000u, 0x68000000u, LDS_CODE_PK_ADD_U16};
         const uint32_t op = wide ? ((rng() & 1) ? LDS_CODE_ADD_F64 : LDS_CODE_ADD_U64) : ops4[rng() % 3];
-        const bool valued = !wide && op == 0x02000000u && geo.col_splits == 1 && rng() % 3 == 0;
+        const bool valued = !wide && (op == 0x02000000u || op == 0x68000000u) && geo.col_splits == 1 && rng() % 3 == 0;   // FLT32, INT32 (round 5)
         std::vector<uint32_t> vals;
         if (valued) {
             vals.resize(m.col.size());
-            for (auto &v : vals) v = (uint32_t)rng();
+            const bool small = rng() & 1;   // (INT32: values that ride as inline constants, or any)
+            for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : (uint32_t)rng();
         }
         // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)
         std::vector<uint32_t> rorder;

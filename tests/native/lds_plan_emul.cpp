@@ -208,6 +208,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 const uint32_t pieces = (KC * RB / 1024) / NW;
                 bool done = false;
                 int64_t lo_half = -1;                         // INT64: the v_add_co_u32 of a pair has been seen for this accumulator
+                uint32_t sval = 0;                            // valued INT32: the SGPR a general value travels in
+                bool sval_set = false;
                 for (uint64_t guard = 0; !done; guard++) {
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
                     // vmcnt is a 6-bit counter: a wave has at most 63 vector loads in flight (the next one is not issued before the oldest
@@ -379,6 +381,33 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc += 2;
                         continue;
                     }
+                    if (vals && std::is_same<T, int32_t>::value && i0 == (0xBE8000FFu | (LDS_CODE_S_VAL << 16))) {   // s_mov_b32 s94, <literal value>
+                        sval = ch.code[pc + 1];
+                        sval_set = true;
+                        pc += 2;
+                        continue;
+                    }
+                    if (vals && std::is_same<T, int32_t>::value && (i0 & 0xFFFFFF00u) == 0xD2850000u) {   // v_mul_lo_u32 x, <inline | s94>, x
+                        const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF, src0 = d1 & 0x1FF, vs1 = (d1 >> 9) & 0x1FF;
+                        if (vs1 != 256 + vd || (d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
+                        uint32_t value;
+                        if (src0 == LDS_CODE_S_VAL) {
+                            if (!sval_set) return 45;                                           // the SGPR was not loaded for this multiply
+                            value = sval;
+                            sval_set = false;
+                        } else if (src0 >= 128 && src0 <= 192) value = src0 - 128;              // inline 0 .. 64
+                        else if (src0 >= 193 && src0 <= 208) value = (uint32_t)(-(int32_t)(src0 - 192));   // inline -1 .. -16
+                        else return 46;
+                        XReg &xr = x[vd - R.x0];
+                        bool infl = false;
+                        for (uint32_t r : fifo) if (r == vd - R.x0 || (r + 1 == vd - R.x0 && x[r + 1].inflight && x[r].inflight)) infl = true;
+                        if (!xr.valid || infl || xr.has_mul) return 34;
+                        xr.inflight = false;
+                        xr.has_mul = true;
+                        xr.mulbits = value;
+                        pc += 2;
+                        continue;
+                    }
                     if (vals && (i0 & 0xFE0001FFu) == 0x0A0000FFu) {                            // v_mul_f32 x, <literal>, x (valued matrices)
                         const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF;
                         if (vd != vs1 || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
@@ -409,7 +438,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         for (uint32_t l = 0; l < wvalid; l++) {
                             T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
                             T &a = acc[(size_t)k * 64 + l];
-                            if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (uint32_t)xv);
+                            if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (xr.has_mul ? xr.mulbits * (uint32_t)xv : (uint32_t)xv));
                             else {
                                 if (xr.has_mul) {
                                     float mv;
@@ -479,6 +508,12 @@ int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,
                      uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
     return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile, boundary);
+}
+// valued INT32 (round 5): the value inline in a v_mul_lo_u32 (all values in [-16, 64]) or through an SGPR
+int lds_code_i32_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
+                         uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const int32_t *vals, uint32_t nw, uint32_t gsize,
+                         uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, 1, nw, gsize, nsets, rows_per_tile, boundary);
 }
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits) {

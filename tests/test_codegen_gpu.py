@@ -84,6 +84,19 @@ def test_valued_float_entries(rng, checked):
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()   # products and sums rounded separately, stored order
 
 
+@pytest.mark.parametrize("small", [True, False])
+def test_valued_int32_entries(rng, checked, small):
+    """valued INT32 on the code stream (round 5; the reference's grande loop multiplies by the stored value for every type,
+    spmm_grande/spmm_mul_csr.c:131): v_mul_lo_u32 takes no literal on gfx9, so the value rides as an INLINE CONSTANT when every value of
+    the matrix lies in [-16, 64], else through an SGPR (s_mov_b32 + v_mul_lo_u32); products and sums wrap modulo 2^32 like the CPU loop's"""
+    rowptr, col = random_csr(rng, 2500, 1800, 18, long_rows=[(7, 2600)])
+    x = feats(rng, 1800, 96, np.int32)
+    vals = rng.integers(-16, 65, size=len(col)).astype(np.int32) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64).astype(np.int32)
+    got, info, note = run(rowptr, col, x, vals=vals)
+    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
+
+
 @pytest.mark.parametrize("geo", [(8, 5, 0, 0, 0, 0), (16, 2, 0, 0, 0, 0), (16, 3, 0, 8, 2, 1), (8, 2, 0, 10, 2, 0), (8, 3, 0, 6, 3, 1), (8, 4, 160, 12, 2, 1), (8, 8, 64, 2, 2, 1), (8, 5, 32, 4, 3, 1)])
 def test_device_stream_equals_host_stream_every_geometry(rng, checked, geo):
     for k, v in zip(GEO_KNOBS, geo):

@@ -341,3 +341,22 @@ def test_data_parallel_encoder_equals_host_encoder():
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread", src, "-o", exe])
     out = subprocess.run([exe, os.environ.get("PYGIM_CG_CASES", "80")], capture_output=True, text=True, timeout=3000)
     assert out.returncode == 0 and "byte for byte" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_valued_int32_code_stream_in_the_interpreter(emul):
+    """valued INT32 (round 5): the host encoder's v_mul_lo_u32 forms -- inline constants for values in [-16, 64], s_mov_b32 + SGPR operand
+    otherwise -- run by the CPU interpreter of the instruction stream; products wrap like the oracle's"""
+    rng = np.random.default_rng(77)
+    nrows, ncols, h = 1500, 1100, 70
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=15, long_rows=[(5, 2000)])
+    x = rng.integers(-2**31, 2**31 - 1, size=(ncols, h), dtype=np.int64).astype(np.int32)
+    rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
+    for small in (True, False):
+        vals = (rng.integers(-16, 65, size=len(col)) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64)).astype(np.int32)
+        out = np.full((nrows, h), 77, dtype=np.int32)
+        stats = (ctypes.c_uint64 * 4)()
+        for nw, kc, nbuf, gs, ns in ((8, 128, 5, 10, 2), (16, 320, 2, 8, 2)):
+            rc = emul.lds_code_i32_val_geo(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, x.ctypes.data_as(ctypes.c_void_p), h,
+                                           out.ctypes.data_as(ctypes.c_void_p), 3, stats, kc, nbuf, vals.ctypes.data_as(ctypes.c_void_p), nw, gs, ns, 0, 1)
+            assert rc == 0, rc
+            assert out.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (small, nw)
