@@ -652,6 +652,38 @@ def main():
                            "note": "same N / nnz / degrees, columns within ~1 % of the row id (synth.make_csr clustered=True); 10 steps, median, outside the timed region; group_create_ms = the one-time plan build (the reference's to_device / prepare step) for it"}
         _lib.group_free(hd_c)
         del rp_c, col_c, out_c
+        # a graph WITH structure and arbitrary node ids beside the two above (round 5, profiles/r05_structured.txt): a stochastic block model of the
+        # same shape (50 communities, 80 % of a row's entries inside its own), ids shuffled -- the library finds the communities by label
+        # propagation and builds its tiles from them (lds_tile_order, automatic)
+        try:
+            rp_s, col_s = synth.make_shape(args.shape, seed=0, device=dev, kind="sbm")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hd_s = _lib.group_create(_lib.CSR, _lib.FLT32, [rp_s.data_ptr()], [col_s.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+            torch.cuda.synchronize()
+            t_create_s = time.perf_counter() - t0
+            out_s = torch.empty((n, h), dtype=torch.float32, device=dev)
+            for _ in range(2):
+                _lib.spmm_run_group(hd_s, [x.data_ptr()], out_s.data_ptr(), stream)
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            for i in range(10):
+                evs[i].record(main_stream)
+                _lib.spmm_run_group(hd_s, [x.data_ptr()], out_s.data_ptr(), stream)
+            evs[10].record(main_stream)
+            torch.cuda.synchronize()
+            ts_s = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(10))
+            cs = torch.bincount(col_s.long(), minlength=n).double()
+            geo_s = _lib.group_lds_geometry(hd_s)
+            result["extra"]["sbm_shuffled_ids"] = {
+                "ms_per_step": round(ts_s[len(ts_s) // 2], 4), "tiles": _lib.group_lds_tiles(hd_s), "lds_plan": _lib.group_lds_plan(hd_s),
+                "entries_sharing_a_read_frac": round(geo_s["shared_entries"] / max(nnz, 1), 3), "group_create_ms": round(t_create_s * 1e3, 1),
+                "check": "column-count checksum exact" if torch.equal(out_s.double().sum(0), cs @ x.double()) else "MISMATCH",
+                "note": "stochastic block model of the same N / nnz / degrees with shuffled node ids (pygim_amd/synth.py make_sbm); 10 steps, median, outside the timed region"}
+            _lib.group_free(hd_s)
+            del rp_s, col_s, out_s
+        except Exception as e:  # noqa: BLE001  (an extra: never the reason the line is missing)
+            result["extra"]["sbm_shuffled_ids"] = {"error": str(e)[:160]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, cpu_out = cpu_baseline(rowptr, col, x, args)
         result["cpu_baseline"] = base

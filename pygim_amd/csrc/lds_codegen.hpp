@@ -74,9 +74,10 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
         throw std::runtime_error("lds codegen: the geometry does not fit the register map");
     if (P.KA > 255) throw std::runtime_error("lds codegen: more than 255 accumulators per wave");
     P.opcode_add = opcode_add;
-    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u) throw std::runtime_error("lds codegen: valued entries of this element type");
+    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64)
+        throw std::runtime_error("lds codegen: valued entries of this element type");
     P.int_inline = (valued && opcode_add == 0x68000000u && int_inline) ? 1 : 0;
-    P.mulw = !valued ? 0 : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
+    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
     if (P.pieces * geo.NW * 1024 != geo.KC * geo.row_bytes) throw std::runtime_error("lds codegen: a chunk is not a whole number of pieces per wave");
@@ -198,6 +199,7 @@ inline void cg_chunk_lists(const uint8_t *flags, const CgParams &P, CgChunks &ou
 struct CgTables {
     // inputs
     const uint32_t *rowptr = nullptr, *colind = nullptr, *vals_in = nullptr;   // CSR (vals: raw bits of 4-byte values, valued only)
+    const uint64_t *vals_in64 = nullptr;                                        // valued DBL64: the values; the sorted 4-byte payload is then the ENTRY INDEX
     const uint32_t *rowinfo = nullptr;                                          // per row
     const uint32_t *tile_pos = nullptr;                                         // [row_tiles * S] -> launch position of the tile
     uint32_t *tnnz = nullptr;                                                   // [row_tiles * S] stored entries (counted when S > 1)
@@ -282,7 +284,7 @@ PYGIM_HD inline void cg_mark_entry(const CgParams &P, const CgTables &T, uint32_
 PYGIM_HD inline void cg_key_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
     const uint32_t ri = T.rowinfo[row], c = T.colind[e];
     T.keys[e] = ((uint64_t)cg_stream_of(P, T, ri, c) << (P.col_bits + 8)) | ((uint64_t)c << 8) | (ri & 255u);
-    if (P.valued) T.vals[e] = T.vals_in[e];
+    if (P.valued) T.vals[e] = P.wide ? e : T.vals_in[e];   // (8-byte values: the entry's index rides with the key)
 }
 // D3: per sorted entry
 PYGIM_HD inline void cg_colflag(const CgParams &P, const CgTables &T, uint64_t i) {
@@ -512,7 +514,15 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
     const uint32_t vx = P.x0 + P.G * P.XW * T.g_xset[g] + u * P.XW, vk = P.acc0 + k * P.XW;
     uint32_t *w = T.code + T.g_apos[g];
     if (P.valued) {
-        if (P.opcode_add == 0x68000000u) {   // INT32: the value inline, or through an SGPR
+        if (P.opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
+            const uint64_t v = T.vals_in64[T.vals[i]];
+            w[6 * q] = 0xBE8000FFu | (LDS_CODE_S_VAL << 16);
+            w[6 * q + 1] = (uint32_t)v;
+            w[6 * q + 2] = 0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16);
+            w[6 * q + 3] = (uint32_t)(v >> 32);
+            w[6 * q + 4] = 0xD2810000u | vx;
+            w[6 * q + 5] = LDS_CODE_S_VAL | ((256 + vx) << 9);
+        } else if (P.opcode_add == 0x68000000u) {   // INT32: the value inline, or through an SGPR
             if (P.int_inline) {
                 w[2 * q] = 0xD2850000u | vx;
                 w[2 * q + 1] = lds_inline_int((int32_t)T.vals[i]) | ((256 + vx) << 9);
@@ -554,14 +564,21 @@ struct CgHostResult {
     CgChunks chunks;
     uint64_t entries = 0, pairs = 0, shared = 0;
 };
+// vals: 4-byte values (FLT32 / INT32 raw bits); vals64: DBL64 values (then vals is ignored: the payload is the entry index)
 inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const uint32_t *vals, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
-                           uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr) {
+                           uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr,
+                           const uint64_t *vals64 = nullptr) {
+    std::vector<uint32_t> idx_payload;
+    if (vals64) {   // (any non-null 4-byte array switches the valued form on)
+        idx_payload.assign(1, 0);
+        vals = idx_payload.data();
+    }
     const uint64_t nnz = rowptr[nrows];
     const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets,
-                                 vals != nullptr && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz));
+                                 vals != nullptr && !vals64 && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz));
     cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
-    T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;
+    T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.vals_in64 = vals64; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;
     if (P.S > 1)   // (the device counts these with one atomic per (row, range))
         for (uint32_t r = 0; r < nrows; r++)
             for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; e++) out.rows.tnnz[cg_tile_of_entry(P, T, r, e)]++;

@@ -261,7 +261,8 @@ struct CgDeviceResult {
 // alloc_exec(bytes) returns executable device memory or nullptr; free_exec(ptr) releases it.  Returns "" on success, else why not
 // (nothing is left allocated then).  h_rowptr: the row pointers on the host (the caller has them); h_rorder: the tile order of the rows
 // (similarity tiles, lds_reorder_dev.hpp) or nullptr for consecutive rows.
-inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_col, const uint32_t *d_vals, const uint32_t *h_rowptr, const uint32_t *h_rorder,
+inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_col, const uint32_t *d_vals, const uint64_t *d_vals64, const uint32_t *h_rowptr,
+                                    const uint32_t *h_rorder,
                                     uint32_t nrows, uint32_t ncols,
                                     const LdsGeometry &geo, uint32_t opcode_add, uint32_t gsize, uint32_t nsets, hipStream_t st,
                                     const std::function<void *(size_t)> &alloc_exec, const std::function<void(void *)> &free_exec, CgDeviceResult &out,
@@ -281,7 +282,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     }
     CgParams P;
     try {
-        P = cg_params(geo, opcode_add, d_vals != nullptr, nrows, ncols, gsize, nsets, int_inline);
+        P = cg_params(geo, opcode_add, d_vals != nullptr || d_vals64 != nullptr, nrows, ncols, gsize, nsets, int_inline);
     } catch (const std::exception &e) {
         return e.what();
     }
@@ -327,7 +328,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
         return bail(e.what());
     }
     CgTables T;
-    T.rowptr = d_rowptr; T.colind = d_col; T.vals_in = d_vals; T.nnz = nnz;
+    T.rowptr = d_rowptr; T.colind = d_col; T.vals_in = d_vals; T.vals_in64 = d_vals64; T.nnz = nnz;
     uint32_t *d_rowinfo = (uint32_t *)dalloc((size_t)nrows * 4);
     uint8_t *d_flags = (uint8_t *)dalloc((size_t)P.ntiles * P.nchunks + 1);
     uint32_t *d_tile_pos = (uint32_t *)dalloc((size_t)P.ntiles * 4), *d_tnnz = (uint32_t *)dalloc((size_t)P.ntiles * 4);

@@ -449,14 +449,18 @@ inline bool lds_int_values_inline(const uint32_t *vals, uint64_t n) {
     return true;
 }
 PYGIM_LDS_HD_INLINE uint32_t lds_inline_int(int32_t v) { return v >= 0 ? 128u + (uint32_t)v : 192u + (uint32_t)(-v); }   // VOP3 source field of an inline integer
+// DBL64 (round 5): the plan's 4-byte value slot carries the ENTRY INDEX and vals64 the values; per entry s_mov_b32 s94, <low half>; s_mov_b32 s95,
+// <high half>; v_mul_f64 x, s[94:95], x (24 bytes), product and sum rounded separately.  (INT64: a 64-bit multiply is six VOP3 instructions -- the sweep.)
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
-                               uint32_t nsets = 0, uint32_t experiment = 0) {
+                               uint32_t nsets = 0, uint32_t experiment = 0, const uint64_t *vals64 = nullptr) {
     const LdsGeometry &geo = plan.geo;
     const uint32_t NW = geo.NW, KA = geo.KA, B = geo.BATCH, KC = geo.KC;
     const uint32_t RB = geo.row_bytes;
     const bool wide = RB == 512;
     if (RB != 256 && RB != 512) throw std::runtime_error("lds code: rows of 256 or 512 bytes");
     if (wide != (opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64)) throw std::runtime_error("lds code: 512-byte rows are the 8-byte element types'");
+    if (!plan.wts.empty() && ((opcode_add == LDS_CODE_ADD_F64 && !vals64) || opcode_add == LDS_CODE_ADD_U64 || opcode_add == LDS_CODE_PK_ADD_U16))
+        throw std::runtime_error("lds code: valued entries of this element type");
     const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets, wide);
     out.regs = R;
     const uint32_t G = R.gsize, NS = R.nsets;
@@ -553,7 +557,14 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             wait_lgkm(younger);
             if (younger <= lds_this_slot) older_reads = false;      // (LDS reads return in order)
             const Grp &g = ring[pend.front()];
-            if (valued && opcode_add == 0x68000000u) {   // INT32: x = val * x (wrapping), the value inline or through an SGPR
+            if (valued && opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
+                for (size_t q = 0; q < g.k.size(); q++) {
+                    const uint64_t v = vals64[g.v[q]];
+                    e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);
+                    e.op(0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16), (uint32_t)(v >> 32));
+                    e.op(0xD2810000u | g.xr[q], LDS_CODE_S_VAL | ((256 + g.xr[q]) << 9));              // v_mul_f64 x[0:1], s[94:95], x[0:1]
+                }
+            } else if (valued && opcode_add == 0x68000000u) {   // INT32: x = val * x (wrapping), the value inline or through an SGPR
                 for (size_t q = 0; q < g.k.size(); q++) {
                     if (int_inline) e.op(0xD2850000u | g.xr[q], lds_inline_int((int32_t)g.v[q]) | ((256 + g.xr[q]) << 9));
                     else {

@@ -74,6 +74,15 @@ int main(int argc, char **argv) {
             const bool small = rng() & 1;   // (INT32: values that ride as inline constants, or any)
             for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : (uint32_t)rng();
         }
+        // valued DBL64 (round 5): the plan's value slot carries the entry index, the values travel beside it
+        const bool valued64 = wide && op == LDS_CODE_ADD_F64 && geo.col_splits == 1 && rng() % 2 == 0;
+        std::vector<uint64_t> vals64;
+        std::vector<uint32_t> eidx;
+        if (valued64) {
+            vals64.resize(m.col.size());
+            eidx.resize(m.col.size());
+            for (size_t i = 0; i < vals64.size(); i++) { vals64[i] = rng(); eidx[i] = (uint32_t)i; }
+        }
         // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)
         std::vector<uint32_t> rorder;
         if (rng() % 3 == 0) {
@@ -84,12 +93,12 @@ int main(int argc, char **argv) {
         const uint32_t *ro = rorder.empty() ? nullptr : rorder.data();
         // the host encoder
         LdsPlanHost plan;
-        lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : nullptr, ro);
+        lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : (valued64 ? eidx.data() : nullptr), ro);
         LdsCodeHost ch;
-        lds_code_from_plan(plan, op, ch, 2, q[4], q[5]);
+        lds_code_from_plan(plan, op, ch, 2, q[4], q[5], 0, valued64 ? vals64.data() : nullptr);
         // the data-parallel form
         CgHostResult r;
-        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5], ro);
+        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5], ro, valued64 ? vals64.data() : nullptr);
         auto bad = [&](const char *what) {
             printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, splits %u, op %08x, valued %d, dups %d, clustered %d)\n", c, what, q[0], q[1], q[2], q[3],
                    q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, geo.col_splits, op, (int)valued, (int)dups, (int)clustered);

@@ -160,14 +160,19 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     geo.KC = kc;       // the code-stream ring (pygim_hip.hip build_lds_plan): 2 x 320 columns, or 3 x 192 (two chunks in flight)
     geo.NBUF = nbuf;
     LdsPlanHost plan;
-    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, reinterpret_cast<const uint32_t *>(vals));
+    std::vector<uint32_t> eidx;   // 8-byte values (valued DBL64): the plan's 4-byte value slot carries the entry index
+    if (WIDE && vals) {
+        eidx.resize(rowptr[nrows]);
+        for (uint32_t i = 0; i < eidx.size(); i++) eidx[i] = i;
+    }
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, WIDE ? (vals ? eidx.data() : nullptr) : reinterpret_cast<const uint32_t *>(vals));
     if (plan.header_overflow) return 13;
     nrows = S * nrows_real;   // rows of the (partial-sum) result the plan writes
     const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : std::is_same<T, double>::value ? LDS_CODE_ADD_F64 :
                             std::is_same<T, int64_t>::value ? LDS_CODE_ADD_U64 : 0x68000000u;
     LdsCodeHost ch;
-    lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets);
+    lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets, 0, (WIDE && vals) ? reinterpret_cast<const uint64_t *>(vals) : nullptr);
     const LdsCodeRegs R = ch.regs;
     if (R.nx() > 32 || NBUF > 16) return 14;
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, RB = geo.row_bytes, chunk_bytes = KC * RB, RPB = 65536 / RB;
@@ -198,7 +203,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 uint64_t barriers = 0;
                 struct VLoad { int buf; int64_t cid; bool last; };
                 std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)
-                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; int64_t chunk = -1; };
+                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; uint64_t mulbits64 = 0; int64_t chunk = -1; };
                 XReg x[32];
                 std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
                 uint64_t pc = ch.start[(size_t)ti * NW + w] / 4;
@@ -210,6 +215,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 int64_t lo_half = -1;                         // INT64: the v_add_co_u32 of a pair has been seen for this accumulator
                 uint32_t sval = 0;                            // valued INT32: the SGPR a general value travels in
                 bool sval_set = false;
+                uint32_t sval_hi = 0;                         // valued DBL64: s95, the high half (s94 = sval the low one)
+                bool sval_hi_set = false;
                 for (uint64_t guard = 0; !done; guard++) {
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
                     // vmcnt is a 6-bit counter: a wave has at most 63 vector loads in flight (the next one is not issued before the oldest
@@ -309,6 +316,23 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc += 2;
                         continue;
                     }
+                    if (WIDE && vals && i0 == (0xBE8000FFu | (LDS_CODE_S_VAL << 16))) { sval = ch.code[pc + 1]; sval_set = true; pc += 2; continue; }           // s_mov_b32 s94, <low half>
+                    if (WIDE && vals && i0 == (0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16))) { sval_hi = ch.code[pc + 1]; sval_hi_set = true; pc += 2; continue; }   // s_mov_b32 s95, <high half>
+                    if (WIDE && vals && opcode == LDS_CODE_ADD_F64 && (i0 & 0xFFFFFF00u) == 0xD2810000u) {                                    // v_mul_f64 x[0:1], s[94:95], x[0:1]
+                        const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF;
+                        if ((d1 & 0x1FF) != LDS_CODE_S_VAL || ((d1 >> 9) & 0x1FF) != 256 + vd || (d1 >> 18) || !sval_set || !sval_hi_set) return 45;
+                        if (vd < R.x0 || vd + 1 >= R.x0 + R.nx() || ((vd - R.x0) & 1)) return 33;
+                        XReg &xr = x[vd - R.x0];
+                        bool infl = false;
+                        for (uint32_t r : fifo) if (r == vd - R.x0) infl = true;
+                        if (!xr.valid || infl || xr.has_mul) return 34;
+                        xr.inflight = false;
+                        xr.has_mul = true;
+                        xr.mulbits64 = ((uint64_t)sval_hi << 32) | sval;
+                        sval_set = sval_hi_set = false;
+                        pc += 2;
+                        continue;
+                    }
                     if (WIDE) {
                         // v_add_f64 acc[0:1], x[0:1], acc[0:1]   |   v_add_co_u32 acc0, vcc, x0, acc0 ; v_addc_co_u32 acc1, vcc, x1, acc1, vcc
                         uint32_t vd = 0, vx = 0;
@@ -345,11 +369,20 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             if (xr.chunk < 0) return 32;
                             const uint64_t xrow = (uint64_t)xr.chunk * KC + xr.ldsrow % KC;
                             const uint32_t k = (vd - R.acc0) / 2;
+                            if ((vals != nullptr) != xr.has_mul) return 35;                     // every entry of a valued matrix is multiplied once
                             for (uint32_t l = 0; l < wvalid; l++) {
-                                const T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
+                                T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
                                 T &a = acc[(size_t)k * 64 + l];
                                 if constexpr (std::is_integral<T>::value) a = (T)((uint64_t)a + (uint64_t)xv);
-                                else a = a + xv;
+                                else {
+                                    if (xr.has_mul) {
+                                        double mv;
+                                        std::memcpy(&mv, &xr.mulbits64, 8);
+                                        volatile double prod = mv * xv;   // product and sum round separately (no FMA)
+                                        xv = prod;
+                                    }
+                                    a = a + xv;
+                                }
                             }
                             if (s == 0) entries_seen++;
                             continue;
@@ -508,6 +541,11 @@ int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,
                      uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
     return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile, boundary);
+}
+// valued DBL64 (round 5): s_mov_b32 x 2 + v_mul_f64 with the value in s[94:95]
+int lds_code_f64_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const double *X, uint32_t h, double *C, uint32_t threads,
+                         uint64_t *stats, uint32_t kc, uint32_t nbuf, const double *vals, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<double>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, 1, 8, gsize, nsets, rows_per_tile, boundary);
 }
 // valued INT32 (round 5): the value inline in a v_mul_lo_u32 (all values in [-16, 64]) or through an SGPR
 int lds_code_i32_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,

@@ -6,6 +6,7 @@
 #include "lds_plan_emul.cpp"
 
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 
@@ -82,7 +83,22 @@ int main(int argc, char **argv) {
         if (c % 5 == 4) {   // the 8-byte element form: 512-byte rows, register pairs (8 waves x 114 rows)
             const uint32_t g8[][4] = {{64, 5, 5, 2}, {48, 6, 3, 3}, {96, 3, 2, 2}, {16, 5, 5, 2}, {32, 10, 4, 2}};
             const auto &q = g8[rng() % 5];
-            if (c % 2) {
+            if (c % 2 && splits == 1 && rng() % 2 == 0) {   // valued DBL64 (round 5): real-valued weights and features, bit-identical to the sequential loop
+                std::vector<double> x((size_t)ncols * h), out((size_t)nrows * h, 77.0), vals(m.col.size());
+                std::uniform_real_distribution<double> ud(-1.0, 1.0);
+                for (auto &v : x) v = ud(rng);
+                for (auto &v : vals) v = ud(rng);
+                const int rc = lds_code_f64_val_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], vals.data(), q[2], q[3], rpt, bnd);
+                if (rc) { printf("case %d: interpreter code %d (valued f64 geo %u %u %u %u)\n", c, rc, q[0], q[1], q[2], q[3]); return 1; }
+                std::vector<double> want((size_t)nrows * h, 0.0);
+                for (uint32_t r = 0; r < nrows; r++)
+                    for (uint32_t e = m.rowptr[r]; e < m.rowptr[r + 1]; e++)
+                        for (uint32_t f = 0; f < h; f++) {
+                            volatile double prod = vals[e] * x[(size_t)m.col[e] * h + f];
+                            want[(size_t)r * h + f] = want[(size_t)r * h + f] + prod;
+                        }
+                if (memcmp(out.data(), want.data(), want.size() * 8) != 0) { printf("case %d: valued f64 result differs\n", c); return 2; }
+            } else if (c % 2) {
                 std::vector<double> x((size_t)ncols * h), out((size_t)nrows * h, 77.0);
                 for (auto &v : x) v = (double)((int64_t)(rng() % 17) - 8);
                 const int rc = lds_code_f64_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], splits, q[2], q[3], rpt, bnd);

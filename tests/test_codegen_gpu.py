@@ -97,6 +97,17 @@ def test_valued_int32_entries(rng, checked, small):
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
 
 
+def test_valued_double_entries(rng, checked):
+    """valued DBL64 on the code stream (round 5): per entry s_mov_b32 x 2 + v_mul_f64 with the value in s[94:95], then v_add_f64 -- product and sum
+    rounded separately, every row summed by one wave in stored order: the CPU loop's bits"""
+    rowptr, col = random_csr(rng, 2200, 1500, 16, long_rows=[(3, 2100)])
+    x = feats(rng, 1500, 70, np.float64)
+    vals = (rng.random(len(col)) * 2 - 1).astype(np.float64)
+    got, info, note = run(rowptr, col, x, vals=vals)
+    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
+
+
 @pytest.mark.parametrize("geo", [(8, 5, 0, 0, 0, 0), (16, 2, 0, 0, 0, 0), (16, 3, 0, 8, 2, 1), (8, 2, 0, 10, 2, 0), (8, 3, 0, 6, 3, 1), (8, 4, 160, 12, 2, 1), (8, 8, 64, 2, 2, 1), (8, 5, 32, 4, 3, 1)])
 def test_device_stream_equals_host_stream_every_geometry(rng, checked, geo):
     for k, v in zip(GEO_KNOBS, geo):

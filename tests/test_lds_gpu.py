@@ -265,8 +265,8 @@ def test_random_shapes(seed, lds_forced):
 
 @pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64", "FLT32", "DBL64"])
 def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
-    """lds_mode = 1 with every val_dt (support/common.h:39-60): INT16 / INT32 / FLT32 take the LDS-staged kernel, the other three
-    keep their kernels -- all equal the oracle (integers bit-exact; floats bit-exact here too: real-valued features, rows of <= 512 entries per
+    """lds_mode = 1 with every val_dt (support/common.h:39-60), unit weights and values: the LDS-staged kernel wherever a plan exists,
+    the sweep otherwise -- all equal the oracle (integers bit-exact; floats bit-exact here too: real-valued features, rows of <= 512 entries per
     panel for the sweep's types, empty rows, one long row)"""
     from conftest import NP_DTYPES
 
@@ -288,7 +288,8 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         try:
             # (round 4: unit-weight INT8 rides the INT16 code stream, its features widened to 16 bits in the staged copy)
             #  and unit-weight INT64 / DBL64 their own 8-byte code stream: rows of 512 bytes in LDS, a register pair per running sum)
-            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32") or (dt in ("INT8", "INT64", "DBL64") and v is None)), dt
+            #  (round 5: valued DBL64 too -- the value through an SGPR pair; valued INT8 / INT64 keep the sweep)
+            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32", "DBL64") or (dt in ("INT8", "INT64") and v is None)), dt
             out = np.full((n, h), 77, dtype=npdt)
             _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
         finally:
