@@ -74,10 +74,10 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
         throw std::runtime_error("lds codegen: the geometry does not fit the register map");
     if (P.KA > 255) throw std::runtime_error("lds codegen: more than 255 accumulators per wave");
     P.opcode_add = opcode_add;
-    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64)
+    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64 && opcode_add != LDS_CODE_ADD_U64)
         throw std::runtime_error("lds codegen: valued entries of this element type");
-    P.int_inline = (valued && opcode_add == 0x68000000u && int_inline) ? 1 : 0;
-    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
+    P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64) && int_inline) ? 1 : 0;
+    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (int_inline ? 8 : 10) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
     if (P.pieces * geo.NW * 1024 != geo.KC * geo.row_bytes) throw std::runtime_error("lds codegen: a chunk is not a whole number of pieces per wave");
@@ -514,7 +514,17 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
     const uint32_t vx = P.x0 + P.G * P.XW * T.g_xset[g] + u * P.XW, vk = P.acc0 + k * P.XW;
     uint32_t *w = T.code + T.g_apos[g];
     if (P.valued) {
-        if (P.opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
+        if (P.opcode_add == LDS_CODE_ADD_U64) {   // INT64 (values that fit int32): lds_code_from_plan's sequence of 32-bit pieces
+            const int32_t v = (int32_t)(uint32_t)T.vals_in64[T.vals[i]];
+            const uint32_t xl = vx, xh = vx + 1, ah = vk + 1, src = P.int_inline ? lds_inline_int(v) : LDS_CODE_S_VAL;
+            uint32_t *m = w + P.mulw * q;
+            if (!P.int_inline) { *m++ = 0xBE8000FFu | (LDS_CODE_S_VAL << 16); *m++ = (uint32_t)v; }
+            *m++ = 0xD2850000u | xh; *m++ = src | ((256 + xh) << 9);
+            *m++ = v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u;
+            *m++ = 0x68000000u | (ah << 17) | (ah << 9) | (256 + xh);
+            *m++ = 0xD2860000u | xh; *m++ = src | ((256 + xl) << 9);
+            *m++ = 0xD2850000u | xl; *m++ = src | ((256 + xl) << 9);
+        } else if (P.opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
             const uint64_t v = T.vals_in64[T.vals[i]];
             w[6 * q] = 0xBE8000FFu | (LDS_CODE_S_VAL << 16);
             w[6 * q + 1] = (uint32_t)v;
@@ -575,7 +585,10 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
     }
     const uint64_t nnz = rowptr[nrows];
     const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets,
-                                 vals != nullptr && !vals64 && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz));
+                                 (vals != nullptr && !vals64 && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz)) ||
+                                     (vals64 && opcode_add == LDS_CODE_ADD_U64 && [&] {
+                                         for (uint64_t i = 0; i < nnz; i++) { const int64_t v = (int64_t)vals64[i]; if (v < -16 || v > 64) return false; }
+                                         return true; }()));
     cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.vals_in64 = vals64; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;

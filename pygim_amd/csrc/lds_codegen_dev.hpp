@@ -235,6 +235,28 @@ __global__ __launch_bounds__(256) void k_cg_int_outside(const uint32_t *vals, ui
         if (v < -16 || v > 64) flag[0] = 1u;
     }
 }
+// valued INT64: flag[0] |= 1 when a value lies outside the inline-constant range [-16, 64], |= 2 when one does not fit 32 bits
+__global__ __launch_bounds__(256) void k_cg_i64_range(const uint64_t *vals, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int64_t v = (int64_t)vals[i];
+        uint32_t f = 0;
+        if (v < -16 || v > 64) f |= 1u;
+        if (v != (int64_t)(int32_t)v) f |= 2u;
+        if (f) atomicOr(flag, f);
+    }
+}
+// 0 = every value inline, 1 = every value fits int32, 2 = some value needs more than 32 bits (or the check failed)
+inline int cg_i64_value_class(const uint64_t *d_vals64, uint64_t n, hipStream_t st) {
+    uint32_t *d_flag = nullptr, h_flag = 2;
+    if (hipMalloc((void **)&d_flag, 64) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    (void)hipMemsetAsync(d_flag, 0, 64, st);
+    if (n) hipLaunchKernelGGL(k_cg_i64_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_vals64, n, d_flag);
+    const bool got = hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    (void)hipFree(d_flag);
+    if (!got) { (void)hipGetLastError(); return 2; }
+    return (h_flag & 2u) ? 2 : (h_flag & 1u) ? 1 : 0;
+}
 __global__ __launch_bounds__(256) void k_cg_fill_words(uint32_t *p, uint64_t n, uint32_t word) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = word;
@@ -279,6 +301,11 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
         (void)hipFree(d_flag);
         if (!got) { (void)hipGetLastError(); return "lds codegen: value range check failed"; }
         int_inline = h_flag == 0;
+    }
+    if (d_vals64 && opcode_add == LDS_CODE_ADD_U64) {   // valued INT64: values that fit int32 only (the caller checked); inline when all allow it
+        const int cls = cg_i64_value_class(d_vals64, nnz, st);
+        if (cls == 2) return "lds codegen: an INT64 value does not fit 32 bits";
+        int_inline = cls == 0;
     }
     CgParams P;
     try {

@@ -459,7 +459,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     const bool wide = RB == 512;
     if (RB != 256 && RB != 512) throw std::runtime_error("lds code: rows of 256 or 512 bytes");
     if (wide != (opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64)) throw std::runtime_error("lds code: 512-byte rows are the 8-byte element types'");
-    if (!plan.wts.empty() && ((opcode_add == LDS_CODE_ADD_F64 && !vals64) || opcode_add == LDS_CODE_ADD_U64 || opcode_add == LDS_CODE_PK_ADD_U16))
+    if (!plan.wts.empty() && (((opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) && !vals64) || opcode_add == LDS_CODE_PK_ADD_U16))
         throw std::runtime_error("lds code: valued entries of this element type");
     const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets, wide);
     out.regs = R;
@@ -498,7 +498,16 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     };
     const LdsCodeRegs Rr = R;
     // (padding tokens carry the value 0: inside the inline range)
-    const bool int_inline = opcode_add == 0x68000000u && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
+    bool int_inline = opcode_add == 0x68000000u && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
+    if (opcode_add == LDS_CODE_ADD_U64 && !plan.wts.empty()) {   // INT64: every value fits int32 (the caller checked); inline when all lie in [-16, 64]
+        int_inline = true;
+        for (uint64_t i = 0; i < plan.ntokens && int_inline; i++) {
+            if ((plan.tok[i] & 0xFF) >= KA) continue;   // padding
+            const int64_t v = (int64_t)vals64[plan.wts[i]];
+            if (v != (int64_t)(int32_t)v) throw std::runtime_error("lds code: an INT64 value does not fit 32 bits");
+            if (v < -16 || v > 64) int_inline = false;
+        }
+    }
     auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs, uint64_t &n_shared) {
         const LdsTile &t = plan.tiles[ti];
         auto s_add_lit = [&](uint32_t sdst, uint32_t ssrc, uint32_t lit) { e.op(0x80000000u | (sdst << 16) | (0xFFu << 8) | ssrc, lit); };
@@ -557,7 +566,21 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             wait_lgkm(younger);
             if (younger <= lds_this_slot) older_reads = false;      // (LDS reads return in order)
             const Grp &g = ring[pend.front()];
-            if (valued && opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
+            if (valued && opcode_add == LDS_CODE_ADD_U64) {
+                // INT64 (round 5), values that fit int32: x * v modulo 2^64 from 32-bit pieces, v_u = v mod 2^32 as the operand V --
+                //   hi(acc) += lo32(x_hi * V) - [v < 0] * x_lo ;  (acc) += (lo32(x_lo * V), hi32(x_lo * V))   [the 64-bit add follows with the sums]
+                for (size_t q = 0; q < g.k.size(); q++) {
+                    const int32_t v = (int32_t)(uint32_t)vals64[g.v[q]];
+                    const uint32_t xl = g.xr[q], xh = g.xr[q] + 1, ah = Rr.acc0 + g.k[q] * 2 + 1;
+                    const uint32_t src = int_inline ? lds_inline_int(v) : LDS_CODE_S_VAL;
+                    if (!int_inline) e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);                    // s_mov_b32 s94, <value>
+                    e.op(0xD2850000u | xh, src | ((256 + xh) << 9));                                              // v_mul_lo_u32 x_hi, V, x_hi
+                    e.op(v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u);              // v_sub_u32 x_hi, x_hi, x_lo  |  s_nop
+                    e.op(0x68000000u | (ah << 17) | (ah << 9) | (256 + xh));                                      // v_add_u32 acc_hi, x_hi, acc_hi
+                    e.op(0xD2860000u | xh, src | ((256 + xl) << 9));                                              // v_mul_hi_u32 x_hi, V, x_lo
+                    e.op(0xD2850000u | xl, src | ((256 + xl) << 9));                                              // v_mul_lo_u32 x_lo, V, x_lo
+                }
+            } else if (valued && opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
                 for (size_t q = 0; q < g.k.size(); q++) {
                     const uint64_t v = vals64[g.v[q]];
                     e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);

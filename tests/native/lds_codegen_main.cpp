@@ -75,13 +75,18 @@ int main(int argc, char **argv) {
             for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : (uint32_t)rng();
         }
         // valued DBL64 (round 5): the plan's value slot carries the entry index, the values travel beside it
-        const bool valued64 = wide && op == LDS_CODE_ADD_F64 && geo.col_splits == 1 && rng() % 2 == 0;
+        const bool valued64 = wide && geo.col_splits == 1 && rng() % 2 == 0;   // DBL64: any bits; INT64: values that fit int32, small or any
         std::vector<uint64_t> vals64;
         std::vector<uint32_t> eidx;
         if (valued64) {
             vals64.resize(m.col.size());
             eidx.resize(m.col.size());
-            for (size_t i = 0; i < vals64.size(); i++) { vals64[i] = rng(); eidx[i] = (uint32_t)i; }
+            const bool small = rng() & 1;
+            for (size_t i = 0; i < vals64.size(); i++) {
+                eidx[i] = (uint32_t)i;
+                if (op == LDS_CODE_ADD_F64) vals64[i] = rng();
+                else vals64[i] = (uint64_t)(int64_t)(small ? (int32_t)(rng() % 81) - 16 : (int32_t)rng());
+            }
         }
         // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)
         std::vector<uint32_t> rorder;

@@ -203,7 +203,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 uint64_t barriers = 0;
                 struct VLoad { int buf; int64_t cid; bool last; };
                 std::vector<VLoad> vfifo;                     // vector loads in flight, oldest first (DMA pieces and touches)
-                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; uint64_t mulbits64 = 0; int64_t chunk = -1; };
+                struct XReg { bool valid = false, inflight = false, has_mul = false; uint32_t ldsrow = 0, mulbits = 0; uint64_t mulbits64 = 0; int64_t chunk = -1;
+                              int mstage = 0; int32_t mval = 0; uint32_t macc = 0; };   // (valued INT64: where the entry's multiply sequence stands)
                 XReg x[32];
                 std::vector<uint32_t> fifo;                   // x registers with a read in flight, oldest first
                 uint64_t pc = ch.start[(size_t)ti * NW + w] / 4;
@@ -318,6 +319,63 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     }
                     if (WIDE && vals && i0 == (0xBE8000FFu | (LDS_CODE_S_VAL << 16))) { sval = ch.code[pc + 1]; sval_set = true; pc += 2; continue; }           // s_mov_b32 s94, <low half>
                     if (WIDE && vals && i0 == (0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16))) { sval_hi = ch.code[pc + 1]; sval_hi_set = true; pc += 2; continue; }   // s_mov_b32 s95, <high half>
+                    if (WIDE && vals && opcode == LDS_CODE_ADD_U64) {
+                        // valued INT64 (values that fit int32): v_mul_lo_u32 x_hi, V, x_hi ; [v_sub_u32 x_hi, x_hi, x_lo] ; v_add_u32 acc_hi, x_hi, acc_hi ;
+                        // v_mul_hi_u32 x_hi, V, x_lo ; v_mul_lo_u32 x_lo, V, x_lo -- V an inline constant or s94 -- then the 64-bit add below
+                        auto operand = [&](uint32_t src0, int32_t *val) -> bool {
+                            if (src0 == LDS_CODE_S_VAL) { if (!sval_set) return false; *val = (int32_t)sval; return true; }
+                            if (src0 >= 128 && src0 <= 192) { *val = (int32_t)(src0 - 128); return true; }
+                            if (src0 >= 193 && src0 <= 208) { *val = -(int32_t)(src0 - 192); return true; }
+                            return false;
+                        };
+                        if ((i0 & 0xFFFFFF00u) == 0xD2850000u || (i0 & 0xFFFFFF00u) == 0xD2860000u) {
+                            const bool hi_op = (i0 & 0xFFFFFF00u) == 0xD2860000u;
+                            const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF, src0 = d1 & 0x1FF, vs1 = ((d1 >> 9) & 0x1FF) - 256;
+                            if ((d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
+                            const uint32_t base = (vd - R.x0) & ~1u;
+                            XReg &xr = x[base];
+                            int32_t v;
+                            if (!operand(src0, &v)) return 46;
+                            if (!hi_op && ((vd - R.x0) & 1)) {            // v_mul_lo_u32 x_hi, V, x_hi : the sequence starts
+                                bool infl = false;
+                                for (uint32_t r : fifo) if (r == base) infl = true;
+                                if (vs1 != vd || !xr.valid || infl || xr.has_mul || xr.mstage != 0) return 34;
+                                xr.inflight = false;
+                                xr.mstage = 1;
+                                xr.mval = v;
+                            } else if (hi_op) {                           // v_mul_hi_u32 x_hi, V, x_lo
+                                if (!((vd - R.x0) & 1) || vs1 != vd - 1 || xr.mstage != 3 || v != xr.mval) return 47;
+                                xr.mstage = 4;
+                            } else {                                      // v_mul_lo_u32 x_lo, V, x_lo : the sequence ends
+                                if (vs1 != vd || xr.mstage != 4 || v != xr.mval) return 47;
+                                xr.mstage = 0;
+                                xr.has_mul = true;
+                                xr.mulbits64 = (uint64_t)(int64_t)xr.mval;
+                                if (src0 == LDS_CODE_S_VAL) sval_set = false;
+                            }
+                            pc += 2;
+                            continue;
+                        }
+                        if ((i0 & 0xFE000000u) == 0x6A000000u) {                                // v_sub_u32 x_hi, x_hi, x_lo (negative values only)
+                            const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, s0 = (i0 & 0x1FF) - 256;
+                            if (vd < R.x0 + 1 || vd >= R.x0 + R.nx() || !((vd - R.x0) & 1) || s0 != vd || vs1 != vd - 1) return 47;
+                            XReg &xr = x[vd - 1 - R.x0];
+                            if (xr.mstage != 1 || xr.mval >= 0) return 47;
+                            xr.mstage = 2;
+                            pc++;
+                            continue;
+                        }
+                        if ((i0 & 0xFE000000u) == 0x68000000u) {                                // v_add_u32 acc_hi, x_hi, acc_hi
+                            const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, s0 = (i0 & 0x1FF) - 256;
+                            if (vd != vs1 || vd < R.acc0 + 1 || vd >= R.acc0 + 2 * KA || !((vd - R.acc0) & 1) || s0 < R.x0 + 1 || s0 >= R.x0 + R.nx() || !((s0 - R.x0) & 1)) return 47;
+                            XReg &xr = x[s0 - 1 - R.x0];
+                            if (xr.mstage != (xr.mval < 0 ? 2 : 1)) return 47;
+                            xr.mstage = 3;
+                            xr.macc = vd - 1;
+                            pc++;
+                            continue;
+                        }
+                    }
                     if (WIDE && vals && opcode == LDS_CODE_ADD_F64 && (i0 & 0xFFFFFF00u) == 0xD2810000u) {                                    // v_mul_f64 x[0:1], s[94:95], x[0:1]
                         const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF;
                         if ((d1 & 0x1FF) != LDS_CODE_S_VAL || ((d1 >> 9) & 0x1FF) != 256 + vd || (d1 >> 18) || !sval_set || !sval_hi_set) return 45;
@@ -370,12 +428,15 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             const uint64_t xrow = (uint64_t)xr.chunk * KC + xr.ldsrow % KC;
                             const uint32_t k = (vd - R.acc0) / 2;
                             if ((vals != nullptr) != xr.has_mul) return 35;                     // every entry of a valued matrix is multiplied once
+                            if (vals && std::is_integral<T>::value && xr.macc != vd) return 48;  // (INT64: its high half went to this accumulator)
+                            xr.has_mul = false;
+                            const bool had_mul = vals != nullptr;
                             for (uint32_t l = 0; l < wvalid; l++) {
                                 T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
                                 T &a = acc[(size_t)k * 64 + l];
-                                if constexpr (std::is_integral<T>::value) a = (T)((uint64_t)a + (uint64_t)xv);
+                                if constexpr (std::is_integral<T>::value) a = (T)((uint64_t)a + (had_mul ? xr.mulbits64 * (uint64_t)xv : (uint64_t)xv));
                                 else {
-                                    if (xr.has_mul) {
+                                    if (had_mul) {
                                         double mv;
                                         std::memcpy(&mv, &xr.mulbits64, 8);
                                         volatile double prod = mv * xv;   // product and sum round separately (no FMA)
@@ -541,6 +602,11 @@ int lds_code_i32_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows
                      uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits, uint32_t nw, uint32_t gsize,
                      uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
     return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits, nw, gsize, nsets, rows_per_tile, boundary);
+}
+// valued INT64 (round 5), values that fit int32: the 64-bit product from 32-bit pieces
+int lds_code_i64_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int64_t *X, uint32_t h, int64_t *C, uint32_t threads,
+                         uint64_t *stats, uint32_t kc, uint32_t nbuf, const int64_t *vals, uint32_t gsize, uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<int64_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, 1, 8, gsize, nsets, rows_per_tile, boundary);
 }
 // valued DBL64 (round 5): s_mov_b32 x 2 + v_mul_f64 with the value in s[94:95]
 int lds_code_f64_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const double *X, uint32_t h, double *C, uint32_t threads,

@@ -97,6 +97,24 @@ def test_valued_int32_entries(rng, checked, small):
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
 
 
+@pytest.mark.parametrize("small", [True, False])
+def test_valued_int64_entries(rng, checked, small):
+    """valued INT64 on the code stream (round 5) when every value fits 32 bits: the 64-bit product from 32-bit pieces (v_mul_lo_u32 x 2,
+    v_mul_hi_u32, a correction for negative values), the value inline ([-16, 64]) or through an SGPR; wraps modulo 2^64 like the CPU loop.
+    Values that need more than 32 bits keep the sweep."""
+    rowptr, col = random_csr(rng, 2200, 1500, 16, long_rows=[(3, 2100)])
+    x = feats(rng, 1500, 70, np.int64)
+    vals = (rng.integers(-16, 65, size=len(col)) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64)).astype(np.int64)
+    got, info, note = run(rowptr, col, x, vals=vals)
+    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
+    wide = vals.copy()
+    wide[5] = 2**40 + 3                                     # one value beyond 32 bits: no code stream for this matrix
+    got, info, note = run(rowptr, col, x, vals=wide)
+    assert info["active"] == 0, (info, note)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, wide, x).tobytes()
+
+
 def test_valued_double_entries(rng, checked):
     """valued DBL64 on the code stream (round 5): per entry s_mov_b32 x 2 + v_mul_f64 with the value in s[94:95], then v_add_f64 -- product and sum
     rounded separately, every row summed by one wave in stored order: the CPU loop's bits"""
