@@ -77,8 +77,9 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
     if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64 && opcode_add != LDS_CODE_ADD_U64)
         throw std::runtime_error("lds codegen: valued entries of this element type");
     P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64) && int_inline) ? 1 : 0;
-    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (int_inline ? 8 : 10) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
+    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (int_inline ? 6 : 8) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
+    if (valued && opcode_add == LDS_CODE_ADD_U64) P.addw = 0;   // (the 64-bit sum is the v_mad_u64_u32 of the multiply)
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
     if (P.pieces * geo.NW * 1024 != geo.KC * geo.row_bytes) throw std::runtime_error("lds codegen: a chunk is not a whole number of pieces per wave");
     P.chunk_bytes = geo.KC * geo.row_bytes;
@@ -522,8 +523,8 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
             *m++ = 0xD2850000u | xh; *m++ = src | ((256 + xh) << 9);
             *m++ = v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u;
             *m++ = 0x68000000u | (ah << 17) | (ah << 9) | (256 + xh);
-            *m++ = 0xD2860000u | xh; *m++ = src | ((256 + xl) << 9);
-            *m++ = 0xD2850000u | xl; *m++ = src | ((256 + xl) << 9);
+            *m++ = 0xD1E86A00u | vk; *m++ = src | ((256 + xl) << 9) | ((256 + vk) << 18);   // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1]
+            return;
         } else if (P.opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
             const uint64_t v = T.vals_in64[T.vals[i]];
             w[6 * q] = 0xBE8000FFu | (LDS_CODE_S_VAL << 16);

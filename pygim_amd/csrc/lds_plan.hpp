@@ -450,7 +450,7 @@ inline bool lds_int_values_inline(const uint32_t *vals, uint64_t n) {
 }
 PYGIM_LDS_HD_INLINE uint32_t lds_inline_int(int32_t v) { return v >= 0 ? 128u + (uint32_t)v : 192u + (uint32_t)(-v); }   // VOP3 source field of an inline integer
 // DBL64 (round 5): the plan's 4-byte value slot carries the ENTRY INDEX and vals64 the values; per entry s_mov_b32 s94, <low half>; s_mov_b32 s95,
-// <high half>; v_mul_f64 x, s[94:95], x (24 bytes), product and sum rounded separately.  (INT64: a 64-bit multiply is six VOP3 instructions -- the sweep.)
+// <high half>; v_mul_f64 x, s[94:95], x (24 bytes), product and sum rounded separately.  (INT64, values that fit int32: v_mul_lo_u32 on the high half + v_mad_u64_u32 -- consume_oldest; wider values: the sweep.)
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
                                uint32_t nsets = 0, uint32_t experiment = 0, const uint64_t *vals64 = nullptr) {
     const LdsGeometry &geo = plan.geo;
@@ -567,18 +567,18 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             if (younger <= lds_this_slot) older_reads = false;      // (LDS reads return in order)
             const Grp &g = ring[pend.front()];
             if (valued && opcode_add == LDS_CODE_ADD_U64) {
-                // INT64 (round 5), values that fit int32: x * v modulo 2^64 from 32-bit pieces, v_u = v mod 2^32 as the operand V --
-                //   hi(acc) += lo32(x_hi * V) - [v < 0] * x_lo ;  (acc) += (lo32(x_lo * V), hi32(x_lo * V))   [the 64-bit add follows with the sums]
+                // INT64 (round 5), values that fit int32: acc += x * v modulo 2^64 from 32-bit pieces, v_u = v mod 2^32 as the operand V --
+                //   hi(acc) += lo32(x_hi * V) - [v < 0] * x_lo ;  acc += x_lo * V (v_mad_u64_u32: the 32 x 32 -> 64-bit product AND the 64-bit sum in one
+                //   instruction; the first form -- v_mul_hi_u32, v_mul_lo_u32, v_add_co, v_addc_co -- was 48 bytes of code per entry, this one is 32)
                 for (size_t q = 0; q < g.k.size(); q++) {
                     const int32_t v = (int32_t)(uint32_t)vals64[g.v[q]];
-                    const uint32_t xl = g.xr[q], xh = g.xr[q] + 1, ah = Rr.acc0 + g.k[q] * 2 + 1;
+                    const uint32_t xl = g.xr[q], xh = g.xr[q] + 1, al = Rr.acc0 + g.k[q] * 2, ah = al + 1;
                     const uint32_t src = int_inline ? lds_inline_int(v) : LDS_CODE_S_VAL;
                     if (!int_inline) e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);                    // s_mov_b32 s94, <value>
                     e.op(0xD2850000u | xh, src | ((256 + xh) << 9));                                              // v_mul_lo_u32 x_hi, V, x_hi
                     e.op(v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u);              // v_sub_u32 x_hi, x_hi, x_lo  |  s_nop
                     e.op(0x68000000u | (ah << 17) | (ah << 9) | (256 + xh));                                      // v_add_u32 acc_hi, x_hi, acc_hi
-                    e.op(0xD2860000u | xh, src | ((256 + xl) << 9));                                              // v_mul_hi_u32 x_hi, V, x_lo
-                    e.op(0xD2850000u | xl, src | ((256 + xl) << 9));                                              // v_mul_lo_u32 x_lo, V, x_lo
+                    e.op(0xD1E86A00u | al, src | ((256 + xl) << 9) | ((256 + al) << 18));                         // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1]
                 }
             } else if (valued && opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
                 for (size_t q = 0; q < g.k.size(); q++) {
@@ -598,7 +598,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             } else if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the products first (every entry has
                           // its own x register here: the multiply overwrites it)
                 for (size_t q = 0; q < g.k.size(); q++) e.op(0x0A0000FFu | (g.xr[q] << 17) | (g.xr[q] << 9), g.v[q]);   // v_mul_f32 x, <literal value>, x
-            for (size_t q = 0; q < g.k.size(); q++) {
+            for (size_t q = 0; q < g.k.size() && !(valued && opcode_add == LDS_CODE_ADD_U64); q++) {   // (valued INT64: the sum is part of the v_mad_u64_u32 above)
                 const uint32_t vk = Rr.acc0 + g.k[q] * (wide ? 2 : 1), vx = g.xr[q];
                 if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + vx));   // v_pk_add_u16 acc, x, acc
                 else if (opcode_add == LDS_CODE_ADD_F64) e.op(0xD2800000u | vk, (256 + vx) | ((256 + vk) << 9));             // v_add_f64 acc[0:1], x[0:1], acc[0:1]

@@ -218,6 +218,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                 bool sval_set = false;
                 uint32_t sval_hi = 0;                         // valued DBL64: s95, the high half (s94 = sval the low one)
                 bool sval_hi_set = false;
+                bool mad_add = false;                  // valued INT64: a v_mad_u64_u32 was decoded, its accumulate follows at once
+                uint32_t mad_vd = 0, mad_vx = 0;
                 for (uint64_t guard = 0; !done; guard++) {
                     if (pc >= ch.code.size() || guard > (1ull << 32)) return 20;
                     // vmcnt is a 6-bit counter: a wave has at most 63 vector loads in flight (the next one is not issued before the oldest
@@ -321,42 +323,46 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if (WIDE && vals && i0 == (0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16))) { sval_hi = ch.code[pc + 1]; sval_hi_set = true; pc += 2; continue; }   // s_mov_b32 s95, <high half>
                     if (WIDE && vals && opcode == LDS_CODE_ADD_U64) {
                         // valued INT64 (values that fit int32): v_mul_lo_u32 x_hi, V, x_hi ; [v_sub_u32 x_hi, x_hi, x_lo] ; v_add_u32 acc_hi, x_hi, acc_hi ;
-                        // v_mul_hi_u32 x_hi, V, x_lo ; v_mul_lo_u32 x_lo, V, x_lo -- V an inline constant or s94 -- then the 64-bit add below
+                        // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1] -- V an inline constant or s94; the last one is the entry's accumulate
                         auto operand = [&](uint32_t src0, int32_t *val) -> bool {
                             if (src0 == LDS_CODE_S_VAL) { if (!sval_set) return false; *val = (int32_t)sval; return true; }
                             if (src0 >= 128 && src0 <= 192) { *val = (int32_t)(src0 - 128); return true; }
                             if (src0 >= 193 && src0 <= 208) { *val = -(int32_t)(src0 - 192); return true; }
                             return false;
                         };
-                        if ((i0 & 0xFFFFFF00u) == 0xD2850000u || (i0 & 0xFFFFFF00u) == 0xD2860000u) {
-                            const bool hi_op = (i0 & 0xFFFFFF00u) == 0xD2860000u;
+                        if ((i0 & 0xFFFFFF00u) == 0xD2850000u) {                                // v_mul_lo_u32 x_hi, V, x_hi : the sequence starts
                             const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF, src0 = d1 & 0x1FF, vs1 = ((d1 >> 9) & 0x1FF) - 256;
-                            if ((d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
+                            if ((d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx() || !((vd - R.x0) & 1)) return 33;
                             const uint32_t base = (vd - R.x0) & ~1u;
                             XReg &xr = x[base];
                             int32_t v;
                             if (!operand(src0, &v)) return 46;
-                            if (!hi_op && ((vd - R.x0) & 1)) {            // v_mul_lo_u32 x_hi, V, x_hi : the sequence starts
-                                bool infl = false;
-                                for (uint32_t r : fifo) if (r == base) infl = true;
-                                if (vs1 != vd || !xr.valid || infl || xr.has_mul || xr.mstage != 0) return 34;
-                                xr.inflight = false;
-                                xr.mstage = 1;
-                                xr.mval = v;
-                            } else if (hi_op) {                           // v_mul_hi_u32 x_hi, V, x_lo
-                                if (!((vd - R.x0) & 1) || vs1 != vd - 1 || xr.mstage != 3 || v != xr.mval) return 47;
-                                xr.mstage = 4;
-                            } else {                                      // v_mul_lo_u32 x_lo, V, x_lo : the sequence ends
-                                if (vs1 != vd || xr.mstage != 4 || v != xr.mval) return 47;
-                                xr.mstage = 0;
-                                xr.has_mul = true;
-                                xr.mulbits64 = (uint64_t)(int64_t)xr.mval;
-                                if (src0 == LDS_CODE_S_VAL) sval_set = false;
-                            }
+                            bool infl = false;
+                            for (uint32_t r : fifo) if (r == base) infl = true;
+                            if (vs1 != vd || !xr.valid || infl || xr.has_mul || xr.mstage != 0) return 34;
+                            xr.inflight = false;
+                            xr.mstage = 1;
+                            xr.mval = v;
                             pc += 2;
                             continue;
                         }
-                        if ((i0 & 0xFE000000u) == 0x6A000000u) {                                // v_sub_u32 x_hi, x_hi, x_lo (negative values only)
+                        if ((i0 & 0xFFFFFF00u) == 0xD1E86A00u) {                                // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1]
+                            const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF, src0 = d1 & 0x1FF, vs1 = ((d1 >> 9) & 0x1FF) - 256, vs2 = ((d1 >> 18) & 0x1FF) - 256;
+                            if ((d1 >> 27) || vs2 != vd || vs1 < R.x0 || vs1 >= R.x0 + R.nx() || ((vs1 - R.x0) & 1)) return 47;
+                            XReg &xr = x[vs1 - R.x0];
+                            int32_t v;
+                            if (!operand(src0, &v)) return 46;
+                            if (xr.mstage != 3 || v != xr.mval || xr.macc != vd) return 47;
+                            xr.mstage = 0;
+                            xr.has_mul = true;
+                            xr.mulbits64 = (uint64_t)(int64_t)xr.mval;
+                            if (src0 == LDS_CODE_S_VAL) sval_set = false;
+                            mad_vd = vd;
+                            mad_vx = vs1;
+                            mad_add = true;
+                            pc += 2;
+                        }
+                        if (!mad_add && (i0 & 0xFE000000u) == 0x6A000000u) {                    // v_sub_u32 x_hi, x_hi, x_lo (negative values only)
                             const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, s0 = (i0 & 0x1FF) - 256;
                             if (vd < R.x0 + 1 || vd >= R.x0 + R.nx() || !((vd - R.x0) & 1) || s0 != vd || vs1 != vd - 1) return 47;
                             XReg &xr = x[vd - 1 - R.x0];
@@ -365,7 +371,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             pc++;
                             continue;
                         }
-                        if ((i0 & 0xFE000000u) == 0x68000000u) {                                // v_add_u32 acc_hi, x_hi, acc_hi
+                        if (!mad_add && (i0 & 0xFE000000u) == 0x68000000u) {                    // v_add_u32 acc_hi, x_hi, acc_hi
                             const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, s0 = (i0 & 0x1FF) - 256;
                             if (vd != vs1 || vd < R.acc0 + 1 || vd >= R.acc0 + 2 * KA || !((vd - R.acc0) & 1) || s0 < R.x0 + 1 || s0 >= R.x0 + R.nx() || !((s0 - R.x0) & 1)) return 47;
                             XReg &xr = x[s0 - 1 - R.x0];
@@ -395,7 +401,12 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         // v_add_f64 acc[0:1], x[0:1], acc[0:1]   |   v_add_co_u32 acc0, vcc, x0, acc0 ; v_addc_co_u32 acc1, vcc, x1, acc1, vcc
                         uint32_t vd = 0, vx = 0;
                         bool is_add = false;
-                        if (opcode == LDS_CODE_ADD_F64 && (i0 & 0xFFFFFF00u) == 0xD2800000u) {
+                        if (mad_add) {                      // (valued INT64: the v_mad_u64_u32 decoded above)
+                            vd = mad_vd;
+                            vx = mad_vx;
+                            is_add = true;
+                            mad_add = false;
+                        } else if (opcode == LDS_CODE_ADD_F64 && (i0 & 0xFFFFFF00u) == 0xD2800000u) {
                             const uint32_t d1 = ch.code[pc + 1];
                             vd = i0 & 0xFF;
                             vx = (d1 & 0x1FF) - 256;

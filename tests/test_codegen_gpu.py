@@ -99,8 +99,8 @@ def test_valued_int32_entries(rng, checked, small):
 
 @pytest.mark.parametrize("small", [True, False])
 def test_valued_int64_entries(rng, checked, small):
-    """valued INT64 on the code stream (round 5) when every value fits 32 bits: the 64-bit product from 32-bit pieces (v_mul_lo_u32 x 2,
-    v_mul_hi_u32, a correction for negative values), the value inline ([-16, 64]) or through an SGPR; wraps modulo 2^64 like the CPU loop.
+    """valued INT64 on the code stream (round 5) when every value fits 32 bits: the 64-bit product from 32-bit pieces (v_mul_lo_u32 on the high half,
+    a correction for negative values, v_mad_u64_u32 for product and sum of the low half), the value inline ([-16, 64]) or through an SGPR; wraps modulo 2^64 like the CPU loop.
     Values that need more than 32 bits keep the sweep."""
     rowptr, col = random_csr(rng, 2200, 1500, 16, long_rows=[(3, 2100)])
     x = feats(rng, 1500, 70, np.int64)
