@@ -547,6 +547,25 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             dma_issued += (experiment & 2) ? 0 : pieces;
             landed_mark[j] = vm_now();
         };
+        // experiment bit 2 (results stay RIGHT): the pieces of a chunk go out one behind every group of reads instead of all behind the slot's
+        // first group -- a wave that waits for room in the vector memory queue then waits with reads in flight
+        const bool spread = (experiment & 4) && pieces <= 4 && !mid;
+        uint32_t dma_left = 0, dma_j = 0;
+        auto dma_begin = [&](uint32_t j) {
+            const uint32_t cid = plan.chunks[t.chunk_off + j], buf = j % NBUF;
+            s_add_lit(Rr.s_pa, Rr.s_xs, cid * chunk_bytes);
+            s_addc0(Rr.s_pa + 1, Rr.s_xs + 1);
+            s_add_lit(124 /* m0 */, Rr.s_ldsw, buf * chunk_bytes);
+            e.op(0xBF800000u);
+            dma_left = pieces;
+            dma_j = j;
+        };
+        auto dma_piece = [&]() {
+            const uint32_t i = pieces - dma_left;
+            e.op(0xDDF48000u | (i * 1024), (Rr.s_pa << 16) | Rr.vl16);
+            dma_issued++;
+            if (!--dma_left) landed_mark[dma_j] = vm_now();
+        };
         auto wait_landed = [&](uint32_t j) {                        // s_waitcnt vmcnt(N): everything up to chunk j's last piece has landed
             const uint64_t younger = vm_now() - landed_mark[j];
             const uint32_t nn = (uint32_t)std::min<uint64_t>(younger, 63);
@@ -710,15 +729,18 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 pend.push_back(gcount % (NS + 1));
                 gcount++;
                 if (dma_due) {
-                    dma_chunk(j + NBUF - 1);
+                    if (spread) dma_begin(j + NBUF - 1);
+                    else dma_chunk(j + NBUF - 1);
                     dma_due = false;
                 }
+                if (dma_left) dma_piece();
                 if (pend.size() >= NS) consume_oldest();            // frees the x-set the next group reads into
                 if (handoff_due && gi + 1 >= (ngroups_est + 1) / 2) handoff();
                 gi++;
                 if (e.since_touch >= TOUCH_EVERY_DW) touch();
             }
             if (dma_due) dma_chunk(j + NBUF - 1);                   // (a slot without entries for this wave)
+            while (dma_left) dma_piece();
             if (handoff_due) handoff();
             if (!mid) {
                 // everybody's reads of this chunk have returned and everybody has landed the next before anybody goes on; the adds of
