@@ -46,7 +46,8 @@ struct CgParams {
     uint32_t NW = 8, KA = 228, KC = 128, NBUF = 5, RB = 256, RPB = 256, G = 10, NS = 2, XW = 1;
     uint32_t wide = 0, valued = 0;
     uint32_t mulw = 0;                              // valued: dwords of an entry's multiply -- 2 (v_mul_f32 literal; v_mul_lo_u32 inline value), 4 (s_mov_b32 + v_mul_lo_u32)
-    uint32_t int_inline = 0;                        // valued INT32: every value lies in [-16, 64] (lds_int_values_inline)
+    uint32_t int_inline = 0;                        // valued INT32 / INT64: every value lies in [-16, 64] (lds_int_values_inline)
+    uint32_t i64_full = 0;                          // valued INT64: some value needs more than 32 bits (both halves through s[94:95])
     uint32_t opcode_add = 0x02000000u, addw = 1;   // dwords per accumulate
     uint32_t pieces = 4, chunk_bytes = 32768;
     uint32_t nrows = 0, ncols = 0, nchunks = 0, ntiles = 0, nstreams = 0;
@@ -61,7 +62,7 @@ struct CgParams {
 constexpr uint32_t CG_TOUCH_EVERY_DW = 256;   // (lds_code_from_plan: TOUCH_EVERY_DW)
 
 inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valued, uint32_t nrows, uint32_t ncols, uint32_t gsize = 0, uint32_t nsets = 0,
-                          bool int_inline = false) {
+                          bool int_inline = false, bool i64_full = false) {
     if (geo.NBUF >= 3 && !geo.boundary) throw std::runtime_error("lds codegen: the mid-slot hand-off takes the host encoder");
     CgParams P;
     const bool wide = geo.row_bytes == 512;
@@ -76,8 +77,9 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
     P.opcode_add = opcode_add;
     if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64 && opcode_add != LDS_CODE_ADD_U64)
         throw std::runtime_error("lds codegen: valued entries of this element type");
-    P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64) && int_inline) ? 1 : 0;
-    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (int_inline ? 6 : 8) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
+    P.i64_full = (valued && opcode_add == LDS_CODE_ADD_U64 && i64_full) ? 1 : 0;
+    P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64) && int_inline && !P.i64_full) ? 1 : 0;
+    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (P.i64_full ? 12 : P.int_inline ? 6 : 8) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
     if (valued && opcode_add == LDS_CODE_ADD_U64) P.addw = 0;   // (the 64-bit sum is the v_mad_u64_u32 of the multiply)
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
@@ -516,13 +518,19 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
     uint32_t *w = T.code + T.g_apos[g];
     if (P.valued) {
         if (P.opcode_add == LDS_CODE_ADD_U64) {   // INT64 (values that fit int32): lds_code_from_plan's sequence of 32-bit pieces
-            const int32_t v = (int32_t)(uint32_t)T.vals_in64[T.vals[i]];
+            const uint64_t v64 = T.vals_in64[T.vals[i]];
+            const int32_t v = (int32_t)(uint32_t)v64;
             const uint32_t xl = vx, xh = vx + 1, ah = vk + 1, src = P.int_inline ? lds_inline_int(v) : LDS_CODE_S_VAL;
             uint32_t *m = w + P.mulw * q;
             if (!P.int_inline) { *m++ = 0xBE8000FFu | (LDS_CODE_S_VAL << 16); *m++ = (uint32_t)v; }
+            if (P.i64_full) { *m++ = 0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16); *m++ = (uint32_t)(v64 >> 32); }
             *m++ = 0xD2850000u | xh; *m++ = src | ((256 + xh) << 9);
-            *m++ = v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u;
+            if (!P.i64_full) *m++ = v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u;
             *m++ = 0x68000000u | (ah << 17) | (ah << 9) | (256 + xh);
+            if (P.i64_full) {
+                *m++ = 0xD2850000u | xh; *m++ = (LDS_CODE_S_VAL + 1) | ((256 + xl) << 9);
+                *m++ = 0x68000000u | (ah << 17) | (ah << 9) | (256 + xh);
+            }
             *m++ = 0xD1E86A00u | vk; *m++ = src | ((256 + xl) << 9) | ((256 + vk) << 18);   // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1]
             return;
         } else if (P.opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair
@@ -589,7 +597,10 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
                                  (vals != nullptr && !vals64 && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz)) ||
                                      (vals64 && opcode_add == LDS_CODE_ADD_U64 && [&] {
                                          for (uint64_t i = 0; i < nnz; i++) { const int64_t v = (int64_t)vals64[i]; if (v < -16 || v > 64) return false; }
-                                         return true; }()));
+                                         return true; }()),
+                                 vals64 && opcode_add == LDS_CODE_ADD_U64 && [&] {
+                                     for (uint64_t i = 0; i < nnz; i++) { const int64_t v = (int64_t)vals64[i]; if (v != (int64_t)(int32_t)v) return true; }
+                                     return false; }());
     cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.vals_in64 = vals64; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;

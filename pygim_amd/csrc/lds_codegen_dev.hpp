@@ -246,15 +246,15 @@ __global__ __launch_bounds__(256) void k_cg_i64_range(const uint64_t *vals, uint
         if (f) atomicOr(flag, f);
     }
 }
-// 0 = every value inline, 1 = every value fits int32, 2 = some value needs more than 32 bits (or the check failed)
+// 0 = every value inline, 1 = every value fits int32, 2 = some value needs more than 32 bits; -1 = the check failed
 inline int cg_i64_value_class(const uint64_t *d_vals64, uint64_t n, hipStream_t st) {
     uint32_t *d_flag = nullptr, h_flag = 2;
-    if (hipMalloc((void **)&d_flag, 64) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    if (hipMalloc((void **)&d_flag, 64) != hipSuccess) { (void)hipGetLastError(); return -1; }
     (void)hipMemsetAsync(d_flag, 0, 64, st);
     if (n) hipLaunchKernelGGL(k_cg_i64_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_vals64, n, d_flag);
     const bool got = hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     (void)hipFree(d_flag);
-    if (!got) { (void)hipGetLastError(); return 2; }
+    if (!got) { (void)hipGetLastError(); return -1; }
     return (h_flag & 2u) ? 2 : (h_flag & 1u) ? 1 : 0;
 }
 __global__ __launch_bounds__(256) void k_cg_fill_words(uint32_t *p, uint64_t n, uint32_t word) {
@@ -302,14 +302,16 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
         if (!got) { (void)hipGetLastError(); return "lds codegen: value range check failed"; }
         int_inline = h_flag == 0;
     }
-    if (d_vals64 && opcode_add == LDS_CODE_ADD_U64) {   // valued INT64: values that fit int32 only (the caller checked); inline when all allow it
+    bool i64_full = false;
+    if (d_vals64 && opcode_add == LDS_CODE_ADD_U64) {   // valued INT64: inline when every value allows it, one SGPR when all fit int32, else both halves
         const int cls = cg_i64_value_class(d_vals64, nnz, st);
-        if (cls == 2) return "lds codegen: an INT64 value does not fit 32 bits";
+        if (cls < 0) return "lds codegen: value range check failed";
         int_inline = cls == 0;
+        i64_full = cls == 2;
     }
     CgParams P;
     try {
-        P = cg_params(geo, opcode_add, d_vals != nullptr || d_vals64 != nullptr, nrows, ncols, gsize, nsets, int_inline);
+        P = cg_params(geo, opcode_add, d_vals != nullptr || d_vals64 != nullptr, nrows, ncols, gsize, nsets, int_inline, i64_full);
     } catch (const std::exception &e) {
         return e.what();
     }

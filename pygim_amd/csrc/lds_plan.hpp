@@ -499,14 +499,16 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     const LdsCodeRegs Rr = R;
     // (padding tokens carry the value 0: inside the inline range)
     bool int_inline = opcode_add == 0x68000000u && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
-    if (opcode_add == LDS_CODE_ADD_U64 && !plan.wts.empty()) {   // INT64: every value fits int32 (the caller checked); inline when all lie in [-16, 64]
+    bool i64_full = false;   // INT64: some value needs more than 32 bits -- both halves travel through s[94:95]
+    if (opcode_add == LDS_CODE_ADD_U64 && !plan.wts.empty()) {   // INT64: inline when all values lie in [-16, 64], one SGPR when all fit int32
         int_inline = true;
-        for (uint64_t i = 0; i < plan.ntokens && int_inline; i++) {
+        for (uint64_t i = 0; i < plan.ntokens; i++) {
             if ((plan.tok[i] & 0xFF) >= KA) continue;   // padding
             const int64_t v = (int64_t)vals64[plan.wts[i]];
-            if (v != (int64_t)(int32_t)v) throw std::runtime_error("lds code: an INT64 value does not fit 32 bits");
+            if (v != (int64_t)(int32_t)v) i64_full = true;
             if (v < -16 || v > 64) int_inline = false;
         }
+        if (i64_full) int_inline = false;
     }
     auto emit_stream = [&](uint32_t ti, uint32_t wv, Emit &e, uint64_t &n_entries, uint64_t &n_pairs, uint64_t &n_shared) {
         const LdsTile &t = plan.tiles[ti];
@@ -589,14 +591,21 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                 // INT64 (round 5), values that fit int32: acc += x * v modulo 2^64 from 32-bit pieces, v_u = v mod 2^32 as the operand V --
                 //   hi(acc) += lo32(x_hi * V) - [v < 0] * x_lo ;  acc += x_lo * V (v_mad_u64_u32: the 32 x 32 -> 64-bit product AND the 64-bit sum in one
                 //   instruction; the first form -- v_mul_hi_u32, v_mul_lo_u32, v_add_co, v_addc_co -- was 48 bytes of code per entry, this one is 32)
+                // Values of more than 32 bits: x * v = x_lo * v_lo + 2^32 * (x_hi * v_lo + x_lo * v_hi) modulo 2^64, every piece unsigned (48 bytes).
                 for (size_t q = 0; q < g.k.size(); q++) {
-                    const int32_t v = (int32_t)(uint32_t)vals64[g.v[q]];
+                    const uint64_t v64 = vals64[g.v[q]];
+                    const int32_t v = (int32_t)(uint32_t)v64;
                     const uint32_t xl = g.xr[q], xh = g.xr[q] + 1, al = Rr.acc0 + g.k[q] * 2, ah = al + 1;
                     const uint32_t src = int_inline ? lds_inline_int(v) : LDS_CODE_S_VAL;
-                    if (!int_inline) e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);                    // s_mov_b32 s94, <value>
+                    if (!int_inline) e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);                    // s_mov_b32 s94, <value / its low half>
+                    if (i64_full) e.op(0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16), (uint32_t)(v64 >> 32));        // s_mov_b32 s95, <high half>
                     e.op(0xD2850000u | xh, src | ((256 + xh) << 9));                                              // v_mul_lo_u32 x_hi, V, x_hi
-                    e.op(v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u);              // v_sub_u32 x_hi, x_hi, x_lo  |  s_nop
+                    if (!i64_full) e.op(v < 0 ? (0x6A000000u | (xh << 17) | (xl << 9) | (256 + xh)) : 0xBF800000u);   // v_sub_u32 x_hi, x_hi, x_lo  |  s_nop
                     e.op(0x68000000u | (ah << 17) | (ah << 9) | (256 + xh));                                      // v_add_u32 acc_hi, x_hi, acc_hi
+                    if (i64_full) {
+                        e.op(0xD2850000u | xh, (LDS_CODE_S_VAL + 1) | ((256 + xl) << 9));                         // v_mul_lo_u32 x_hi, V_hi, x_lo
+                        e.op(0x68000000u | (ah << 17) | (ah << 9) | (256 + xh));                                  // v_add_u32 acc_hi, x_hi, acc_hi
+                    }
                     e.op(0xD1E86A00u | al, src | ((256 + xl) << 9) | ((256 + al) << 18));                         // v_mad_u64_u32 acc[0:1], vcc, V, x_lo, acc[0:1]
                 }
             } else if (valued && opcode_add == LDS_CODE_ADD_F64) {   // DBL64: the value through an SGPR pair

@@ -14,13 +14,14 @@ st = torch.cuda.current_stream().cuda_stream
 for dt, code in ((torch.float32, _lib.FLT32), (torch.float64, _lib.DBL64), (torch.int32, _lib.INT32), (torch.int64, _lib.INT64)):
     x = synth.features(n, h, dt, seed=0, device=dev)
     out = torch.empty((n, h), dtype=dt, device=dev)
-    for weighted, narrow in ((False, 1), (True, 1)) + (((True, 0),) if dt in (torch.float64, torch.int64) else ()) + (((True, 2),) if dt == torch.int32 else ()):
+    for weighted, narrow in ((False, 1), (True, 1)) + (((True, 0),) if dt in (torch.float64, torch.int64) else ()) + (((True, 2),) if dt in (torch.int32, torch.int64) else ()):
         _lib.set_tunable("narrow_vals", min(narrow, 1))   # (8-byte types: values that fit 4 bytes exactly are streamed as such)
         vals = None
         if weighted:
             vals = (torch.rand(nnz, device=dev) * 2 - 1).to(dt) if dt.is_floating_point else torch.randint(-3, 4, (nnz,), device=dev, dtype=dt)
-            if narrow == 2:   # INT32: values of any size (no inline constants: the value travels through an SGPR)
-                vals = torch.randint(-2**31, 2**31 - 1, (nnz,), device=dev, dtype=torch.int64).to(torch.int32)
+            if narrow == 2:   # values of any size (no inline constants: the value travels through an SGPR; INT64: both halves through a pair)
+                vals = torch.randint(-2**31, 2**31 - 1, (nnz,), device=dev, dtype=torch.int64).to(torch.int32) if dt == torch.int32 else \
+                    torch.randint(-2**62, 2**62, (nnz,), device=dev, dtype=torch.int64)
         hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None if vals is None else [vals.data_ptr()], [n], [n], [nnz], [1], [h], h)
         for _ in range(2): _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st)
         torch.cuda.synchronize()

@@ -75,17 +75,17 @@ int main(int argc, char **argv) {
             for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : (uint32_t)rng();
         }
         // valued DBL64 (round 5): the plan's value slot carries the entry index, the values travel beside it
-        const bool valued64 = wide && geo.col_splits == 1 && rng() % 2 == 0;   // DBL64: any bits; INT64: values that fit int32, small or any
+        const bool valued64 = wide && geo.col_splits == 1 && rng() % 2 == 0;   // DBL64: any bits; INT64: inline values, values that fit int32, or any 64 bits
         std::vector<uint64_t> vals64;
         std::vector<uint32_t> eidx;
         if (valued64) {
             vals64.resize(m.col.size());
             eidx.resize(m.col.size());
-            const bool small = rng() & 1;
+            const uint32_t cls = (uint32_t)(rng() % 3);   // INT64: every value inline / every value fits int32 / any 64 bits
             for (size_t i = 0; i < vals64.size(); i++) {
                 eidx[i] = (uint32_t)i;
                 if (op == LDS_CODE_ADD_F64) vals64[i] = rng();
-                else vals64[i] = (uint64_t)(int64_t)(small ? (int32_t)(rng() % 81) - 16 : (int32_t)rng());
+                else vals64[i] = cls == 2 ? (rng() % 4 ? rng() : (uint64_t)(int64_t)(int32_t)rng()) : (uint64_t)(int64_t)(cls == 0 ? (int32_t)(rng() % 81) - 16 : (int32_t)rng());
             }
         }
         // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)

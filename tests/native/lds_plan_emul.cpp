@@ -335,8 +335,14 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             if ((d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx() || !((vd - R.x0) & 1)) return 33;
                             const uint32_t base = (vd - R.x0) & ~1u;
                             XReg &xr = x[base];
-                            int32_t v;
-                            if (!operand(src0, &v)) return 46;
+                            int32_t v = 0;
+                            if (src0 != LDS_CODE_S_VAL + 1 && !operand(src0, &v)) return 46;
+                            if (src0 == LDS_CODE_S_VAL + 1) {                                 // full 64-bit values: v_mul_lo_u32 x_hi, s95, x_lo (x_lo * v_hi)
+                                if (!sval_hi_set || vs1 != vd - 1 || xr.mstage != 3) return 47;
+                                xr.mstage = 5;
+                                pc += 2;
+                                continue;
+                            }
                             bool infl = false;
                             for (uint32_t r : fifo) if (r == base) infl = true;
                             if (vs1 != vd || !xr.valid || infl || xr.has_mul || xr.mstage != 0) return 34;
@@ -352,11 +358,13 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             XReg &xr = x[vs1 - R.x0];
                             int32_t v;
                             if (!operand(src0, &v)) return 46;
-                            if (xr.mstage != 3 || v != xr.mval || xr.macc != vd) return 47;
+                            if ((xr.mstage != 3 && xr.mstage != 6) || v != xr.mval || xr.macc != vd) return 47;
+                            if ((xr.mstage == 6) != sval_hi_set) return 47;                    // (s95 is set exactly in the full form)
+                            xr.mulbits64 = xr.mstage == 6 ? (((uint64_t)sval_hi << 32) | (uint32_t)xr.mval) : (uint64_t)(int64_t)xr.mval;
                             xr.mstage = 0;
                             xr.has_mul = true;
-                            xr.mulbits64 = (uint64_t)(int64_t)xr.mval;
                             if (src0 == LDS_CODE_S_VAL) sval_set = false;
+                            sval_hi_set = false;
                             mad_vd = vd;
                             mad_vx = vs1;
                             mad_add = true;
@@ -375,7 +383,14 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                             const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, s0 = (i0 & 0x1FF) - 256;
                             if (vd != vs1 || vd < R.acc0 + 1 || vd >= R.acc0 + 2 * KA || !((vd - R.acc0) & 1) || s0 < R.x0 + 1 || s0 >= R.x0 + R.nx() || !((s0 - R.x0) & 1)) return 47;
                             XReg &xr = x[s0 - 1 - R.x0];
-                            if (xr.mstage != (xr.mval < 0 ? 2 : 1)) return 47;
+                            if (xr.mstage == 5) {                        // full 64-bit values: the second sum into the high half
+                                if (xr.macc != vd - 1) return 48;
+                                xr.mstage = 6;
+                                pc++;
+                                continue;
+                            }
+                            // (one-SGPR / inline form: a negative value passes through the v_sub_u32; the full form has no correction)
+                            if (xr.mstage != ((xr.mval < 0 && !sval_hi_set) ? 2 : 1)) return 47;
                             xr.mstage = 3;
                             xr.macc = vd - 1;
                             pc++;

@@ -104,11 +104,11 @@ int main(int argc, char **argv) {
                 const int rc = lds_code_f64_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], splits, q[2], q[3], rpt, bnd);
                 if (rc) { printf("case %d: interpreter code %d (f64 geo %u %u %u %u)\n", c, rc, q[0], q[1], q[2], q[3]); return 1; }
                 if (out != reference<double>(m, nrows, x, h, nullptr)) { printf("case %d: f64 result differs\n", c); return 2; }
-            } else if (splits == 1 && rng() % 2 == 0) {   // valued INT64 (round 5): values that fit int32, small (inline) or any (through s94)
+            } else if (splits == 1 && rng() % 2 == 0) {   // valued INT64 (round 5): inline values, values that fit int32 (through s94), any 64 bits (s[94:95])
                 std::vector<int64_t> x((size_t)ncols * h), out((size_t)nrows * h, 77), vals(m.col.size());
                 for (auto &v : x) v = (int64_t)rng();
-                const bool small = rng() & 1;
-                for (auto &v : vals) v = small ? (int64_t)(rng() % 81) - 16 : (int64_t)(int32_t)rng();
+                const uint32_t cls = (uint32_t)(rng() % 3);   // every value inline / every value fits int32 / any 64 bits (both halves through s[94:95])
+                for (auto &v : vals) v = cls == 0 ? (int64_t)(rng() % 81) - 16 : cls == 1 ? (int64_t)(int32_t)rng() : (rng() % 4 ? (int64_t)rng() : (int64_t)(int32_t)rng());
                 const int rc = lds_code_i64_val_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, q[0], q[1], vals.data(), q[2], q[3], rpt, bnd);
                 if (rc) { printf("case %d: interpreter code %d (valued i64 geo %u %u %u %u)\n", c, rc, q[0], q[1], q[2], q[3]); return 1; }
                 std::vector<int64_t> want((size_t)nrows * h, 0);

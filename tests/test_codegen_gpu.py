@@ -99,9 +99,9 @@ def test_valued_int32_entries(rng, checked, small):
 
 @pytest.mark.parametrize("small", [True, False])
 def test_valued_int64_entries(rng, checked, small):
-    """valued INT64 on the code stream (round 5) when every value fits 32 bits: the 64-bit product from 32-bit pieces (v_mul_lo_u32 on the high half,
-    a correction for negative values, v_mad_u64_u32 for product and sum of the low half), the value inline ([-16, 64]) or through an SGPR; wraps modulo 2^64 like the CPU loop.
-    Values that need more than 32 bits keep the sweep."""
+    """valued INT64 on the code stream (round 5): the 64-bit product from 32-bit pieces (v_mul_lo_u32 on the high half, a correction for negative
+    values, v_mad_u64_u32 for product and sum of the low half), the value inline ([-16, 64]) or through an SGPR; wraps modulo 2^64 like the CPU loop.
+    A matrix with a value beyond 32 bits takes the full form: both halves through s[94:95], x_lo * v_lo + 2^32 (x_hi * v_lo + x_lo * v_hi)."""
     rowptr, col = random_csr(rng, 2200, 1500, 16, long_rows=[(3, 2100)])
     x = feats(rng, 1500, 70, np.int64)
     vals = (rng.integers(-16, 65, size=len(col)) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64)).astype(np.int64)
@@ -109,9 +109,11 @@ def test_valued_int64_entries(rng, checked, small):
     assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
     wide = vals.copy()
-    wide[5] = 2**40 + 3                                     # one value beyond 32 bits: no code stream for this matrix
+    wide[5] = 2**40 + 3                                     # one value beyond 32 bits: the full form for this matrix
+    if not small:
+        wide[::3] = rng.integers(-2**63, 2**63 - 1, size=len(wide[::3]), dtype=np.int64)
     got, info, note = run(rowptr, col, x, vals=wide)
-    assert info["active"] == 0, (info, note)
+    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, wide, x).tobytes()
 
 

@@ -288,8 +288,8 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         try:
             # (round 4: unit-weight INT8 rides the INT16 code stream, its features widened to 16 bits in the staged copy)
             #  and unit-weight INT64 / DBL64 their own 8-byte code stream: rows of 512 bytes in LDS, a register pair per running sum)
-            #  (round 5: valued DBL64 too -- the value through an SGPR pair; valued INT8 / INT64 keep the sweep)
-            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32", "DBL64") or (dt in ("INT8", "INT64") and v is None)), dt
+            #  (round 5: valued DBL64 and valued INT64 of any size too -- the value through an SGPR pair; valued INT8 keeps the sweep)
+            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32", "DBL64", "INT64") or (dt == "INT8" and v is None)), dt
             out = np.full((n, h), 77, dtype=npdt)
             _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
         finally:
