@@ -217,6 +217,10 @@ int pygim_group_lds_code(int64_t handle, int64_t out[4]);
  * the propagation ended with, the rows of the largest one; and whether the L2 sweep's work items are in locality order (0 = by length alone,
  * 1 = blocks of consecutive rows: the stored ids are local, 2 = blocks of the propagated order; tunable "panel_locality") */
 int pygim_group_lds_tiles(int64_t handle, int64_t out[4]);
+/* how many products (or blocks of pygim_block_run) the LDS-staged kernels have served for this group since it was created: a plan existing
+ * (pygim_group_lds_plan) does not say that a given call took it -- widths, alignment and accumulation decide per call (the reference has one
+ * kernel per build, spmm_default/dpu_kernels/spmm_mul_csr_dpu.c, so nothing to ask there) */
+int pygim_group_lds_runs(int64_t handle, int64_t *out);
 /* geometry of that schedule, as the library planned it (callers price staged bytes from THIS, not from assumed constants):
  * waves per workgroup, accumulators (rows) per wave, columns per chunk (chunk bytes = 256 x this), chunk buffers of the LDS ring,
  * staged columns per group of reads and x-register sets of a code stream (0 0 for a token plan), stored entries served by another

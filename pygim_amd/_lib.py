@@ -19,7 +19,7 @@ EXPORTS = [
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
     "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry", "pygim_group_lds_note",
-    "pygim_group_lds_tiles",
+    "pygim_group_lds_tiles", "pygim_group_lds_runs",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -75,6 +75,7 @@ def lib():
         L.pygim_group_lds_geometry.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_note.argtypes = [c_i64, ctypes.c_char_p, c_i64]
         L.pygim_group_lds_tiles.argtypes = [c_i64, p_i64]
+        L.pygim_group_lds_runs.argtypes = [c_i64, p_i64]
         L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
@@ -211,6 +212,13 @@ def group_lds_tiles(handle):
     out = (ctypes.c_int64 * 4)()
     check(lib().pygim_group_lds_tiles(int(handle), out))
     return dict(zip(["similarity", "labels", "largest_label_rows", "sweep_locality"], [int(v) for v in out[:4]]))
+
+
+def group_lds_runs(handle):
+    """products (or blocks) the LDS-staged kernels served for this group so far"""
+    out = ctypes.c_int64(0)
+    check(lib().pygim_group_lds_runs(int(handle), ctypes.byref(out)))
+    return int(out.value)
 
 
 def group_lds_geometry(handle):

@@ -902,6 +902,13 @@ __global__ void k_narrow_vals(const T *__restrict__ vals, uint64_t n, typename N
     if (!same) atomicOr(flag, 1);
 }
 
+// wide[i] = vals[i] sign-extended to 32 bits (valued INT8 / INT16 on the code stream: the encoders read 4-byte value slots)
+template <typename T>
+__global__ void k_widen_vals(const T *__restrict__ vals, uint64_t n, uint32_t *__restrict__ wide) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wide[i] = (uint32_t)(int32_t)vals[i];
+}
+
 // One launch per column panel: the first coop_grid blocks take the panel's LONG items (one wave each,
 // dispatched first), the rest the ordinary items (one lane group each).
 template <typename T, int VEC, int LOG_LPR, int AMODE, int HAS_VALS, bool DEQ = false>

@@ -75,11 +75,9 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
         throw std::runtime_error("lds codegen: the geometry does not fit the register map");
     if (P.KA > 255) throw std::runtime_error("lds codegen: more than 255 accumulators per wave");
     P.opcode_add = opcode_add;
-    if (valued && opcode_add != 0x02000000u && opcode_add != 0x68000000u && opcode_add != LDS_CODE_ADD_F64 && opcode_add != LDS_CODE_ADD_U64)
-        throw std::runtime_error("lds codegen: valued entries of this element type");
     P.i64_full = (valued && opcode_add == LDS_CODE_ADD_U64 && i64_full) ? 1 : 0;
-    P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64) && int_inline && !P.i64_full) ? 1 : 0;
-    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (P.i64_full ? 12 : P.int_inline ? 6 : 8) : (opcode_add == 0x68000000u && !int_inline) ? 4 : 2;
+    P.int_inline = (valued && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_ADD_U64 || opcode_add == LDS_CODE_PK_ADD_U16) && int_inline && !P.i64_full) ? 1 : 0;
+    P.mulw = !valued ? 0 : opcode_add == LDS_CODE_ADD_F64 ? 6 : opcode_add == LDS_CODE_ADD_U64 ? (P.i64_full ? 12 : P.int_inline ? 6 : 8) : ((opcode_add == 0x68000000u || opcode_add == LDS_CODE_PK_ADD_U16) && !int_inline) ? 4 : 2;
     P.addw = (opcode_add == LDS_CODE_PK_ADD_U16 || opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) ? 2 : 1;
     if (valued && opcode_add == LDS_CODE_ADD_U64) P.addw = 0;   // (the 64-bit sum is the v_mad_u64_u32 of the multiply)
     P.pieces = (geo.KC * geo.row_bytes / 1024) / geo.NW;
@@ -541,6 +539,11 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
             w[6 * q + 3] = (uint32_t)(v >> 32);
             w[6 * q + 4] = 0xD2810000u | vx;
             w[6 * q + 5] = LDS_CODE_S_VAL | ((256 + vx) << 9);
+        } else if (P.opcode_add == LDS_CODE_PK_ADD_U16) {   // INT16 / INT8: v_pk_mul_lo_u16 x, V, x op_sel_hi:[0,1], V inline or through s94
+            uint32_t *m = w + P.mulw * q;
+            if (!P.int_inline) { *m++ = 0xBE8000FFu | (LDS_CODE_S_VAL << 16); *m++ = T.vals[i]; }
+            *m++ = 0xD3814000u | vx;
+            *m++ = 0x10000000u | ((256 + vx) << 9) | (P.int_inline ? lds_inline_int((int32_t)T.vals[i]) : LDS_CODE_S_VAL);
         } else if (P.opcode_add == 0x68000000u) {   // INT32: the value inline, or through an SGPR
             if (P.int_inline) {
                 w[2 * q] = 0xD2850000u | vx;
@@ -594,7 +597,7 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
     }
     const uint64_t nnz = rowptr[nrows];
     const CgParams P = cg_params(geo, opcode_add, vals != nullptr, nrows, ncols, gsize, nsets,
-                                 (vals != nullptr && !vals64 && opcode_add == 0x68000000u && lds_int_values_inline(vals, nnz)) ||
+                                 (vals != nullptr && !vals64 && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_PK_ADD_U16) && lds_int_values_inline(vals, nnz)) ||
                                      (vals64 && opcode_add == LDS_CODE_ADD_U64 && [&] {
                                          for (uint64_t i = 0; i < nnz; i++) { const int64_t v = (int64_t)vals64[i]; if (v < -16 || v > 64) return false; }
                                          return true; }()),

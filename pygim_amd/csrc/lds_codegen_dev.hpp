@@ -292,7 +292,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     const uint64_t nnz = h_rowptr[nrows];
     if (nnz == 0 || nnz >= (1ull << 31)) return "lds codegen: no entries, or 2^31 and more";
     bool int_inline = false;
-    if (d_vals && opcode_add == 0x68000000u) {   // valued INT32: inline constants when every value allows it (one pass over the values)
+    if (d_vals && (opcode_add == 0x68000000u || opcode_add == LDS_CODE_PK_ADD_U16)) {   // valued INT32 / INT16: inline constants when every value allows it (one pass over the values)
         uint32_t *d_flag = nullptr, h_flag = 1;
         if (hipMalloc((void **)&d_flag, 64) != hipSuccess) { (void)hipGetLastError(); return "lds codegen: out of device memory"; }
         (void)hipMemsetAsync(d_flag, 0, 64, st);

@@ -449,6 +449,7 @@ inline bool lds_int_values_inline(const uint32_t *vals, uint64_t n) {
     return true;
 }
 PYGIM_LDS_HD_INLINE uint32_t lds_inline_int(int32_t v) { return v >= 0 ? 128u + (uint32_t)v : 192u + (uint32_t)(-v); }   // VOP3 source field of an inline integer
+// INT16 / INT8 (round 5): the value sign-extended in the 4-byte slot; v_pk_mul_lo_u16 x, V, x op_sel_hi:[0,1] (both halves of x times V's low half), V inline or s94.
 // DBL64 (round 5): the plan's 4-byte value slot carries the ENTRY INDEX and vals64 the values; per entry s_mov_b32 s94, <low half>; s_mov_b32 s95,
 // <high half>; v_mul_f64 x, s[94:95], x (24 bytes), product and sum rounded separately.  (INT64, values that fit int32: v_mul_lo_u32 on the high half + v_mad_u64_u32 -- consume_oldest; wider values: the sweep.)
 inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, LdsCodeHost &out, unsigned threads = 0, uint32_t gsize = 0,
@@ -459,7 +460,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     const bool wide = RB == 512;
     if (RB != 256 && RB != 512) throw std::runtime_error("lds code: rows of 256 or 512 bytes");
     if (wide != (opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64)) throw std::runtime_error("lds code: 512-byte rows are the 8-byte element types'");
-    if (!plan.wts.empty() && (((opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) && !vals64) || opcode_add == LDS_CODE_PK_ADD_U16))
+    if (!plan.wts.empty() && (opcode_add == LDS_CODE_ADD_F64 || opcode_add == LDS_CODE_ADD_U64) && !vals64)
         throw std::runtime_error("lds code: valued entries of this element type");
     const LdsCodeRegs R = lds_code_regs(NW, gsize, nsets, wide);
     out.regs = R;
@@ -498,7 +499,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
     };
     const LdsCodeRegs Rr = R;
     // (padding tokens carry the value 0: inside the inline range)
-    bool int_inline = opcode_add == 0x68000000u && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
+    bool int_inline = (opcode_add == 0x68000000u || opcode_add == LDS_CODE_PK_ADD_U16) && !plan.wts.empty() && lds_int_values_inline(plan.wts.data(), plan.wts.size());
     bool i64_full = false;   // INT64: some value needs more than 32 bits -- both halves travel through s[94:95]
     if (opcode_add == LDS_CODE_ADD_U64 && !plan.wts.empty()) {   // INT64: inline when all values lie in [-16, 64], one SGPR when all fit int32
         int_inline = true;
@@ -614,6 +615,11 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), (uint32_t)v);
                     e.op(0xBE8000FFu | ((LDS_CODE_S_VAL + 1) << 16), (uint32_t)(v >> 32));
                     e.op(0xD2810000u | g.xr[q], LDS_CODE_S_VAL | ((256 + g.xr[q]) << 9));              // v_mul_f64 x[0:1], s[94:95], x[0:1]
+                }
+            } else if (valued && opcode_add == LDS_CODE_PK_ADD_U16) {   // INT16 (and INT8 on its widened features): both halves of x times the value's low half
+                for (size_t q = 0; q < g.k.size(); q++) {
+                    if (!int_inline) e.op(0xBE8000FFu | (LDS_CODE_S_VAL << 16), g.v[q]);                      // s_mov_b32 s94, <value, sign-extended>
+                    e.op(0xD3814000u | g.xr[q], 0x10000000u | ((256 + g.xr[q]) << 9) | (int_inline ? lds_inline_int((int32_t)g.v[q]) : LDS_CODE_S_VAL));   // v_pk_mul_lo_u16 x, V, x op_sel_hi:[0,1]
                 }
             } else if (valued && opcode_add == 0x68000000u) {   // INT32: x = val * x (wrapping), the value inline or through an SGPR
                 for (size_t q = 0; q < g.k.size(); q++) {

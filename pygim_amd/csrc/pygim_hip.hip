@@ -519,6 +519,13 @@ int pygim_group_lds_tiles(int64_t handle, int64_t out[4]) {
     return 0;
 }
 
+int pygim_group_lds_runs(int64_t handle, int64_t *out) {
+    Group *g = lookup(handle);
+    if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    *out = g->lds_runs;
+    return 0;
+}
+
 int pygim_group_lds_geometry(int64_t handle, int64_t out[8]) {
     Group *g = lookup(handle);
     if (!g) return fail(PYGIM_ERR_INVALID, "unknown group handle");

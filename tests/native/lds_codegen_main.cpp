@@ -67,12 +67,12 @@ int main(int argc, char **argv) {
         const bool wide = q[6] == 512;
         const uint32_t ops4[] = {0x02000000u, 0x68000000u, LDS_CODE_PK_ADD_U16};
         const uint32_t op = wide ? ((rng() & 1) ? LDS_CODE_ADD_F64 : LDS_CODE_ADD_U64) : ops4[rng() % 3];
-        const bool valued = !wide && (op == 0x02000000u || op == 0x68000000u) && geo.col_splits == 1 && rng() % 3 == 0;   // FLT32, INT32 (round 5)
+        const bool valued = !wide && geo.col_splits == 1 && rng() % 3 == 0;   // FLT32, INT32 (round 5), INT16 (round 5: v_pk_mul_lo_u16)
         std::vector<uint32_t> vals;
         if (valued) {
             vals.resize(m.col.size());
             const bool small = rng() & 1;   // (INT32: values that ride as inline constants, or any)
-            for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : (uint32_t)rng();
+            for (auto &v : vals) v = small ? (uint32_t)((int32_t)(rng() % 81) - 16) : op == LDS_CODE_PK_ADD_U16 ? (uint32_t)(int32_t)(int16_t)rng() : (uint32_t)rng();
         }
         // valued DBL64 (round 5): the plan's value slot carries the entry index, the values travel beside it
         const bool valued64 = wide && geo.col_splits == 1 && rng() % 2 == 0;   // DBL64: any bits; INT64: inline values, values that fit int32, or any 64 bits

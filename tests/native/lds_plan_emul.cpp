@@ -149,7 +149,10 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     }
     LdsGeometry geo;
     geo.col_splits = S;
-    constexpr bool WIDE = sizeof(T) == 8;   // INT64 / DBL64: 512-byte rows, ds_read_b64, register pairs (8 waves x 114 accumulators)
+    constexpr bool WIDE = sizeof(T) == 8;
+    constexpr bool PK16 = sizeof(T) == 2;      // INT16: two features to a lane (v_pk_add_u16 / v_pk_mul_lo_u16), 128 features to a 256-byte row
+    constexpr uint32_t F = PK16 ? 128 : 64;     // features of a slice
+    if (PK16 && nw != 8) return 12;   // INT64 / DBL64: 512-byte rows, ds_read_b64, register pairs (8 waves x 114 accumulators)
     if (WIDE && nw != 8) return 12;
     geo.NW = nw == 8 ? 8 : 16;          // round 4: 8 waves x 228 accumulators (2 waves per SIMD) beside 16 x 96
     geo.KA = nw == 8 ? (WIDE ? LDS_CODE8_KA64 : LDS_CODE8_KA) : 96;
@@ -165,18 +168,23 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
         eidx.resize(rowptr[nrows]);
         for (uint32_t i = 0; i < eidx.size(); i++) eidx[i] = i;
     }
-    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, WIDE ? (vals ? eidx.data() : nullptr) : reinterpret_cast<const uint32_t *>(vals));
+    std::vector<uint32_t> vals32;  // INT16 values: sign-extended to the plan's 4-byte value slot
+    if (PK16 && vals) {
+        vals32.resize(rowptr[nrows]);
+        for (uint32_t i = 0; i < vals32.size(); i++) vals32[i] = (uint32_t)(int32_t)vals[i];
+    }
+    lds_plan_build(rowptr, col, nrows, ncols, geo, plan, threads, WIDE ? (vals ? eidx.data() : nullptr) : PK16 ? (vals ? vals32.data() : nullptr) : reinterpret_cast<const uint32_t *>(vals));
     if (plan.header_overflow) return 13;
     nrows = S * nrows_real;   // rows of the (partial-sum) result the plan writes
     const uint32_t NBUF = geo.NBUF;
     const uint32_t opcode = std::is_same<T, float>::value ? 0x02000000u : std::is_same<T, double>::value ? LDS_CODE_ADD_F64 :
-                            std::is_same<T, int64_t>::value ? LDS_CODE_ADD_U64 : 0x68000000u;
+                            std::is_same<T, int64_t>::value ? LDS_CODE_ADD_U64 : PK16 ? LDS_CODE_PK_ADD_U16 : 0x68000000u;
     LdsCodeHost ch;
     lds_code_from_plan(plan, opcode, ch, threads, gsize, nsets, 0, (WIDE && vals) ? reinterpret_cast<const uint64_t *>(vals) : nullptr);
     const LdsCodeRegs R = ch.regs;
     if (R.nx() > 32 || NBUF > 16) return 14;
     const uint32_t NW = geo.NW, KA = geo.KA, KC = geo.KC, RB = geo.row_bytes, chunk_bytes = KC * RB, RPB = 65536 / RB;
-    const uint32_t nslices = (h + 63) / 64;
+    const uint32_t nslices = (h + F - 1) / F;
     if (stats) {
         stats[0] = plan.ntiles;
         stats[1] = ch.code.size() * 4;
@@ -187,11 +195,11 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
     std::vector<char> written((size_t)nrows, 0);
     for (uint32_t ti = 0; ti < plan.ntiles; ti++) {
         for (uint32_t s = 0; s < nslices; s++) {
-            const uint32_t wvalid = std::min(64u, h - s * 64);
+            const uint32_t wvalid = std::min(F, h - s * F);
             // LDS as the 16 waves of the workgroup see it: which chunk each buffer holds (the DMA of all waves lands the same chunk)
             uint64_t barriers_w0 = 0;
             for (uint32_t w = 0; w < NW; w++) {
-                std::vector<T> acc((size_t)KA * 64, T(0));
+                std::vector<T> acc((size_t)KA * F, T(0));
                 int64_t buf_chunk[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};      // what a buffer holds, as far as this wave may rely on it
                 int64_t landed_chunk[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // landed (waited for), visible to everybody after the next barrier
                 bool dirty[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false}; // a DMA into the buffer has been issued and not yet fenced (wait + barrier)
@@ -501,15 +509,16 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc += 2;
                         continue;
                     }
-                    if (vals && std::is_same<T, int32_t>::value && i0 == (0xBE8000FFu | (LDS_CODE_S_VAL << 16))) {   // s_mov_b32 s94, <literal value>
+                    if (vals && (std::is_same<T, int32_t>::value || PK16) && i0 == (0xBE8000FFu | (LDS_CODE_S_VAL << 16))) {   // s_mov_b32 s94, <literal value>
                         sval = ch.code[pc + 1];
                         sval_set = true;
                         pc += 2;
                         continue;
                     }
-                    if (vals && std::is_same<T, int32_t>::value && (i0 & 0xFFFFFF00u) == 0xD2850000u) {   // v_mul_lo_u32 x, <inline | s94>, x
+                    if (vals && ((std::is_same<T, int32_t>::value && (i0 & 0xFFFFFF00u) == 0xD2850000u) ||          // v_mul_lo_u32 x, <inline | s94>, x
+                                 (PK16 && (i0 & 0xFFFFFF00u) == 0xD3814000u))) {                               // v_pk_mul_lo_u16 x, <inline | s94>, x op_sel_hi:[0,1]
                         const uint32_t d1 = ch.code[pc + 1], vd = i0 & 0xFF, src0 = d1 & 0x1FF, vs1 = (d1 >> 9) & 0x1FF;
-                        if (vs1 != 256 + vd || (d1 >> 18) || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
+                        if (vs1 != 256 + vd || (d1 >> 18) != (PK16 ? 0x400u : 0u) || vd < R.x0 || vd >= R.x0 + R.nx()) return 33;
                         uint32_t value;
                         if (src0 == LDS_CODE_S_VAL) {
                             if (!sval_set) return 45;                                           // the SGPR was not loaded for this multiply
@@ -541,8 +550,16 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         pc += 2;
                         continue;
                     }
-                    if ((i0 & 0xFE000000u) == opcode) {                                         // v_add acc[k], x, acc[k]
-                        const uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, src0 = i0 & 0x1FF;
+                    if ((!PK16 && (i0 & 0xFE000000u) == opcode) || (PK16 && (i0 & 0xFFFFFF00u) == 0xD38A4000u)) {   // v_add acc[k], x, acc[k]  |  v_pk_add_u16 acc[k], x, acc[k]
+                        uint32_t vd = (i0 >> 17) & 0xFF, vs1 = (i0 >> 9) & 0xFF, src0 = i0 & 0x1FF;
+                        if (PK16) {
+                            const uint32_t d1 = ch.code[pc + 1];
+                            vd = i0 & 0xFF;
+                            vs1 = ((d1 >> 9) & 0x1FF) - 256;
+                            src0 = d1 & 0x1FF;
+                            if ((d1 >> 18) != 0x600u) return 30;          // op_sel_hi of both sources
+                            pc++;
+                        }
                         if (vd != vs1 || vd < R.acc0 || vd >= R.acc0 + KA || src0 < 256 + R.x0 || src0 >= 256 + R.x0 + R.nx()) return 30;
                         XReg &xr = x[src0 - 256 - R.x0];
                         // a pair's second register retires with the pair: find whether its instruction is still in the fifo
@@ -556,8 +573,8 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                         const uint32_t k = vd - R.acc0;
                         if ((vals != nullptr) != xr.has_mul) return 35;                         // every entry of a valued matrix is multiplied once
                         for (uint32_t l = 0; l < wvalid; l++) {
-                            T xv = xrow < ncols ? X[xrow * h + s * 64 + l] : T(0);
-                            T &a = acc[(size_t)k * 64 + l];
+                            T xv = xrow < ncols ? X[xrow * h + s * F + l] : T(0);
+                            T &a = acc[(size_t)k * F + l];
                             if constexpr (std::is_integral<T>::value) a = (T)((uint32_t)a + (xr.has_mul ? xr.mulbits * (uint32_t)xv : (uint32_t)xv));
                             else {
                                 if (xr.has_mul) {
@@ -582,7 +599,7 @@ static int run_code(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows,
                     if (row == 0xFFFFFFFFu) continue;
                     if (row >= nrows) return 7;
                     if (s == 0) written[row]++;
-                    for (uint32_t l = 0; l < wvalid; l++) C[(size_t)row * h + s * 64 + l] = acc[(size_t)k * 64 + l];
+                    for (uint32_t l = 0; l < wvalid; l++) C[(size_t)row * h + s * F + l] = acc[(size_t)k * F + l];
                 }
             }
         }
@@ -648,5 +665,11 @@ int lds_code_i32_val_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t n
 int lds_code_i32(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int32_t *X, uint32_t h, int32_t *C,
                  uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, uint32_t col_splits) {
     return run_code<int32_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, nullptr, col_splits);
+}
+// INT16 (two features to a lane), unit weights or valued (round 5: v_pk_mul_lo_u16 with the value inline or through s94); INT8 rides the same stream
+int lds_code_i16_geo(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, uint32_t ncols, const int16_t *X, uint32_t h, int16_t *C,
+                     uint32_t threads, uint64_t *stats, uint32_t kc, uint32_t nbuf, const int16_t *vals, uint32_t col_splits, uint32_t gsize,
+                     uint32_t nsets, uint32_t rows_per_tile, uint32_t boundary) {
+    return run_code<int16_t>(rowptr, col, nrows, ncols, X, h, C, threads, stats, kc, nbuf, vals, col_splits, 8, gsize, nsets, rows_per_tile, boundary);
 }
 }

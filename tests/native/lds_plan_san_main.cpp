@@ -143,6 +143,23 @@ int main(int argc, char **argv) {
             const int rc2 = lds_emul_f32(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out2.data(), g[0] == 8 ? 192 : 96, g[0] == 8 ? 16 : 8, 3, stats, g[0],
                                          valued ? vals.data() : nullptr, splits);
             if (rc2 || out2 != out) { printf("case %d: token walk code %d / differs\n", c, rc2); return 3; }
+        } else if (g[0] == 8 && rng() % 3 == 0) {   // INT16 (two features to a lane), unit weights or valued (round 5: v_pk_mul_lo_u16, the value inline or through s94)
+            std::vector<int16_t> x((size_t)ncols * h), out((size_t)nrows * h, 77), vals;
+            for (auto &v : x) v = (int16_t)rng();
+            const bool valued = splits == 1 && (rng() & 1);
+            if (valued) {
+                vals.resize(m.col.size());
+                const bool small = rng() & 1;
+                for (auto &v : vals) v = small ? (int16_t)((int32_t)(rng() % 81) - 16) : (int16_t)rng();
+            }
+            const int rc = lds_code_i16_geo(m.rowptr.data(), m.col.data(), nrows, ncols, x.data(), h, out.data(), 3, stats, g[1], g[2], valued ? vals.data() : nullptr, splits, g[3], g[4], rpt, bnd);
+            if (rc) { printf("case %d: interpreter code %d (i16 valued %d, geo %u %u %u %u %u)\n", c, rc, (int)valued, g[0], g[1], g[2], g[3], g[4]); return 1; }
+            std::vector<int16_t> want((size_t)nrows * h, 0);
+            for (uint32_t r = 0; r < nrows; r++)
+                for (uint32_t e = m.rowptr[r]; e < m.rowptr[r + 1]; e++)
+                    for (uint32_t f = 0; f < h; f++)
+                        want[(size_t)r * h + f] = (int16_t)((uint32_t)want[(size_t)r * h + f] + (valued ? (uint32_t)(int32_t)vals[e] : 1u) * (uint32_t)(int32_t)x[(size_t)m.col[e] * h + f]);
+            if (out != want) { printf("case %d: i16 result differs (valued %d)\n", c, (int)valued); return 2; }
         } else if (splits == 1 && rng() % 3 == 0) {   // valued INT32 (round 5): small values ride as inline constants, any others through an SGPR
             std::vector<int32_t> x((size_t)ncols * h), out((size_t)nrows * h, 77), vals(m.col.size());
             for (auto &v : x) v = (int32_t)rng();

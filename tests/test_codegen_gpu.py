@@ -59,6 +59,7 @@ def run(rowptr, col, x, vals=None, device=False):
         out = np.full((n, h), 77, dtype=x.dtype)
         xx = np.ascontiguousarray(x)
         _lib.spmm_run_group(hd, [xx.ctypes.data], out.ctypes.data)
+        info["runs"] = _lib.group_lds_runs(hd)   # (a plan existing does not say that this call took it)
     finally:
         _lib.group_free(hd)
     return out, info, note
@@ -71,7 +72,7 @@ def test_device_stream_equals_host_stream_every_type(rng, checked, dt):
         h = (h * max(1, 4 // np.dtype(dt).itemsize) + 1) // 2 * 2   # (narrow types: as many BYTES per row; INT16 rows hold whole lanes)
         x = feats(rng, ncols, h, dt)
         got, info, note = run(rowptr, col, x)
-        assert info["active"] == 1 and info["device_generated"] == 1 and note == "code-stream form", (info, note)
+        assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1 and note == "code-stream form", (info, note)
         assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (dt, n, ncols, h)
 
 
@@ -93,7 +94,7 @@ def test_valued_int32_entries(rng, checked, small):
     x = feats(rng, 1800, 96, np.int32)
     vals = rng.integers(-16, 65, size=len(col)).astype(np.int32) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64).astype(np.int32)
     got, info, note = run(rowptr, col, x, vals=vals)
-    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
 
 
@@ -106,15 +107,29 @@ def test_valued_int64_entries(rng, checked, small):
     x = feats(rng, 1500, 70, np.int64)
     vals = (rng.integers(-16, 65, size=len(col)) if small else rng.integers(-2**31, 2**31 - 1, size=len(col), dtype=np.int64)).astype(np.int64)
     got, info, note = run(rowptr, col, x, vals=vals)
-    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
     wide = vals.copy()
     wide[5] = 2**40 + 3                                     # one value beyond 32 bits: the full form for this matrix
     if not small:
         wide[::3] = rng.integers(-2**63, 2**63 - 1, size=len(wide[::3]), dtype=np.int64)
     got, info, note = run(rowptr, col, x, vals=wide)
-    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, wide, x).tobytes()
+
+
+@pytest.mark.parametrize("dt", [np.int16, np.int8])
+@pytest.mark.parametrize("small", [True, False])
+def test_valued_int16_int8_entries(rng, checked, dt, small):
+    """valued INT16 / INT8 on the code stream (round 5): v_pk_mul_lo_u16 x, V, x op_sel_hi:[0,1] -- both 16-bit features of a lane times the value, inline
+    ([-16, 64]) or through s94 -- then v_pk_add_u16; INT8 on its features widened to 16 bits (the store keeps the low byte).  Wraps like the CPU loop."""
+    info = np.iinfo(dt)
+    rowptr, col = random_csr(rng, 2200, 1500, 16, long_rows=[(3, 2100)])
+    x = feats(rng, 1500, 280, dt)
+    vals = (rng.integers(-16, 65, size=len(col)) if small else rng.integers(info.min, info.max, size=len(col), endpoint=True)).astype(dt)
+    got, inf, note = run(rowptr, col, x, vals=vals)
+    assert inf["active"] == 1 and inf["device_generated"] == 1 and inf["runs"] >= 1, (inf, note)
+    assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
 
 
 def test_valued_double_entries(rng, checked):
@@ -124,7 +139,7 @@ def test_valued_double_entries(rng, checked):
     x = feats(rng, 1500, 70, np.float64)
     vals = (rng.random(len(col)) * 2 - 1).astype(np.float64)
     got, info, note = run(rowptr, col, x, vals=vals)
-    assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+    assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1, (info, note)
     assert got.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes()
 
 
@@ -154,7 +169,7 @@ def test_column_split_tiles(rng, checked, splits):
             rowptr, col = random_csr(rng, n, ncols, float(rng.uniform(5, 40)), empty_frac=0.2, long_rows=[(3, 4000)])
             x = feats(rng, ncols, h, dt) if dt == np.int32 else rng.integers(-8, 4, size=(ncols, h)).astype(np.float32)   # (exact float sums: the ranges reorder them)
             got, info, note = run(rowptr, col, x)
-            assert info["active"] == 1 and info["device_generated"] == 1, (info, note)
+            assert info["active"] == 1 and info["device_generated"] == 1 and info["runs"] >= 1, (info, note)
             assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes(), (splits, dt)
     finally:
         _lib.set_tunable("lds_col_split", old[0])

@@ -288,8 +288,8 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         try:
             # (round 4: unit-weight INT8 rides the INT16 code stream, its features widened to 16 bits in the staged copy)
             #  and unit-weight INT64 / DBL64 their own 8-byte code stream: rows of 512 bytes in LDS, a register pair per running sum)
-            #  (round 5: valued DBL64 and valued INT64 of any size too -- the value through an SGPR pair; valued INT8 keeps the sweep)
-            assert (_lib.group_lds_plan(hd)["tiles"] > 0) == (dt in ("INT16", "INT32", "FLT32", "DBL64", "INT64") or (dt == "INT8" and v is None)), dt
+            #  (round 5: every valued type too -- INT32 / INT16 / INT8 v_mul_lo_u32 / v_pk_mul_lo_u16 with the value inline or in an SGPR, INT64 / DBL64 through an SGPR pair)
+            assert _lib.group_lds_plan(hd)["tiles"] > 0, dt
             out = np.full((n, h), 77, dtype=npdt)
             _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
         finally:
@@ -323,13 +323,14 @@ def test_int16_two_features_to_a_lane(rng, lds_forced):
         x = rng.integers(info.min, info.max, size=(ncols, h), endpoint=True).astype(np.int16)
         vals = rng.integers(info.min, info.max, size=len(col), endpoint=True).astype(np.int16)
         rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
-        for v, code in ((None, 1), (None, 0), (vals, 1)):   # unit weights: the code-stream form (v_pk_add_u16 in the stream) and the token kernel
+        # the code-stream form (v_pk_add_u16 in the stream; round 5: valued too -- v_pk_mul_lo_u16) and the token kernels (lds_code = 0)
+        for v, code in ((None, 1), (None, 0), (vals, 1), (vals, 0)):
             old_code = _lib.set_tunable("lds_code", code)
             hd = _lib.group_create(_lib.CSR, _lib.INT16, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data],
                                    [n], [ncols], [len(ci)], [1], [h], h)
             try:
                 assert _lib.group_lds_plan(hd)["tiles"] > 0
-                assert _lib.group_lds_code(hd)["active"] == (1 if (v is None and code) else 0)
+                assert _lib.group_lds_code(hd)["active"] == code
                 out = np.full((n, h), 77, dtype=np.int16)
                 _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
             finally:

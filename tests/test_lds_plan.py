@@ -360,3 +360,22 @@ def test_valued_int32_code_stream_in_the_interpreter(emul):
                                            out.ctypes.data_as(ctypes.c_void_p), 3, stats, kc, nbuf, vals.ctypes.data_as(ctypes.c_void_p), nw, gs, ns, 0, 1)
             assert rc == 0, rc
             assert out.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (small, nw)
+
+
+def test_int16_code_stream_unit_and_valued(emul):
+    """INT16 in the code-stream form (two features to a lane: v_pk_add_u16), unit weights and -- round 5 -- valued: v_pk_mul_lo_u16 x, V, x op_sel_hi:[0,1]
+    (both halves of x times the low half of V), V an inline constant for values in [-16, 64], else s_mov_b32 s94 + SGPR operand; interpreted on the CPU
+    against the oracle's wrapping loop"""
+    rng = np.random.default_rng(78)
+    nrows, ncols, h = 1400, 1000, 200
+    rowptr, col = random_csr(rng, nrows, ncols, avg_deg=15, long_rows=[(5, 2000)])
+    x = rng.integers(-2**15, 2**15 - 1, size=(ncols, h), dtype=np.int64).astype(np.int16)
+    rp, ci = np.ascontiguousarray(rowptr, np.uint32), np.ascontiguousarray(col, np.uint32)
+    for vals in (None, rng.integers(-16, 65, size=len(col)).astype(np.int16), rng.integers(-2**15, 2**15 - 1, size=len(col), dtype=np.int64).astype(np.int16)):
+        out = np.full((nrows, h), 77, dtype=np.int16)
+        stats = (ctypes.c_uint64 * 4)()
+        for kc, nbuf, gs, ns in ((128, 5, 10, 2), (192, 3, 6, 3)):
+            rc = emul.lds_code_i16_geo(rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p), nrows, ncols, x.ctypes.data_as(ctypes.c_void_p), h,
+                                       out.ctypes.data_as(ctypes.c_void_p), 3, stats, kc, nbuf, None if vals is None else vals.ctypes.data_as(ctypes.c_void_p), 1, gs, ns, 0, 1)
+            assert rc == 0, rc
+            assert out.tobytes() == oracle.spmm_csr(rowptr, col, vals, x).tobytes(), (vals is None, kc)
