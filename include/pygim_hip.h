@@ -245,12 +245,12 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
  * "lds_code_kc" (columns per chunk, 0 = by the ring), "lds_code_gsize" / "lds_code_nsets" (staged columns per group of LDS reads / x-register sets: the
  * reads run nsets - 1 groups ahead of the adds; 0 = default), "lds_codegen" (code streams: 1 = generated on the device from the resident CSR -- the default --, 0 = by
  * the host encoder, 2 = on the device and checked word for word against the host encoder), "lds_tile_order" (which rows share a tile: 0 = consecutive
- * rows, 1 = rows ordered by similarity, 2 = automatic: similarity for square parts of a million entries and more), "lds_lp_rounds", "lds_xcd_slices" (code-stream products: slices of X per XCD -- 0 = automatic (the default), 1 = an XCD streams one slice through
+ * rows, 1 = rows ordered by similarity, 2 = automatic: similarity for square parts of a million entries and more), "lds_lp_rounds", "lds_hybrid" (density split of a community-structured part whose ids carry no locality: the dense (tile, chunk) cells through the LDS-staged kernel, the rest through the sweep; 0 = off, 1 = integer types, 2 = floats too -- their sums are then reordered), "lds_hybrid_min" (entries a cell must hold), "lds_xcd_slices" (code-stream products: slices of X per XCD -- 0 = automatic (the default), 1 = an XCD streams one slice through
  * its L2; 2 / 4 = the workgroups an XCD runs side by side are slices of the same tile and share its code stream in L2), "lds_long_slots", "lds_ablate" (timing experiments, wrong results)};
  * returns the previous value, or -1 for an unknown name (pygim_last_error() says which).
  * READ AT GROUP CREATION (they shape the plan; changing them afterwards does not touch existing groups, and switching "lds_code" off
  * after a code-stream group was created sends that group's products to the sweep): panel_*, long_*, split_unit_pattern, narrow_vals,
- * merge_parts, lds_code, lds_codegen, lds_tile_order, lds_lp_rounds, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_code_boundary, lds_waves, lds_col_split,
+ * merge_parts, lds_code, lds_codegen, lds_tile_order, lds_lp_rounds, lds_hybrid, lds_hybrid_min, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_code_boundary, lds_waves, lds_col_split,
  * lds_col_split_f32, lds_round_tiles, lds_long_slots, lds_min_reuse_x100 and lds_mode (whether a plan is made at all), lds_threads.
  * The others are read per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);

@@ -944,7 +944,8 @@ __global__ __launch_bounds__(256) void k_csr_panel(const uint32_t *__restrict__ 
 // In the slice-major copy a panel of one slice is one contiguous range.
 template <typename T, int VEC, int LOG_LPR>
 __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrows, uint32_t w, uint32_t nslices,
-                             T *__restrict__ Xs, uint32_t slice_rows) {  // slice_rows >= nrows: rows between two slices of the copy
+                             T *__restrict__ Xs, uint32_t slice_rows,   // slice_rows >= nrows: rows between two slices of the copy
+                             const uint32_t *__restrict__ order = nullptr) {  // row j of the copy = X[order[j]] (lds_hybrid_dev.hpp), or X[j]
     constexpr int LPR = 1 << LOG_LPR;
     constexpr uint32_t F = LPR * VEC;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -956,13 +957,14 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
     const uint32_t f0 = sl * F + li * VEC;
     static_assert(VEC * sizeof(T) == 16, "16-byte pieces");
     T *dst = Xs + ((int64_t)sl * slice_rows + j) * F + li * VEC;
+    const int64_t src_row = order ? (int64_t)order[j] : (int64_t)j;
     if (f0 + VEC <= w) {  // X rows may sit at any byte alignment; the copy is 16-byte aligned
-        const u32x4_b q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_b *>(X + (int64_t)j * ldx + f0));
+        const u32x4_b q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_b *>(X + src_row * ldx + f0));
         *reinterpret_cast<u32x4_t *>(dst) = (u32x4_t)q;
     } else {
         T v[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? X[(int64_t)j * ldx + f0 + k] : T(0);
+        for (int k = 0; k < VEC; k++) v[k] = (f0 + k < w) ? X[src_row * ldx + f0 + k] : T(0);
         store_vec<T, VEC>(dst, v);
     }
 }

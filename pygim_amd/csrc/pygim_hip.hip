@@ -19,6 +19,7 @@
 #include "lds_kernel_gen.hpp"
 #include "lds_codegen_dev.hpp"
 #include "lds_reorder_dev.hpp"
+#include "lds_hybrid_dev.hpp"
 #endif
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -171,6 +172,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
     else if (n == "lds_fail") slot = &g_tune.lds_fail;
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
+    else if (n == "lds_hybrid") slot = &g_tune.lds_hybrid;
+    else if (n == "lds_hybrid_min") slot = &g_tune.lds_hybrid_min;
     else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
     else if (n == "lds_xcd_slices") slot = &g_tune.lds_xcd_slices;
     else if (n == "lds_codegen") slot = &g_tune.lds_codegen;
@@ -305,6 +308,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
         if (!g->all_ones && (rc = split_unit_pattern(p, dtype, es, g->d_flags + 4, (uint32_t *)(g->d_flags + 5), st))) return bail(rc);
         if ((rc = build_plans(p, es, g->d_flags + 4, st, g->h, /*allow_lds=*/!(g->merged && g_tune.merge_parts)))) return bail(rc);
         if (!(g->merged && g_tune.merge_parts) && (rc = narrow_values(p, dtype, g->d_flags + 6, st))) return bail(rc);
+        if (!(g->merged && g_tune.merge_parts) && (rc = build_hybrid(p, dtype, es, g->d_flags + 4, st, g->h))) return bail(rc);
     }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PYGIM_ERR_HIP, "sync after create"));
     g->timers[4] = now_ms() - t0;
@@ -557,6 +561,8 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap) {
         for (size_t i = 1; i < g->parts.size(); i++)
             if (g->parts[i].lds_note != g->parts[0].lds_note) text += "; part " + std::to_string(i) + ": " + g->parts[i].lds_note;
     }
+    for (size_t i = 0; i < g->parts.size(); i++)
+        if (!g->parts[i].hy_note.empty() && g->parts[i].hy_dense) text += "; part " + std::to_string(i) + ": " + g->parts[i].hy_note;
     const size_t n = std::min<size_t>(text.size(), (size_t)cap - 1);
     std::memcpy(out, text.data(), n);
     out[n] = 0;
