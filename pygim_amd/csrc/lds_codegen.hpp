@@ -157,7 +157,7 @@ inline void cg_deal_rows_b(const LdsGeometry &geo, const CgParams &P, CgRows &ou
     const uint32_t ntiles = P.ntiles;
     std::vector<uint32_t> ord(ntiles);
     for (uint32_t t = 0; t < ntiles; t++) ord[t] = t;
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tnnz[a] > out.tnnz[b]; });
+    if (!geo.keep_tile_order) std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tnnz[a] > out.tnnz[b]; });
     out.tile_pos.assign(ntiles, 0);
     for (uint32_t i = 0; i < ntiles; i++) out.tile_pos[ord[i]] = i;
     out.rowmap.assign((size_t)ntiles * RS, 0xFFFFFFFFu);

@@ -67,6 +67,7 @@ struct LdsGeometry {
     uint32_t KC = 320;    // columns per chunk: two chunks of 64-feature rows (2 x 80 KiB) fill the 160 KiB of a CU's LDS
     uint32_t BATCH = 16;  // tokens per batch (one scalar load)
     uint32_t rows_per_tile = 0;  // 0 = NW * KA; fewer rows per tile = more, lighter tiles (to fill whole rounds of workgroups)
+    uint32_t keep_tile_order = 0;   // 1 = tiles stay in the order of the rows (neighbouring tiles stage the same chunks: launch_lds gives an XCD a run of them); 0 = heaviest first
     uint32_t col_splits = 1;     // S > 1: every row tile becomes S workgroup tiles, each with 1/S of the chunk range; tile (t, c) writes its
                                  // partial sums to row r + c * nrows (the row map says so): the caller sums the S row blocks afterwards.
                                  // For row shares too short to fill the chip with whole-X workgroups (a rank's share on N GPUs)
@@ -298,7 +299,7 @@ inline void lds_plan_build(const uint32_t *rowptr, const uint32_t *col, uint32_t
     // heaviest tile first
     std::vector<uint32_t> ord(ntiles);
     for (uint32_t t = 0; t < ntiles; t++) ord[t] = t;
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tiles[a].nnz > out.tiles[b].nnz; });
+    if (!geo.keep_tile_order) std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return out.tiles[a].nnz > out.tiles[b].nnz; });
     std::vector<LdsTile> tiles2(ntiles);
     std::vector<uint32_t> rowmap2(out.rowmap.size());
     for (uint32_t i = 0; i < ntiles; i++) {

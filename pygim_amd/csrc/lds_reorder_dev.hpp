@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void k_lp_iter(const uint32_t *rowptr, const u
 // how good the labels are: the number of stored entries whose column carries its row's label (of nnz: ~p_in for a planted partition, ~0
 // for labels that mean nothing)
 __global__ __launch_bounds__(256) void k_lp_agree(const uint32_t *rowptr, const uint32_t *col, uint32_t nrows, const uint32_t *lab, unsigned long long *acc) {
-    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // a wave walks rows wave, wave + (waves of the grid), ...: ONE atomic per wave at the end (one per row on a single address cost 29 ms for 2.4 M rows)
     unsigned long long same = 0;
-    if (row < nrows) {
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += (uint64_t)gridDim.x * 4) {
         const uint32_t mine = lab[row], e1 = rowptr[row + 1];
         for (uint32_t e = rowptr[row] + (threadIdx.x & 63); e < e1; e += 64) same += lab[col[e]] == mine ? 1u : 0u;
     }
@@ -147,7 +147,7 @@ inline std::string lds_similarity_order(const uint32_t *d_rowptr, const uint32_t
     unsigned long long h_agree = 0;
     if (agree) {   // (keys_b is free until the sort: its first word takes the count)
         (void)hipMemsetAsync(keys_b, 0, 8, st);
-        hipLaunchKernelGGL(k_lp_agree, dim3(rb), dim3(256), 0, st, d_rowptr, d_col, nrows, (const uint32_t *)lab_a, (unsigned long long *)keys_b);
+        hipLaunchKernelGGL(k_lp_agree, dim3(std::min<unsigned>(rb, 4096u)), dim3(256), 0, st, d_rowptr, d_col, nrows, (const uint32_t *)lab_a, (unsigned long long *)keys_b);
         (void)hipMemcpyAsync(&h_agree, keys_b, 8, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         *agree = h_agree;

@@ -174,6 +174,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
     else if (n == "lds_hybrid") slot = &g_tune.lds_hybrid;
     else if (n == "lds_hybrid_min") slot = &g_tune.lds_hybrid_min;
+    else if (n == "lds_hybrid_contig") slot = &g_tune.lds_hybrid_contig;
     else if (n == "lds_code_boundary") slot = &g_tune.lds_code_boundary;
     else if (n == "lds_xcd_slices") slot = &g_tune.lds_xcd_slices;
     else if (n == "lds_codegen") slot = &g_tune.lds_codegen;

@@ -568,6 +568,8 @@ struct LdsArgs {
     uint32_t piece_bytes;              // code-stream kernels: bytes of a chunk that one wave DMAs (chunk bytes / 16: the plan's ring geometry)
     uint32_t xcd_sx;                   // slices per XCD (round 5): 1 = an XCD streams ONE slice of X (X shared in its L2, a tile's code fetched by every
                                        // slice's XCDs); 2 / 4 = consecutive workgroups of an XCD are slices of the SAME tile and share its code in L2
+    uint32_t xcd_contig;               // 0 = an XCD takes every xcd_group-th tile; T > 0 = a contiguous run of T tiles (plans whose neighbouring tiles stage the
+                                       // same chunks -- the dense half of a density split: they then meet in that XCD's L2)
 };
 """
 
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(%(threads)d) void %(name)s(LdsArgs a) {
                         // xcd_sx > 1 workgroups i, i + 1 (.. i + 3) of an XCD are the slices of ONE tile: the same code stream, in step
         const uint32_t xcd = b & 7, i = b >> 3, sx = a.xcd_sx ? a.xcd_sx : 1u;
         slice = (xcd / a.xcd_group) * sx + i %% sx;
-        ti = (xcd %% a.xcd_group) + a.xcd_group * (i / sx);
+        ti = a.xcd_contig ? (xcd %% a.xcd_group) * a.xcd_contig + i / sx : (xcd %% a.xcd_group) + a.xcd_group * (i / sx);
     } else {
         slice = b %% a.nslices;
         ti = b / a.nslices;
