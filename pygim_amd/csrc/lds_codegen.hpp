@@ -131,8 +131,9 @@ inline void cg_deal_rows_a(const uint32_t *rowptr, const LdsGeometry &geo, const
     out.rowinfo.assign(nrows, 0);
     out.rowmap_rt.assign((size_t)nrt * RS, 0xFFFFFFFFu);
     out.tnnz.assign((size_t)nrt * P.S, 0);
-    std::vector<uint32_t> order;
-    for (uint32_t rt = 0; rt < nrt; rt++) {
+    // (the row tiles are independent: host threads -- 2.4 M rows of a products-shaped part took 177 ms on one)
+    lds_parallel_for(nrt, 0, [&](uint32_t rt) {
+        std::vector<uint32_t> order;
         const uint32_t r0 = rt * R, r1 = std::min(nrows, r0 + R), nr = r1 - r0;
         if (P.S == 1) {
             if (!rorder) out.tnnz[rt] = rowptr[r1] - rowptr[r0];
@@ -148,7 +149,7 @@ inline void cg_deal_rows_a(const uint32_t *rowptr, const LdsGeometry &geo, const
             out.rowinfo[rid(r0 + order[i])] = ((rt * NW + w) << 8) | round;
             out.rowmap_rt[((size_t)rt * NW + w) * KAS + round] = rid(r0 + order[i]);
         }
-    }
+    });
 }
 // phase b (the tiles' entry counts known -- S > 1: counted on the device): launch order (heaviest first, stable), row map, tile table
 inline void cg_deal_rows_b(const LdsGeometry &geo, const CgParams &P, CgRows &out) {
