@@ -130,3 +130,25 @@ def test_calls_the_lds_kernel_does_not_take_keep_the_parts_own_plan(split_forced
     assert np.array_equal(got[:, :8], full[:, :8])
     assert np.array_equal(got[:, 64:256], full[:, 64:256] + 3)
     assert np.all(got[:, 8:64] == 3)
+
+
+def test_split_under_feature_windows(split_forced):
+    """ds_parts = 2 (dense_split, backend_pim/spmm.py:9-13): the group runs one block product per feature window; each takes the split"""
+    dev = torch.device("cuda", 0)
+    rowptr, col = _graph(dev, seed=15)
+    n = rowptr.numel() - 1
+    x = synth.features(n, 256, torch.int32, seed=9, device=dev)
+    xa, xb = x[:, :128].contiguous(), x[:, 128:].contiguous()
+    _lib.set_tunable("lds_hybrid", 1)
+    hd = _lib.group_create(_lib.CSR, _lib.INT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [col.numel()], [2], [128, 128], 256)
+    try:
+        assert "density split" in _lib.group_lds_note(hd)
+        out = torch.full((n, 256), 9, dtype=torch.int32, device=dev)
+        _lib.spmm_run_group(hd, [xa.data_ptr(), xb.data_ptr()], out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        runs = _lib.group_lds_runs(hd)
+    finally:
+        _lib.group_free(hd)
+    want = oracle.spmm_csr(rowptr.cpu().numpy(), col.cpu().numpy(), None, x.cpu().numpy())
+    assert runs >= 1
+    assert out.cpu().numpy().tobytes() == want.tobytes()
