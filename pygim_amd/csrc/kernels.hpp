@@ -973,7 +973,7 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
 // 256 bytes, as for INT16 -- so that the stream's packed 16-bit adds carry them; the low byte of every 16-bit sum is the int8 sum.
 // One thread: 8 features (8 bytes in, 16 bytes out).
 __global__ void k_slice_pack_widen8(const int8_t *__restrict__ X, int64_t ldx, uint32_t nrows, uint32_t w, uint32_t nslices,
-                                    int16_t *__restrict__ Xs, uint32_t slice_rows) {
+                                    int16_t *__restrict__ Xs, uint32_t slice_rows, const uint32_t *__restrict__ order = nullptr) {   // (order: as k_slice_pack)
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t per_row = (uint64_t)nslices * 16;
     const uint64_t j = t / per_row;
@@ -982,8 +982,9 @@ __global__ void k_slice_pack_widen8(const int8_t *__restrict__ X, int64_t ldx, u
     const uint32_t sl = rem >> 4, li = rem & 15;
     const uint32_t f0 = sl * 128 + li * 8;
     int16_t v[8];
+    const int64_t src_row = order ? (int64_t)order[j] : (int64_t)j;
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = (f0 + k < w) ? (int16_t)X[(int64_t)j * ldx + f0 + k] : (int16_t)0;
+    for (int k = 0; k < 8; k++) v[k] = (f0 + k < w) ? (int16_t)X[src_row * ldx + f0 + k] : (int16_t)0;
     store_vec<int16_t, 8>(Xs + ((int64_t)sl * slice_rows + j) * 128 + li * 8, v);
 }
 

@@ -21,8 +21,8 @@ args = ap.parse_args()
 dev = torch.device("cuda", 0)
 _lib.init_ranks(1)
 n, nnz, dmax = synth.SHAPES[args.shape]
-dt = {"f32": torch.float32, "i32": torch.int32, "i16": torch.int16}[args.dtype]
-code = {torch.float32: _lib.FLT32, torch.int32: _lib.INT32, torch.int16: _lib.INT16}[dt]
+dt = {"f32": torch.float32, "i32": torch.int32, "i16": torch.int16, "i8": torch.int8}[args.dtype]
+code = {torch.float32: _lib.FLT32, torch.int32: _lib.INT32, torch.int16: _lib.INT16, torch.int8: _lib.INT8}[dt]
 x = synth.features(n, args.h, dt, seed=0, device=dev)
 print(f"# {args.shape}-shaped (N = {n}, nnz = {nnz}), {args.dtype} h = {args.h}; ids shuffled", flush=True)
 for kind in args.kinds.split(","):
