@@ -27,6 +27,11 @@ x = synth.features(n, args.h, dt, seed=0, device=dev)
 print(f"# {args.shape}-shaped (N = {n}, nnz = {nnz}), {args.dtype} h = {args.h}; ids shuffled", flush=True)
 for kind in args.kinds.split(","):
     rowptr, col = synth.make_shape(args.shape, seed=0, device=dev, kind=None if kind == "uniform" else kind)
+    fmt, idx0, vals, nnz_g = _lib.CSR, rowptr, None, nnz
+    if args.format == "COO":   # as the reference builds it: coalesce() -- duplicates become weights > 1 (backend_pim/spmm.py:40-42)
+        r_, col, vals = synth.csr_to_coo_coalesced(rowptr, col, dt)
+        fmt, idx0, nnz_g = _lib.COO, r_, int(col.numel())
+        print(f"  (COO, coalesced: {nnz_g} entries, {int((vals != 1).sum())} of them with a weight other than 1)", flush=True)
     ref = None
     for hy, mc in [(0, 0)] + [(2 if dt.is_floating_point else 1, int(v)) for v in args.min.split(",")]:
         _lib.set_tunable("lds_hybrid", hy)
@@ -34,7 +39,7 @@ for kind in args.kinds.split(","):
             _lib.set_tunable("lds_hybrid_min", mc)
         torch.cuda.synchronize()
         t0 = time.time()
-        hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [args.h], args.h)
+        hd = _lib.group_create(fmt, code, [idx0.data_ptr()], [col.data_ptr()], None if vals is None else [vals.data_ptr()], [n], [n], [nnz_g], [1], [args.h], args.h)
         torch.cuda.synchronize()
         t_create = (time.time() - t0) * 1e3
         out = torch.full((n, args.h), 77, dtype=dt, device=dev)
