@@ -62,6 +62,7 @@ int main(int argc, char **argv) {
         LdsGeometry geo;
         geo.NW = q[0]; geo.KA = q[1]; geo.KC = q[2]; geo.NBUF = q[3]; geo.row_bytes = q[6]; geo.BATCH = 8;
         geo.boundary = 1;
+        geo.keep_tile_order = (rng() % 4 == 0) ? 1 : 0;   // tiles in row order (the dense half of a density split) instead of heaviest first
         geo.rows_per_tile = (rng() % 4 == 0) ? 16 + (uint32_t)(rng() % 1500) : 0;
         geo.col_splits = (rng() % 4 == 0) ? 2 + (uint32_t)(rng() % 7) : 1;   // tiles split into column ranges (short row shares on N GPUs)
         const bool wide = q[6] == 512;
