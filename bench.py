@@ -688,14 +688,16 @@ def main():
         # kernel as a whole, so the part is split by density (csrc/lds_hybrid_dev.hpp) -- the cells inside communities through the LDS-staged kernel
         # over X staged in the propagation's order, the rest added by the sweep; lds_hybrid = 0 beside it is the part's own plan
         if args.shape == "reddit":
+            hy_prev = None
             try:
                 n3, nnz3, _ = synth.SHAPES["ogbn-products"]
                 rp3, col3 = synth.make_shape("ogbn-products", seed=0, device=dev, kind="sbm")
                 x3 = synth.features(n3, h, torch.int32, seed=0, device=dev)
                 out3 = torch.empty((n3, h), dtype=torch.int32, device=dev)
-                ref3, info3 = None, {}
+                ref3, info3, hy_prev = None, {}, None
                 for hy in (0, 1):
-                    _lib.set_tunable("lds_hybrid", hy)
+                    prev = _lib.set_tunable("lds_hybrid", hy)
+                    hy_prev = prev if hy_prev is None else hy_prev
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     hd3 = _lib.group_create(_lib.CSR, _lib.INT32, [rp3.data_ptr()], [col3.data_ptr()], None, [n3], [n3], [nnz3], [1], [h], h)
@@ -721,13 +723,14 @@ def main():
                     else:
                         info3[key]["check"] = "equal to the part's own plan, element by element" if torch.equal(out3, ref3) else "MISMATCH"
                     _lib.group_free(hd3)
-                _lib.set_tunable("lds_hybrid", 1)
+                _lib.set_tunable("lds_hybrid", hy_prev)
                 info3["note"] = ("products-shaped stochastic block model (N = 2 449 029, nnz = 123 718 280, 1 200 communities, 80 % of a row's entries inside its own), ids "
                                  f"shuffled, INT32 h = {h}; 6 steps, median, outside the timed region")
                 result["extra"]["products_sbm_shuffled_ids"] = info3
                 del rp3, col3, x3, out3, ref3
             except Exception as e:  # noqa: BLE001
-                _lib.set_tunable("lds_hybrid", 1)
+                if hy_prev is not None:
+                    _lib.set_tunable("lds_hybrid", hy_prev)
                 result["extra"]["products_sbm_shuffled_ids"] = {"error": str(e)[:160]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, cpu_out = cpu_baseline(rowptr, col, x, args)

@@ -79,6 +79,10 @@ int pygim_release(void);
 /* number of pygim_release calls so far: a handle made under an earlier generation is dead (every group was freed),
  * even when the allocator hands the same address out again -- wrappers that cache a handle compare this. */
 int64_t pygim_generation(void);
+/* creation serial of a live group (1, 2, 3 ... over the life of the process, never reused): a handle is an address, and the allocator may hand
+ * a freed group's address to the next one -- a wrapper that frees what it created (the reference's spmm_free_group,
+ * spmm_default/pytorch_api.cpp:198-201, is the caller's to call) remembers the serial and frees only while it still matches. */
+int pygim_group_serial(int64_t handle, int64_t *out);
 int pygim_is_initialized(void);
 const char *pygim_last_error(void);
 /* name / CU count / bytes of HBM of the device in use */

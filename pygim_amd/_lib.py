@@ -19,7 +19,7 @@ EXPORTS = [
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
     "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry", "pygim_group_lds_note",
-    "pygim_group_lds_tiles", "pygim_group_lds_runs",
+    "pygim_group_lds_tiles", "pygim_group_lds_runs", "pygim_group_serial",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -59,6 +59,7 @@ def lib():
         L.pygim_group_create.argtypes = [c_int, c_int, c_int, vp, vp, vp, p_i64, p_i64, p_i64, p_i64, p_i64, c_i64,
                                          p_i64]
         L.pygim_group_free.argtypes = [c_i64]
+        L.pygim_group_serial.argtypes = [c_i64, p_i64]
         L.pygim_spmm_run_group.argtypes = [c_i64, vp, vp, vp]
         L.pygim_spmm_run_group_x.argtypes = [c_i64, vp, vp, c_int, vp]
         L.pygim_grande_run_group.argtypes = [c_i64, vp, p_i64, vp, vp]
@@ -237,6 +238,13 @@ def group_lds_note(handle):
 def generation():
     """count of pygim_release calls: handles of an earlier generation are dead"""
     return int(lib().pygim_generation())
+
+
+def group_serial(handle):
+    """creation serial of a live group (never reused, unlike the address that is the handle); PygimError for a dead handle"""
+    out = ctypes.c_int64(0)
+    check(lib().pygim_group_serial(int(handle), ctypes.byref(out)))
+    return int(out.value)
 
 
 def group_info(handle):

@@ -56,6 +56,7 @@ class SparseGroupBase:
         self.raw = coo
         self.dtype = dtype
         self.format = format
+        self._handle = None  # (handle, generation) of the device group this object owns
         self.sp_info_ptr = None
         self.result = None
         self.parts = [self.raw]
@@ -63,6 +64,48 @@ class SparseGroupBase:
         self.dense_parts = 0
         self.hidden_size = 0
         self.nparts = 1
+
+    # -- the device group's lifetime ----------------------------------------------
+    # The reference leaves spmm_free_group (spmm_default/pytorch_api.cpp:198-201) to the caller and its wrappers never call
+    # it: a DPU group is a few arrays.  Here a group owns its CSR, its plans and -- for the LDS-staged product -- up to a GB of
+    # executable code, so the wrapper frees what it created: when the handle is replaced (to_pim_group again) and when the
+    # object dies.  A handle is an address: after dpu_release (every group freed) or a spmm_free_group by the caller it may
+    # belong to a later group, so the wrapper remembers the group's creation serial (pygim_group_serial, never reused) and
+    # frees only while the handle still names THAT group.
+    @property
+    def sp_info_ptr(self):
+        return self._handle[0] if self._handle is not None else None
+
+    @sp_info_ptr.setter
+    def sp_info_ptr(self, handle):
+        self.free_group()
+        if handle is not None:
+            from .. import _lib
+
+            try:
+                self._handle = (int(handle), _lib.group_serial(handle))
+            except _lib.PygimError:   # not a group of this library (another pim_ops backend registered under the same names): not ours to free
+                self._handle = (int(handle), None)
+
+    def free_group(self):
+        """spmm_free_group on the group this object created, if it is still alive."""
+        from .. import _lib
+
+        held, self._handle = getattr(self, "_handle", None), None
+        if held is None or held[1] is None or not _lib.is_initialized():
+            return
+        try:
+            alive = _lib.group_serial(held[0]) == held[1]
+        except _lib.PygimError:  # freed by the caller or by dpu_release
+            alive = False
+        if alive:
+            torch.ops.pim_ops.spmm_free_group(held[0])
+
+    def __del__(self):
+        try:
+            self.free_group()
+        except Exception:  # interpreter shutdown: torch.ops or the library may be gone already
+            pass
 
     # -- partitioning -----------------------------------------------------------
     def col_split(self, nparts=4):

@@ -37,6 +37,7 @@ class SparseTensorCOO(SparseGroupBase):
         self.dpus_per_rank = dpus_per_rank
 
     def to_pim_group_csr(self, hidden_size, B_parts=4):
+        self.free_group()  # (a group made earlier goes before its replacement is built, not after)
         self.format = "CSR"
         self.hidden_size = hidden_size
         if len(self.csr) != len(self.parts):

@@ -21,6 +21,7 @@ def dense_split(B, nparts, dim=1):
 
 class SparseTensorCOO(SparseGroupBase):
     def _register(self, hidden_size, B_parts, fmt):
+        self.free_group()  # (a group made earlier goes before its replacement is built, not after)
         self.format = fmt
         self.hidden_size = hidden_size
         self.dense_parts = B_parts

@@ -36,6 +36,7 @@ class SparseTensorCOO(SparseGroupBase):
             self._drop_wide()
         except Exception:  # interpreter shutdown: the library may be gone already
             pass
+        super().__del__()
 
     def build_coo(self):
         quantum = 64 // torch.iinfo(self.dtype).bits
@@ -47,6 +48,7 @@ class SparseTensorCOO(SparseGroupBase):
     def to_pim_group_coo(self, hidden_size, rank_pre_spmv=1):
         B_parts = hidden_size
         self._drop_wide()
+        self.free_group()
         self.format = "COO"
         self.hidden_size = hidden_size
         self.dense_parts = B_parts

@@ -283,6 +283,8 @@ struct CgDeviceResult {
 // alloc_exec(bytes) returns executable device memory or nullptr; free_exec(ptr) releases it.  Returns "" on success, else why not
 // (nothing is left allocated then).  h_rowptr: the row pointers on the host (the caller has them); h_rorder: the tile order of the rows
 // (similarity tiles, lds_reorder_dev.hpp) or nullptr for consecutive rows.
+static bool g_cg_fail_big_alloc = false;   // lds_fail bit 8 (rt_plans.inc)
+
 inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_col, const uint32_t *d_vals, const uint64_t *d_vals64, const uint32_t *h_rowptr,
                                     const uint32_t *h_rorder,
                                     uint32_t nrows, uint32_t ncols,
@@ -319,7 +321,8 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     bool failed = false;
     auto dalloc = [&](size_t bytes) -> void * {
         void *p = nullptr;
-        if (failed || hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) {
+        // (g_cg_fail_big_alloc: tests -- the first transient of 1 MiB and more "runs out of device memory", as the sort keys of a large graph may)
+        if (failed || (g_cg_fail_big_alloc && bytes >= (1u << 20)) || hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) {
             (void)hipGetLastError();
             failed = true;
             return nullptr;

@@ -241,8 +241,9 @@ at::Tensor spmv_coo_run_group(int64_t handle, std::vector<at::Tensor> B_parts) {
 #endif
 #endif
 
-#if PYGIM_VARIANT == 0
-// ---- MatrixMarket debug ops (spmm_default/utils.hpp:139-173) ------------------------------------
+#if PYGIM_VARIANT != 2
+// ---- MatrixMarket debug ops (spmm_default/utils.hpp:139-173; the grande library registers the same five from its own copy of
+// that header, spmm_grande/pytorch_api.cpp:338-342) -----------------------------------------------
 // Same result as the reference reader + coo2csr (utils.hpp:15-127): '%' lines skipped, the size line
 // gives rows / columns / entries, both dimensions padded to even, indices 1-based in the file, the
 // value column ignored (every stored value is 1), entries of a row kept in file order.
@@ -320,11 +321,11 @@ TORCH_LIBRARY(pim_ops, m) {
 #if PYGIM_VARIANT == 0
     m.def("spmm_coo_to_device_group", &spmm_coo_to_device_group);
     m.def("spmm_coo_run_group", &spmm_coo_run_group);
+#endif
     m.def("read_matrix_rowptr", &read_matrix_rowptr);
     m.def("read_matrix_colind", &read_matrix_colind);
     m.def("read_matrix_values", &read_matrix_values);
     m.def("read_matrix_nrows", &read_matrix_nrows);
     m.def("read_matrix_ncols", &read_matrix_ncols);
-#endif
 #endif
 }

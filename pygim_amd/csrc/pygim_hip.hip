@@ -315,6 +315,7 @@ int pygim_group_create(int format, int dtype, int n_parts, const int32_t *const 
     g->timers[4] = now_ms() - t0;
     {
         std::lock_guard<std::mutex> lk(g_ctx.mu);
+        g->serial = ++g_ctx.group_serial;
         g_ctx.groups.insert(g);
     }
     *out_handle = (int64_t) reinterpret_cast<uintptr_t>(g);
@@ -524,6 +525,13 @@ int pygim_group_lds_tiles(int64_t handle, int64_t out[4]) {
     return 0;
 }
 
+int pygim_group_serial(int64_t handle, int64_t *out) {
+    Group *g = lookup(handle);
+    if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    *out = g->serial;
+    return 0;
+}
+
 int pygim_group_lds_runs(int64_t handle, int64_t *out) {
     Group *g = lookup(handle);
     if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
@@ -563,7 +571,7 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap) {
             if (g->parts[i].lds_note != g->parts[0].lds_note) text += "; part " + std::to_string(i) + ": " + g->parts[i].lds_note;
     }
     for (size_t i = 0; i < g->parts.size(); i++)
-        if (!g->parts[i].hy_note.empty() && g->parts[i].hy_dense) text += "; part " + std::to_string(i) + ": " + g->parts[i].hy_note;
+        if (!g->parts[i].hy_note.empty()) text += "; part " + std::to_string(i) + ": " + g->parts[i].hy_note;   // (a split that was tried and dropped says why)
     const size_t n = std::min<size_t>(text.size(), (size_t)cap - 1);
     std::memcpy(out, text.data(), n);
     out[n] = 0;

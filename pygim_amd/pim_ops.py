@@ -306,6 +306,12 @@ _SCHEMAS = {
         ("spmm_csr_to_device_group(Tensor[] row_indices, Tensor[] col_indices, Tensor[] values, int[] nrows, "
          "int[] ncols, Tensor[] dense_cols, int h_size) -> int", _grande_csr_to_device_group),
         ("spmm_csr_run_group(int sp_group_ptr, Tensor[] B_parts) -> Tensor", _grande_run_group),
+        # (the grande library registers the .mtx debug ops too: spmm_grande/pytorch_api.cpp:338-342, the same utils.hpp)
+        ("read_matrix_rowptr(str filename) -> Tensor", _read_matrix_rowptr),
+        ("read_matrix_colind(str filename) -> Tensor", _read_matrix_colind),
+        ("read_matrix_values(str filename) -> Tensor", _read_matrix_values),
+        ("read_matrix_nrows(str filename) -> int", _read_matrix_nrows),
+        ("read_matrix_ncols(str filename) -> int", _read_matrix_ncols),
     ],
     "spmv": [
         ("dpu_init_ranks(int nr_ranks) -> ()", _dpu_init_ranks_void),

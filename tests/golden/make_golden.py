@@ -19,7 +19,7 @@ Sources of truth, in order:
                         97-118) on the reference's own structs (oracle/ref_host_glue.inc).
 Inputs follow the reference driver: graph shapes of SURVEY.md section 8c, features
 torch.randint(-8, 4) under torch.manual_seed (spmm_test.py:70).
-Usage: python tests/golden/make_golden.py
+Usage: python tests/golden/make_golden.py [quant]
 """
 import os
 import sys
@@ -107,6 +107,56 @@ def reference_pin(fmt, rowptr, row, col, vals, x, y):
     return oracle.REF_HOST_PINNED_BY
 
 
+QUANT_PINNED_BY = ("reference symmetric_quantize / symmetric_dequantize (models/quantize.py:20-42) and GCNConv.message_and_aggregate "
+                   "(models/pyg_gcn_conv.py:130-137) cut out by name with ast and executed with torch only; the aggregation inside is the "
+                   "reference's spmm_host_csr compiled in place (oracle/_ref/libref_host_grande_*)")
+
+
+def reference_quantiser(root="/root/reference"):
+    """{'symmetric_quantize', 'symmetric_dequantize', 'message_and_aggregate'}: the reference's own function bodies, compiled from
+    the FunctionDef nodes of models/quantize.py and models/pyg_gcn_conv.py (class GCNConv) -- or None without /root/reference."""
+    import ast
+
+    qpath, cpath = os.path.join(root, "models", "quantize.py"), os.path.join(root, "models", "pyg_gcn_conv.py")
+    if not (os.path.exists(qpath) and os.path.exists(cpath)):
+        return None
+
+    def cut(path, names, cls=None):
+        tree = ast.parse(open(path).read(), filename=path)
+        body = tree.body
+        if cls is not None:
+            body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+        nodes = [n for n in body if isinstance(n, ast.FunctionDef) and n.name in names]
+        assert sorted(n.name for n in nodes) == sorted(names), (path, names)
+        for n in nodes:  # (annotations name typing / torch_sparse symbols the cut leaves behind)
+            n.returns = None
+            for a in n.args.args + n.args.kwonlyargs:
+                a.annotation = None
+        return ast.fix_missing_locations(ast.Module(body=nodes, type_ignores=[]))
+
+    class _NoSparseTensor:  # `isinstance(adj_t, SparseTensor)` in the layer: our adjacency object is not one, so `adj_t.mul` runs
+        pass
+
+    ns = {"torch": torch, "SparseTensor": _NoSparseTensor, "matmul": None}
+    exec(compile(cut(qpath, ["symmetric_quantize", "symmetric_dequantize"]), qpath, "exec"), ns)
+    exec(compile(cut(cpath, ["message_and_aggregate"], cls="GCNConv"), cpath, "exec"), ns)
+    return {k: ns[k] for k in ("symmetric_quantize", "symmetric_dequantize", "message_and_aggregate")}
+
+
+class RefAdjacency:
+    """what the conv layer is handed as ``adj_t`` when the backend is on (inference.py -> prepare_pim_spmm): `.dtype` and
+    `.mul(x_q)`; the product is the reference's own host loop (unit weights) on the quantised features"""
+
+    def __init__(self, rowptr, col, dtype):
+        self.rowptr, self.col, self.dtype = rowptr, col, dtype
+        self.seen_xq = self.out_q = None
+
+    def mul(self, x_q):
+        self.seen_xq = x_q.numpy().copy()
+        self.out_q = oracle.ref_spmm_host_csr(self.rowptr, self.col, None, self.seen_xq, variant="grande")
+        return torch.from_numpy(self.out_q)
+
+
 PINNED_BY = {"last": None}
 
 
@@ -180,6 +230,43 @@ def group_vectors(rng):
             save(f"group_{fmt.lower()}_{name}_sp{sp_parts}_ds{ds_parts}", **kw)
 
 
+def quant_vectors():
+    # (6) quantise -> aggregate -> dequantise of the conv layers (pyg_gcn_conv.py:130-137, quantize.py:20-42): outputs of the
+    # REFERENCE'S OWN functions.  models/quantize.py cannot be imported (line 5: `from torch_sparse import ...`, an un-vendored
+    # package), but symmetric_quantize / symmetric_dequantize need torch alone, and GCNConv.message_and_aggregate needs those two
+    # plus an adjacency object with `.dtype` and `.mul`: the three FunctionDef nodes are cut out of the reference files BY NAME with
+    # `ast` (as oracle/build_ref_host.sh cuts the C loops), compiled in memory and executed here -- nothing of the reference is
+    # written to disk.  The adjacency's `.mul` is the reference's own host loop compiled in place (oracle/_ref/libref_host_*).
+    # The repo's restatements (oracle.symmetric_*, pygim_amd.quantize) are then CHECKED against these outputs, not the other way round.
+    ref_fns = reference_quantiser()
+    rng6 = np.random.default_rng(66)
+    rowptr, col = random_csr(rng6, 256, 256, 14, empty_frac=0.1, long_rows=[(5, 1200)])
+    x = (rng6.standard_normal((256, 40)) * 2.5).astype(np.float32)
+    for name in ("INT8", "INT16", "INT32", "FLT32"):
+        npdt = NP_DTYPES[name]
+        if ref_fns is None or not oracle.have_ref_host():
+            print(f"quant_gcn_{name}: /root/reference or oracle/_ref missing -- NOT regenerated")
+            continue
+        adj = RefAdjacency(rowptr, col, TORCH_OF[name])
+        out_t = ref_fns["message_and_aggregate"](None, adj, torch.from_numpy(x))   # the layer's own call order, pyg_gcn_conv.py:130-137
+        s_t, xq_t = ref_fns["symmetric_quantize"](torch.from_numpy(x), dtype=TORCH_OF[name])
+        assert np.array_equal(adj.seen_xq, xq_t.numpy()) and adj.seen_xq.dtype == npdt
+        scale, xq, out_q, out = np.float32(s_t.item()), xq_t.numpy(), adj.out_q, out_t.numpy()
+        assert out.dtype == np.float32
+        # the repo's statements of the same lines against the reference's output
+        s_o, xq_o = oracle.symmetric_quantize(x, npdt)
+        assert np.float32(s_o) == scale and xq_o.tobytes() == xq.tobytes(), "oracle.symmetric_quantize != reference"
+        assert oracle.spmm_csr(rowptr, col, None, xq).tobytes() == out_q.tobytes()
+        assert oracle.symmetric_dequantize(out_q, 1.0, s_o).tobytes() == out.tobytes(), "oracle.symmetric_dequantize != reference"
+        from pygim_amd import quantize as qz
+
+        s_p, xq_p = qz.symmetric_quantize(torch.from_numpy(x), TORCH_OF[name])
+        assert np.float32(s_p.item()) == scale and np.array_equal(xq_p.numpy(), xq), "pygim_amd.quantize != reference"
+        assert np.array_equal(qz.symmetric_dequantize(torch.from_numpy(out_q), 1.0, s_p).numpy(), out)
+        save(f"quant_gcn_{name}", rowptr=rowptr, col=col, x=x, scale=scale, xq=xq, out_q=out_q, out=out,
+             pinned_by=QUANT_PINNED_BY)
+
+
 def main():
     for f in os.listdir(HERE):
         if f.endswith(".npz"):
@@ -249,23 +336,7 @@ def main():
         save("partition_ref", n_cases=k, **kw)
     else:
         print("oracle/_ref missing: partition vectors NOT regenerated")
-    # (6) quantise -> aggregate -> dequantise of the conv layers (pyg_gcn_conv.py:130-137, quantize.py:20-42) with a fixed
-    # x: the numpy restatement, accepted only when the torch statement of the same lines gives the same bits
-    from pygim_amd import quantize as qz
-
-    rng6 = np.random.default_rng(66)
-    rowptr, col = random_csr(rng6, 256, 256, 14, empty_frac=0.1, long_rows=[(5, 1200)])
-    x = (rng6.standard_normal((256, 40)) * 2.5).astype(np.float32)
-    for name in ("INT8", "INT16", "INT32", "FLT32"):
-        npdt = NP_DTYPES[name]
-        scale, xq = oracle.symmetric_quantize(x, npdt)
-        out_q = oracle.spmm_csr(rowptr, col, None, xq)
-        out = oracle.symmetric_dequantize(out_q, 1.0, scale)
-        s_t, xq_t = qz.symmetric_quantize(torch.from_numpy(x), TORCH_OF[name])
-        assert np.float32(s_t.item()) == scale and np.array_equal(xq_t.numpy(), xq), "numpy vs torch quantiser"
-        out_t = qz.symmetric_dequantize(torch.from_numpy(out_q), 1.0, s_t)
-        assert np.array_equal(out_t.numpy(), out)
-        save(f"quant_gcn_{name}", rowptr=rowptr, col=col, x=x, scale=np.float32(scale), xq=xq, out_q=out_q, out=out)
+    quant_vectors()
     # (7) MatrixMarket reader: outputs of the REFERENCE's own readCOOMatrix + coo2csr (utils.hpp:15-127, compiled in place
     # into oracle/_ref/libref_utils.so) on small files; the file text travels in the fixture
     if oracle.have_ref_utils():
@@ -291,4 +362,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["quant"]:   # only the conv layers' quantiser vectors
+        quant_vectors()
+    else:
+        main()

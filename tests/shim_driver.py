@@ -22,8 +22,8 @@ names = {"spmm": ["spmm_csr_to_device_group", "spmm_csr_run_group", "spmm_coo_to
          "spmv": ["spmv_coo_to_device_group", "spmv_coo_run_group"]}[variant]
 for nme in names + ["dpu_init_ranks", "dpu_init_dpus", "dpu_release", "spmm_free_group"]:
     assert hasattr(ops, nme), nme
-if variant == "spmm":
-    # MatrixMarket debug ops of the default variant (utils.hpp:139-173): against the reference reader built in
+if variant in ("spmm", "grande"):
+    # MatrixMarket debug ops of the default and the grande variant (utils.hpp:139-173; spmm_grande/pytorch_api.cpp:338-342): against the reference reader built in
     # place (oracle/_ref/libref_utils.so) when present, else against the stated semantics
     import tempfile
 

@@ -280,3 +280,64 @@ def test_reddit_lds_staged_product_is_the_cpu_loop_bit_for_bit(clustered):
                 assert torch.equal(c_lds, c_sweep)
         finally:
             _lib.group_free(hd)
+
+
+@pytest.mark.parametrize("fail", [8, 12])
+def test_products_scale_group_survives_a_failed_transient_allocation(fail):
+    """creating a products-scale group needs gigabytes of transient device memory for the device code generator
+    (sort keys, column tables).  lds_fail bit 8 makes its first large allocation "run out of memory" on the products-shaped community graph
+    (2.4 M rows, 123.7 M entries, the density split's dense half); the rung below is the host encoder, which either cannot hold a part of this
+    size (8: its slot headers overflow) or fails outright (8 | 4): the split is dropped and the part's own sweep serves the group, every step
+    down named in pygim_group_lds_note.  Either way the product is right (column-count checksum + sampled rows against the oracle), nothing of
+    the failed attempt stays allocated, and the next group is created normally."""
+    dev = torch.device("cuda", 0)
+    n, nnz, _ = synth.SHAPES["ogbn-products"]
+    h = 128
+    rowptr, col = synth.make_shape("ogbn-products", seed=0, device=dev, kind="sbm")
+    x = synth.features(n, h, torch.int32, seed=0, device=dev)
+    colcount = torch.bincount(col.long(), minlength=n).double()
+    want_sum = colcount @ x.double()
+
+    out = torch.empty((n, h), dtype=torch.int32, device=dev)
+
+    def used():   # bytes in use on the device beyond torch's live tensors (its cache handed back first)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free, total = torch.cuda.mem_get_info()
+        return total - free - torch.cuda.memory_allocated()
+
+    def create():
+        return _lib.group_create(_lib.CSR, _lib.INT32, [rowptr.data_ptr()], [col.data_ptr()], None, [n], [n], [nnz], [1], [h], h)
+
+    def product(hd, dst):
+        _lib.spmm_run_group(hd, [x.data_ptr()], dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+
+    base = used()
+    old = _lib.set_tunable("lds_fail", fail)
+    try:
+        hd = create()
+    finally:
+        _lib.set_tunable("lds_fail", old)
+    try:
+        note = _lib.group_lds_note(hd)
+        # (the host encoder is the rung below the device's -- but a dense half of this size does not fit its slot headers, so either way the
+        # split is dropped, the part's own sweep serves the group and the note names every step down)
+        assert "hybrid: no code-stream plan for the dense cells" in note and "sweep" in note and "device code generation not used" in note, note
+        assert ("could not be built" in note) if fail == 12 else ("does not fit its slot headers" in note and "out of device memory" in note), note
+        product(hd, out)
+        assert torch.equal(out.double().sum(0), want_sum)
+        sample_rows_vs_oracle(rowptr, col, None, x, out, [(0, 300), (n // 2, n // 2 + 300), (n - 300, n)])
+        assert _lib.group_lds_runs(hd) == 0
+    finally:
+        _lib.group_free(hd)
+    assert used() - base < (64 << 20), f"{(used() - base) >> 20} MiB still allocated after the group was freed"
+    hd = create()   # undisturbed: the device writes the stream
+    try:
+        note = _lib.group_lds_note(hd)
+        assert "density split" in note and "host encoder" not in note, note
+        again = torch.empty_like(out)
+        product(hd, again)
+        assert torch.equal(again, out)
+    finally:
+        _lib.group_free(hd)

@@ -190,11 +190,13 @@ def test_no_fixture_is_unpinned():
     """every arithmetic fixture names the reference build that produced it"""
     seen = 0
     for f in sorted(os.listdir(GOLDEN)):
-        if f.endswith(".npz") and (f.startswith("spmm_") or f.startswith("group_")):
+        if f.endswith(".npz") and (f.startswith("spmm_") or f.startswith("group_") or f.startswith("quant_")):
             pin = str(np.load(os.path.join(GOLDEN, f))["pinned_by"])
             assert pin.startswith("reference ") and "unpinned" not in pin, (f, pin)
+            if f.startswith("quant_"):  # outputs of the reference's own quantiser and layer code, not of a restatement
+                assert "models/quantize.py:20-42" in pin and "pyg_gcn_conv.py:130-137" in pin and "ast" in pin, (f, pin)
             seen += 1
-    assert seen >= 45
+    assert seen >= 49
 
 
 @needs_ref_host
@@ -284,8 +286,10 @@ def test_golden_vectors():
 
 @pytest.mark.parametrize("name", ["INT8", "INT16", "INT32", "FLT32"])
 def test_quantiser_golden_vectors(name):
-    """quantise -> aggregate -> dequantise of the conv layers with a fixed x: the numpy
-    restatement and the torch statement (pygim_amd.quantize) both reproduce the committed fixture"""
+    """quantise -> aggregate -> dequantise of the conv layers with a fixed x.  The fixture holds outputs of the
+    REFERENCE'S OWN symmetric_quantize / symmetric_dequantize / GCNConv.message_and_aggregate (cut out by name and executed by
+    tests/golden/make_golden.py, `pinned_by`); the numpy restatement (the checker) and the torch statement (pygim_amd.quantize, the
+    product's host side) both reproduce it"""
     from pygim_amd import quantize as qz
 
     z = np.load(os.path.join(GOLDEN, f"quant_gcn_{name}.npz"))
@@ -298,6 +302,8 @@ def test_quantiser_golden_vectors(name):
     tdt = {"INT8": torch.int8, "INT16": torch.int16, "INT32": torch.int32, "FLT32": torch.float32}[name]
     s_t, xq_t = qz.symmetric_quantize(torch.from_numpy(z["x"]), tdt)
     assert np.float32(s_t.item()) == z["scale"] and np.array_equal(xq_t.numpy(), z["xq"])
+    assert np.array_equal(qz.symmetric_dequantize(torch.from_numpy(z["out_q"]), 1.0, s_t).numpy(), z["out"])
+    assert str(z["pinned_by"]).startswith("reference symmetric_quantize")
 
 
 def test_matrix_market_reader_against_reference_vectors(tmp_path):

@@ -94,3 +94,33 @@ def test_sweep_items_in_locality_order_give_the_same_product(kind):
     finally:
         _lib.set_tunable("lds_mode", old[0])
         _lib.set_tunable("panel_locality", old[1])
+
+
+@pytest.mark.parametrize("kind", ["sbm", "clustered"])
+def test_narrow_blocks_on_a_group_whose_sweep_items_are_in_locality_order(kind):
+    """a group created for WIDE products (h = 100) gets its sweep items in locality order -- no longer longest-first inside a
+    panel -- while the LDS-staged SpMV kernel hands out lane groups by length class from prefixes of a length-sorted list.  A narrow call
+    (pygim_block_run, 1..4 features) on such a group must not take that kernel: every width against the oracle, exact."""
+    dev = torch.device("cuda", 0)
+    rowptr, col = synth.make_shape("products-mini", seed=9, device=dev, kind=kind)
+    n = rowptr.numel() - 1
+    # (long rows too: the classes above 32 / 64 / 128 / 256 entries are the ones a misplaced item would be truncated in)
+    old = _lib.set_tunable("lds_mode", 2), _lib.set_tunable("panel_locality", 2)
+    try:
+        for vals in (False, True):
+            v = torch.randint(-3, 4, (col.numel(),), dtype=torch.int32, device=dev) if vals else None
+            hd = _lib.group_create(_lib.CSR, _lib.INT32, [rowptr.data_ptr()], [col.data_ptr()], [v.data_ptr()] if vals else None, [n], [n], [col.numel()], [1], [100], 100)
+            try:
+                assert _lib.group_lds_tiles(hd)["sweep_locality"] in (1, 2)
+                for w in (1, 2, 3, 4):
+                    x = synth.features(n, w, torch.int32, seed=10 + w, device=dev)
+                    out = torch.empty((n, w), dtype=torch.int32, device=dev)
+                    _lib.block_run(hd, 0, x.data_ptr(), w, out.data_ptr(), w, w, 0, 0)
+                    torch.cuda.synchronize()
+                    want = oracle.spmm_csr(rowptr.cpu().numpy(), col.cpu().numpy(), v.cpu().numpy() if vals else None, x.cpu().numpy())
+                    assert np.array_equal(out.cpu().numpy(), want), (kind, vals, w)
+            finally:
+                _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("lds_mode", old[0])
+        _lib.set_tunable("panel_locality", old[1])

@@ -143,3 +143,75 @@ def test_fused_quantise_aggregate_dequantise(rng, dt):
 
 
 NP_OF = {"INT8": np.int8, "INT16": np.int16, "INT32": np.int32}
+
+
+def _device_used_bytes():
+    """bytes in use on the device beyond torch's live tensors (its cache handed back first)"""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    return total - free - torch.cuda.memory_allocated()
+
+
+@pytest.mark.parametrize("variant", ["spmm", "grande"])
+def test_wrappers_free_the_groups_they_create(variant):
+    """a Reddit-shaped group owns ~1 GB of executable code + CSR + the sweep's plan; the reference's wrappers never call
+    spmm_free_group (spmm_default/pytorch_api.cpp:198-201 leaves it to the caller) and only dpu_release reclaims.  Here the wrapper frees
+    the group it created when the handle is replaced and when the object dies: 20 groups created and dropped through the Python surface
+    leave the device's memory flat; a caller's own spmm_free_group (or dpu_release) beforehand is not freed twice."""
+    import gc
+
+    from pygim_amd import _lib, synth
+
+    pim_ops.load(variant)
+    dev = torch.device("cuda", 0)
+    rowptr, col = synth.make_shape("reddit", seed=0, device=dev)
+    n, h = rowptr.numel() - 1, 256
+    adj = SparseTensorShim(rowptr=rowptr, col=col, sparse_sizes=(n, n))
+    x = synth.features(n, h, torch.float32, seed=0, device=dev)
+    units = torch.ops.pim_ops.dpu_init_ranks(1)
+
+    def make():
+        a = ns(data_type=torch.float32, sp_format="CSR", sp_parts=1, ds_parts=1, hidden_size=h)
+        if variant == "grande":
+            return grande_mod.prepare_pim_spmm_grande(adj, a, list(units))
+        return spmm_mod.prepare_pim_spmm(adj, a)
+
+    try:
+        A = make()
+        want = A.mul(x).double().sum().item()
+        assert _lib.group_lds_code(A.sp_info_ptr)["active"] == 1, _lib.group_lds_note(A.sp_info_ptr)   # the ~1 GB kind of group
+        del A
+        gc.collect()
+        base = _device_used_bytes()
+        peak = base
+        for i in range(20):
+            A = make()
+            if i % 5 == 0:
+                assert A.mul(x).double().sum().item() == want
+            if i == 7:      # re-created on the same object: the old group goes when the handle is replaced
+                first, first_serial = A.sp_info_ptr, _lib.group_serial(A.sp_info_ptr)
+                (A.to_pim_group_csr if variant == "grande" else A.to_pim_group)(h, *(() if variant == "grande" else (1,)))
+                try:   # the first group is gone: its address is dead, or names a LATER group (the allocator hands addresses out again)
+                    assert _lib.group_serial(first) > first_serial
+                except _lib.PygimError:
+                    pass
+                assert _lib.group_serial(A.sp_info_ptr) > first_serial
+            if i == 11:     # the caller frees it as the reference API allows: the wrapper must not free it again (nor a later group at that address)
+                torch.ops.pim_ops.spmm_free_group(A.sp_info_ptr)
+            peak = max(peak, _device_used_bytes())
+            del A
+            gc.collect()
+        used = _device_used_bytes()
+        assert used - base < (192 << 20), f"device memory grew by {(used - base) >> 20} MiB over 20 create / drop cycles"
+        assert peak - base < (3 << 30), f"more than one group alive at a time: {(peak - base) >> 20} MiB above the baseline"
+        # a wrapper that outlives dpu_release holds a dead handle: dropping it afterwards touches nothing
+        A = make()
+        torch.ops.pim_ops.dpu_release()
+        torch.ops.pim_ops.dpu_init_ranks(1)
+        B = make()
+        del A
+        gc.collect()
+        assert B.mul(x).double().sum().item() == want
+    finally:
+        torch.ops.pim_ops.dpu_release()
