@@ -732,6 +732,30 @@ def main():
                 if hy_prev is not None:
                     _lib.set_tunable("lds_hybrid", hy_prev)
                 result["extra"]["products_sbm_shuffled_ids"] = {"error": str(e)[:160]}
+    if rank == 0 and world == 1 and not args.no_extra and not args.clustered and (args.shape, h) == ("reddit", 256):
+        # BASELINE.json's OTHER configurations beside the headline, each with its own roofline object and check, measured
+        # outside the timed region (pygim_amd/bench_configs.py); the SBM / clustered extras above are graphs of this build's own making
+        from pygim_amd import bench_configs
+
+        result["extra"]["note_on_structured_graphs"] = "clustered_*, sbm_shuffled_ids and products_sbm_shuffled_ids are NOT BASELINE configurations (locality studies of this build)"
+        cfgs = {}
+        for key, fn in (("configs[2]_products_coo_i32", lambda: bench_configs.config3_products_coo(dev, stream, h)),
+                        ("configs[3]_reddit_gcn_3_layers_one_gpu", lambda: bench_configs.config4_gcn_one_gpu(dev, h)),
+                        ("configs[4]_papers100m_per_gpu", lambda: bench_configs.config5_papers_slices(dev, stream))):
+            t0 = time.perf_counter()
+            try:
+                cfgs[key] = fn()
+            except Exception as e:  # noqa: BLE001  (an extra: never the reason the line is missing)
+                cfgs[key] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+            if isinstance(cfgs[key], dict):
+                cfgs[key]["wall_s"] = round(time.perf_counter() - t0, 1)
+            torch.cuda.empty_cache()
+        result["baseline_configs"] = cfgs
+        try:
+            result["extra"]["end_to_end_cpu_tensors"] = bench_configs.end_to_end_cpu_tensors(rowptr, col, n, h)
+            result["extra"]["end_to_end_cpu_tensors_ms"] = result["extra"]["end_to_end_cpu_tensors"]["ms_per_mul"]
+        except Exception as e:  # noqa: BLE001
+            result["extra"]["end_to_end_cpu_tensors"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, cpu_out = cpu_baseline(rowptr, col, x, args)
         result["cpu_baseline"] = base

@@ -35,7 +35,11 @@ LDS_ROWS_MAX = 8 * 228      # rows of a tile (waves x accumulators per wave)
 # + stored entries x 0.26 ns      (what the entries add on top: LDS reads beside the DMA's writes)
 LDS_NS_PER_COLUMN = 3.43
 LDS_NS_PER_ENTRY = 0.26
-LDS_COL_SPLIT = False       # True when the caller lets FLT32 shares be split into column ranges (tunable lds_col_split_f32; bench.py at N > 1)
+LDS_NS_PER_COLUMN_FLOOR = 4.4   # ... and never less than this per column, however few entries a tile has: with every CU streaming, the L2 -> LDS path
+                                # lands ~57 GB/s per CU (round 6, profiles/r06_stamps.txt: lighter tiles leave the 0.57 us per 128-column chunk unchanged)
+LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are split into column ranges (the library's default since round 6; tunable
+                            # lds_col_split_f32 = 0 keeps the bit-identical stored-order form -- callers that set it set this to False)
+LDS_MIN_LANES = 17          # narrower products keep the sweep (tunable lds_min_width)
 LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
@@ -65,26 +69,29 @@ def lds_rows_per_tile(nrows, nslices, rmax=LDS_ROWS_MAX, cus=CUS):
 
 
 def lds_product_seconds(nrows, ncols, nnz, h, es):
-    """the LDS-staged product on one GPU, or None where the library keeps the sweep (4-byte elements, rows of at least 33
+    """the LDS-staged product on one GPU, or None where the library keeps the sweep (4-byte elements, rows of at least 17
     elements, enough stored entries per staged column); uniform columns assumed (every tile streams every chunk)"""
-    if es != 4 or h < 33 or nrows == 0 or nnz == 0:
+    if es != 4 or h < LDS_MIN_LANES or nrows == 0 or nnz == 0:
         return None
     nsl = -(-h // 64)
     pack_s = ncols * h * es * 2 / RATE_STREAM
     # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
     tall = -(-int(nrows) // LDS_ROWS_MAX)
-    if LDS_COL_SPLIT and tall * nsl * 2 <= CUS:
+    if LDS_COL_SPLIT and nnz >= (1 << 20) and tall * nsl * 2 <= CUS:
         split = min(8, CUS // (tall * nsl))
         if nnz / (tall * ncols) < LDS_MIN_REUSE:
             return None
-        per_wg = (ncols / split * LDS_NS_PER_COLUMN + nnz / tall / split * LDS_NS_PER_ENTRY) * 1e-9
+        tall2 = CUS // (nsl * split)            # (round 6) more, lighter row tiles when tall x slices x ranges leaves compute units idle
+        if tall < tall2 <= 2 * tall:
+            tall = tall2
+        per_wg = max(ncols / split * LDS_NS_PER_COLUMN + nnz / tall / split * LDS_NS_PER_ENTRY, ncols / split * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
         reduce_s = (split + 1) * nrows * h * es / RATE_STREAM
         return per_wg + reduce_s + pack_s + 2 * LAUNCH
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    per_wg = (ncols * LDS_NS_PER_COLUMN + nnz / tiles * LDS_NS_PER_ENTRY) * 1e-9
+    per_wg = max(ncols * LDS_NS_PER_COLUMN + nnz / tiles * LDS_NS_PER_ENTRY, ncols * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
     rounds = -(-tiles * nsl // CUS)
     return rounds * per_wg + pack_s + LAUNCH
 

@@ -171,6 +171,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_nbuf") slot = &g_tune.lds_code_nbuf;
     else if (n == "lds_code_waves") slot = &g_tune.lds_code_waves;
     else if (n == "lds_fail") slot = &g_tune.lds_fail;
+    else if (n == "lds_stamp") slot = &g_tune.lds_stamp;
     else if (n == "lds_code_exp") slot = &g_tune.lds_code_exp;
     else if (n == "lds_hybrid") slot = &g_tune.lds_hybrid;
     else if (n == "lds_hybrid_min") slot = &g_tune.lds_hybrid_min;
@@ -185,6 +186,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_code_nsets") slot = &g_tune.lds_code_nsets;
     else if (n == "lds_col_split") slot = &g_tune.lds_col_split;
     else if (n == "lds_col_split_f32") slot = &g_tune.lds_col_split_f32;
+    else if (n == "lds_fill_tiles") slot = &g_tune.lds_fill_tiles;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);

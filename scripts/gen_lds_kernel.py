@@ -73,7 +73,7 @@ GEO_CODE8_64.acc_regs = 228
 GEO_CODE8_64.lane_shift = 3
 
 
-def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
+def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None, stamps=False):
     """ablate (timing experiments only, results wrong): 1 = one accumulator index per batch, 2 = no LDS reads,
     3 = no address computation and no LDS reads, 4 = no accumulation, 5 = no scalar token loads inside the batch loop,
     6 = no workgroup barrier, 7 = no chunk DMA, 8 = no token-line touches; 9 = (correct results) LDS reads interleaved with the adds"""
@@ -110,6 +110,19 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
         a(f"s_lshr_b32 {NBN}, s{TOK[r] + 1}, 18")     # batches of the slot after it (token prefetch)
         a(f"s_lshr_b32 {CIDN}, s{TOK[r] + 2}, 18")    # chunk id of the slot after it (DMA)
 
+    def stamp(k):
+        # measurement build (k_*_ts, tunable lds_stamp): the constant 100 MHz clock at four points of a wave's life -> stamps[(block * NW + wave) * 4 + k].
+        # v8 / v9 / v10 are x registers: free before the stream starts and after it returns; s[72:73] are free in the shell
+        if not stamps:
+            return
+        a("s_memrealtime s[72:73]")
+        a("s_waitcnt lgkmcnt(0)")
+        a("v_mov_b32 v8, s72")
+        a("v_mov_b32 v9, s73")
+        a("v_mov_b32 v10, 0")
+        a(f"global_store_dwordx2 v10, v[8:9], %[stamps] offset:{8 * k}")
+
+    stamp(0)
     # ---- set-up
     a(f"v_lshlrev_b32 {VL4}, {g.lane_shift}, %[lane]")
     if VL128 != VL16:
@@ -138,6 +151,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
             a(f"v_and_b32 {VL128}, 7, %[lane]")    # lane offsets (lane % 8) * 128
             a(f"v_lshlrev_b32 {VL128}, 7, {VL128}")  # (the 8-wave shell touches with lane * 16: the same 8 lines)
         a("s_addc_u32 s85, s85, 0")
+        stamp(1)
         a("s_swappc_b64 s[86:87], %[code]")
         a("s_branch L_out_%=")                     # (the token loop below is not part of this form)
     cut = len(L)
@@ -329,6 +343,48 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
     if code:
         del L[cut - 1:]                            # (nothing between the stream's return and the store stage)
     a("L_out_%=:")
+    stamp(2)
+    # Row ids of the wave's KA accumulators.  Token kernels: eight per scalar load of the row map, each load waited for (29 round trips to
+    # memory per wave).  Code-stream kernels (round 6; the stamps of profiles/r06_stamps.txt: 22 us of every workgroup's life were this
+    # loop, the loads' latency): the whole row map of the wave comes in ONE round trip -- lane l of v[RM + j] = rowmap[64 j + l], up to four
+    # vector loads in flight together -- and the loop takes its eight ids per step out of the registers with v_readlane_b32.
+    ka_stride = (KA + 7) & ~7
+    RM = 20                                           # v20..v23: x registers, free once the stream has returned
+    nblk = (ka_stride + 63) // 64 if code else 1
+    if code:
+        assert g.X0 <= RM and RM + 4 + 1 <= ACC0 and nblk <= 4
+        a("s_mov_b64 exec, -1")
+        a(f"v_lshlrev_b32 v{RM + 4}, 2, %[lane]")
+        for j in range(nblk):
+            cnt = min(64, ka_stride - 64 * j)
+            if cnt < 64:
+                a(f"s_bfm_b64 exec, {cnt}, 0")     # (nothing is read past the wave's part of the row map)
+            a(f"global_load_dword v{RM + j}, v{RM + 4}, %[rowmap] offset:{256 * j}")
+        a("s_mov_b64 exec, -1")
+        a("s_waitcnt vmcnt(0)")
+
+    def row_loop(row_body, tail):
+        """the loop over the wave's accumulators, eight per step: row_body(i, rid, tag) stores accumulator KREG + i to row `rid` of C"""
+        for j in range(nblk):
+            a(f"s_mov_b32 {KREG}, {64 * j}")
+            a(f"L_orow{j}_%=:")
+            if code:
+                for i in range(8):
+                    a(f"s_sub_u32 {DLDS}, {KREG}, {64 * j - i}" if 64 * j - i >= 0 else f"s_add_u32 {DLDS}, {KREG}, {i - 64 * j}")
+                    a(f"v_readlane_b32 s{TOK[0] + i}, v{RM + j}, {DLDS}")
+            else:
+                a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
+                a("s_waitcnt lgkmcnt(0)")
+            for i in range(8):
+                row_body(i, f"s{TOK[0] + i}", f"{j}{i}")
+            if not code:
+                a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
+                a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
+            a(f"s_add_u32 {KREG}, {KREG}, 8")
+            a(f"s_cmp_lt_u32 {KREG}, {min(64 * j + 64, ka_stride) if code else KA}")
+            a(f"s_cbranch_scc1 L_orow{j}_%=")
+        tail()
+
     if out_kind in ("f64", "i64"):
         # 8-byte elements (round 4): row k's running sum is the register pair v[ACC0 + 2k : ACC0 + 2k + 1], one feature per lane (64 to a
         # slice of 512 bytes); the store writes 8 bytes per lane, or adds into C first (v_add_f64 / a 64-bit integer add)
@@ -337,14 +393,10 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
         a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
         a("s_and_b64 exec, exec, vcc")
         a(f"s_mov_b64 {NP}, %[rowmap]")
-        a(f"s_mov_b32 {KREG}, 0")
-        a("L_orow_%=:")
-        a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
-        a("s_waitcnt lgkmcnt(0)")
-        for i in range(8):
-            rid = f"s{TOK[0] + i}"
+
+        def row64(i, rid, tag):
             a(f"s_cmp_eq_u32 {rid}, -1")
-            a(f"s_cbranch_scc1 L_oskip{i}_%=")
+            a(f"s_cbranch_scc1 L_oskip{tag}_%=")
             a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
             a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
             a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
@@ -356,7 +408,7 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
             a(f"v_mov_b32 v9, v{ACC0 + 1}")
             a("s_set_gpr_idx_off")
             a("s_cmp_eq_u32 %[accum], 0")
-            a(f"s_cbranch_scc1 L_ost{i}_%=")
+            a(f"s_cbranch_scc1 L_ost{tag}_%=")
             a(f"global_load_dwordx2 v[16:17], {VB}, {PA}")
             a("s_waitcnt vmcnt(0)")
             if out_kind == "f64":
@@ -364,16 +416,16 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
             else:
                 a("v_add_co_u32 v8, vcc, v16, v8")
                 a("v_addc_co_u32 v9, vcc, v17, v9, vcc")
-            a(f"L_ost{i}_%=:")
+            a(f"L_ost{tag}_%=:")
             a(f"global_store_dwordx2 {VB}, v[8:9], {PA}")
-            a(f"L_oskip{i}_%=:")
-        a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
-        a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
-        a(f"s_add_u32 {KREG}, {KREG}, 8")
-        a(f"s_cmp_lt_u32 {KREG}, {KA}")
-        a("s_cbranch_scc1 L_orow_%=")
-        a(f"s_mov_b64 exec, {EX}")
-        a("s_waitcnt vmcnt(0)")
+            a(f"L_oskip{tag}_%=:")
+
+        def tail64():
+            a(f"s_mov_b64 exec, {EX}")
+            a("s_waitcnt vmcnt(0)")
+
+        row_loop(row64, tail64)
+        stamp(3)
         return L
     if out_kind in ("i8", "i8_deq", "i16_deq"):
         # "i16_deq": the INT16 stream's own dequantising store (sign-extended 16-bit halves), same shape as "i8_deq"
@@ -410,13 +462,9 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
             a(f"s_mov_b64 exec, {EX}")
             a("s_waitcnt vmcnt(0)")
             a("L_nopost_%=:")
-        a("L_orow_%=:")
-        a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
-        a("s_waitcnt lgkmcnt(0)")
-        for i in range(8):
-            rid = f"s{TOK[0] + i}"
+        def row8(i, rid, tag):
             a(f"s_cmp_eq_u32 {rid}, -1")
-            a(f"s_cbranch_scc1 L_oskip{i}_%=")
+            a(f"s_cbranch_scc1 L_oskip{tag}_%=")
             a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
             a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
             a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
@@ -440,29 +488,29 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
                 a(f"v_mul_f32 {T2}, %[scale], {T2}")
                 a(f"v_mul_f32 {T3}, %[scale], {T3}")
                 a("s_cmp_eq_u64 %[pmul], 0")
-                a(f"s_cbranch_scc1 L_np{i}_%=")
+                a(f"s_cbranch_scc1 L_np{tag}_%=")
                 a(f"v_mul_f32 {T2}, v{VP}, {T2}")
                 a(f"v_mul_f32 {T3}, v{VP + 1}, {T3}")
                 a(f"v_add_f32 {T2}, v{VQ}, {T2}")
                 a(f"v_add_f32 {T3}, v{VQ + 1}, {T3}")
                 a("s_cmp_eq_u32 %[relu], 0")
-                a(f"s_cbranch_scc1 L_np{i}_%=")
+                a(f"s_cbranch_scc1 L_np{tag}_%=")
                 a(f"v_max_f32 {T2}, 0, {T2}")
                 a(f"v_max_f32 {T3}, 0, {T3}")
-                a(f"L_np{i}_%=:")
+                a(f"L_np{tag}_%=:")
                 a(f"s_mov_b64 exec, {EXA}")
                 a(f"global_store_dword {VL8}, {T2}, {PA}")
                 a(f"s_mov_b64 exec, {EXB}")
                 a(f"global_store_dword {VL8}, {T3}, {PA} offset:4")
                 a(f"s_mov_b64 exec, {EX}")
-            a(f"L_oskip{i}_%=:")
-        a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
-        a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
-        a(f"s_add_u32 {KREG}, {KREG}, 8")
-        a(f"s_cmp_lt_u32 {KREG}, {KA}")
-        a("s_cbranch_scc1 L_orow_%=")
-        a(f"s_mov_b64 exec, {EX}")
-        a("s_waitcnt vmcnt(0)")
+            a(f"L_oskip{tag}_%=:")
+
+        def tail8():
+            a(f"s_mov_b64 exec, {EX}")
+            a("s_waitcnt vmcnt(0)")
+
+        row_loop(row8, tail8)
+        stamp(3)
         return L
     a(f"s_mov_b64 {EX}, exec")
     a("v_cmp_gt_u32 vcc, %[wvalid], %[lane]")
@@ -477,13 +525,9 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
         a(f"global_load_dword v{XS[0] + 1}, {VL4}, %[padd]")
         a("s_waitcnt vmcnt(0)")
         a("L_nopost_%=:")
-    a("L_orow_%=:")                                # eight rows per scalar load of the row map
-    a(f"s_load_dwordx8 s[{TOK[0]}:{TOK[0] + 7}], {NP}, 0x0")
-    a("s_waitcnt lgkmcnt(0)")
-    for i in range(8):
-        rid = f"s{TOK[0] + i}"
+    def row4(i, rid, tag):
         a(f"s_cmp_eq_u32 {rid}, -1")
-        a(f"s_cbranch_scc1 L_oskip{i}_%=")
+        a(f"s_cbranch_scc1 L_oskip{tag}_%=")
         a(f"s_mul_i32 {PA_LO}, {rid}, %[ldc]")
         a(f"s_mul_hi_u32 {PA_HI}, {rid}, %[ldc]")
         a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
@@ -498,29 +542,31 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None):
                 a(f"v_cvt_f32_i32 {VT0}, {VT0}")
             a(f"v_mul_f32 {VT0}, %[scale], {VT0}")
             a("s_cmp_eq_u64 %[pmul], 0")
-            a(f"s_cbranch_scc1 L_np{i}_%=")
+            a(f"s_cbranch_scc1 L_np{tag}_%=")
             a(f"v_mul_f32 {VT0}, v{XS[0]}, {VT0}")         # product and sum rounded separately, as k_post_affine / torch's a * y + b
             a(f"v_add_f32 {VT0}, v{XS[0] + 1}, {VT0}")
             a("s_cmp_eq_u32 %[relu], 0")
-            a(f"s_cbranch_scc1 L_np{i}_%=")
+            a(f"s_cbranch_scc1 L_np{tag}_%=")
             a(f"v_max_f32 {VT0}, 0, {VT0}")
-            a(f"L_np{i}_%=:")
+            a(f"L_np{tag}_%=:")
         else:
             a("s_cmp_eq_u32 %[accum], 0")
-            a(f"s_cbranch_scc1 L_ost{i}_%=")
+            a(f"s_cbranch_scc1 L_ost{tag}_%=")
             a(f"global_load_dword {VT1}, {VL4}, {PA}")
             a("s_waitcnt vmcnt(0)")
             a(f"{op_add} {VT0}, {VT1}, {VT0}")
-            a(f"L_ost{i}_%=:")
+            a(f"L_ost{tag}_%=:")
         a(f"global_store_dword {VL4}, {VT0}, {PA}")
-        a(f"L_oskip{i}_%=:")
-    a(f"s_add_u32 {NP_LO}, {NP_LO}, 32")
-    a(f"s_addc_u32 {NP_HI}, {NP_HI}, 0")
-    a(f"s_add_u32 {KREG}, {KREG}, 8")
-    a(f"s_cmp_lt_u32 {KREG}, {KA}")
-    a("s_cbranch_scc1 L_orow_%=")
-    a(f"s_mov_b64 exec, {EX}")
-    a("s_waitcnt vmcnt(0)")
+        a(f"L_oskip{tag}_%=:")
+
+    def tail4():
+        a(f"s_mov_b64 exec, {EX}")
+        a("s_waitcnt vmcnt(0)")
+
+    row_loop(row4, tail4)
+    stamp(3)
+    if stamps:
+        a("s_waitcnt vmcnt(0)")
     return L
 
 
@@ -568,6 +614,7 @@ struct LdsArgs {
     uint32_t piece_bytes;              // code-stream kernels: bytes of a chunk that one wave DMAs (chunk bytes / 16: the plan's ring geometry)
     uint32_t xcd_sx;                   // slices per XCD (round 5): 1 = an XCD streams ONE slice of X (X shared in its L2, a tile's code fetched by every
                                        // slice's XCDs); 2 / 4 = consecutive workgroups of an XCD are slices of the SAME tile and share its code in L2
+    uint64_t *stamps;                  // measurement build (k_lds_code8_f32_ts): four 100 MHz clock values per wave (start, stream entered, stream left, stored)
     uint32_t xcd_contig;               // 0 = an XCD takes every xcd_group-th tile; T > 0 = a contiguous run of T tiles (plans whose neighbouring tiles stage the
                                        // same chunks -- the dense half of a density split: they then meet in that XCD's L2)
 };
@@ -658,6 +705,8 @@ def main():
         variants.append((f"k_lds_code8_{base}" + ("_deq" if deq else ""), op, "C8", 0,
                          "CODE-STREAM form, 8 waves x 228 accumulators (2 waves per SIMD, 1 824-row tiles: fewer rounds of workgroups, less of X staged)",
                          None, deq))
+    variants.append(("k_lds_code8_f32_ts", "v_add_f32", "C8", 0,
+                     "MEASUREMENT build of k_lds_code8_f32 (tunable lds_stamp): the same product, plus four clock stamps per wave", None, None))
     variants.append(("k_lds_code8_f64", "v_add_f64", "C8W", 0,
                      "CODE-STREAM form, DBL64: 512-byte rows in LDS, one ds_read_b64 per staged column, a register pair per running sum (8 waves x 114 rows)", None, None, "f64"))
     variants.append(("k_lds_code8_i64", "v_add_co_u32", "C8W", 0,
@@ -680,7 +729,8 @@ def main():
         is_code = "_code" in name
         out_kind = v[7] if len(v) > 7 else None
         cslice, fps = {None: (256, 64), "i8": (128, 128), "i8_deq": (512, 128), "i16_deq": (512, 128), "f64": (512, 64), "i64": (512, 64)}[out_kind]
-        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code, out_kind=out_kind))
+        ts = name.endswith("_ts")
+        asm = "\n".join(f'        "{ln}\\n"' for ln in body(op, g, ab, op_mul, deq, code=is_code, out_kind=out_kind, stamps=ts))
         guard = "_ab" in name   # ablation builds (timing experiments, wrong results) only with -DPYGIM_LDS_ABLATE (make ablate)
         if guard:
             text += "\n#ifdef PYGIM_LDS_ABLATE"
@@ -696,8 +746,11 @@ def main():
                               post_ops=(',\n          [pmul] "s"(pmul_s), [padd] "s"(padd_s), [relu] "s"(a.post_relu)' if deq else ""),
                               code_decl=("    const uint64_t code_a = (uint64_t)(a.code + a.code_start[(uint64_t)ti * NW + wave]);\n"
                                          "    const uint64_t code_s = ((uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(code_a >> 32))) << 32) | "
-                                         "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)code_a);" if is_code else ""),
-                              code_ops=(',\n          [code] "s"(code_s)' if is_code else ""),
+                                         "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)code_a);" if is_code else "") +
+                                        ("\n    const uint64_t stamps_a = (uint64_t)(a.stamps + ((uint64_t)b * NW + wave) * 4);\n"
+                                         "    const uint64_t stamps_s = ((uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(stamps_a >> 32))) << 32) | "
+                                         "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)stamps_a);" if ts else ""),
+                              code_ops=((',\n          [code] "s"(code_s)' if is_code else "") + (', [stamps] "s"(stamps_s)' if ts else "")),
                               piece_expr=("a.piece_bytes" if is_code else "PIECE"))
         if guard:
             text += "#endif  // PYGIM_LDS_ABLATE\n"

@@ -162,7 +162,7 @@ def test_column_split_tiles(rng, checked, splits):
     """short row shares (a rank's share on N GPUs): every row tile becomes `splits` workgroup tiles, each with a range of the chunks, partial
     sums reduced in range order -- generated on the device like the rest (the entries of every (row tile, range) are counted there before
     the tiles are put in launch order), word for word the host encoder's"""
-    old = _lib.set_tunable("lds_col_split", splits), _lib.set_tunable("lds_col_split_f32", 1)
+    old = _lib.set_tunable("lds_col_split", splits), _lib.set_tunable("lds_col_split_f32", 2)
     try:
         for dt in (np.int32, np.float32):
             n, ncols, h = int(rng.integers(500, 4000)), int(rng.integers(2000, 9000)), int(rng.integers(64, 260))

@@ -380,8 +380,8 @@ def test_quantised_aggregation_with_the_dequantising_store(rng, lds_forced, dt, 
 def test_short_row_shares_split_their_tiles_into_column_ranges(rng, lds_forced, code):
     """a rank's row share on N GPUs is a few tall tiles: too few workgroups to fill the chip when each streams a whole slice of X.
     The plan then splits every row tile into S column ranges (S x the workgroups, 1/S of X each), partial sums land in a scratch
-    block and are added in range order.  INT32 / INT16: exact, automatic.  FLT32: only with lds_col_split_f32 = 1, and then a row's
-    sum is the sum of its ranges' sequential sums (compared here on integer-valued features, where every order is exact, and
+    block and are added in range order.  INT32 / INT16: exact, automatic.  FLT32: automatic from a million entries up (round 6), any part with lds_col_split_f32 = 2, never
+    with 0 -- and then a row's sum is the sum of its ranges' sequential sums (compared here on integer-valued features, where every order is exact, and
     on real ones against the norm-wise bound)."""
     old_code = _lib.set_tunable("lds_code", code)
     try:
@@ -391,11 +391,11 @@ def test_short_row_shares_split_their_tiles_into_column_ranges(rng, lds_forced, 
         got, plan = product(rowptr, col, xi)
         assert plan["tiles"] >= 4 * 2 and plan["tiles"] % 2 == 0          # 2 tall row tiles x S >= 4 column ranges
         assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xi).tobytes()
-        # FLT32: not split unless asked
+        # FLT32: a part of this size (375 k entries) is not split unless asked
         xf = features(rng, ncols, h, np.float32)
         got, plan1 = product(rowptr, col, xf)
         assert got.tobytes() == oracle.spmm_csr(rowptr, col, None, xf).tobytes()   # (bit-identical: whole rows, stored order)
-        old = _lib.set_tunable("lds_col_split_f32", 1)
+        old = _lib.set_tunable("lds_col_split_f32", 2)
         try:
             got, plan2 = product(rowptr, col, xf)
             xint = rng.integers(-8, 8, size=(ncols, h)).astype(np.float32)
