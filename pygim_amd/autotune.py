@@ -39,6 +39,8 @@ LDS_NS_PER_COLUMN_FLOOR = 4.4   # ... and never less than this per column, howev
                                 # lands ~57 GB/s per CU (round 6, profiles/r06_stamps.txt: lighter tiles leave the 0.57 us per 128-column chunk unchanged)
 LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are split into column ranges (the library's default since round 6; tunable
                             # lds_col_split_f32 = 0 keeps the bit-identical stored-order form -- callers that set it set this to False)
+LDS_ROW_TAIL = 3            # percent of a share's rows that may stay outside the plan (tunable lds_row_tail)
+TAIL_S = 30e-6              # the two tail kernels
 LDS_MIN_LANES = 17          # narrower products keep the sweep (tunable lds_min_width)
 LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
@@ -77,16 +79,30 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
     pack_s = ncols * h * es * 2 / RATE_STREAM
     # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
     tall = -(-int(nrows) // LDS_ROWS_MAX)
-    if LDS_COL_SPLIT and nnz >= (1 << 20) and tall * nsl * 2 <= CUS:
-        split = min(8, CUS // (tall * nsl))
+    split = min(8, CUS // (tall * nsl)) if tall * nsl * 2 <= CUS else 1
+    tail_rows = 0
+    if LDS_COL_SPLIT and nnz >= (1 << 20):
+        # (round 6) a share whose rows all but fit tall' x slices x S' = one workgroup per compute unit for a larger S': the last few rows (at most
+        # LDS_ROW_TAIL percent) stay outside the plan (k_lds_tail_seg / _fin, a few tens of microseconds)
+        for s2 in range(8, split, -1):
+            tall_s = CUS // (nsl * s2)
+            if not tall_s:
+                continue
+            covered = tall_s * LDS_ROWS_MAX
+            if covered >= nrows:
+                break
+            if (nrows - covered) * 100 <= nrows * LDS_ROW_TAIL and tall_s * nsl * s2 * 10 >= CUS * 9:
+                split, tall, tail_rows = s2, tall_s, nrows - covered
+                break
+    if LDS_COL_SPLIT and nnz >= (1 << 20) and split > 1:
         if nnz / (tall * ncols) < LDS_MIN_REUSE:
             return None
         tall2 = CUS // (nsl * split)            # (round 6) more, lighter row tiles when tall x slices x ranges leaves compute units idle
-        if tall < tall2 <= 2 * tall:
+        if not tail_rows and tall < tall2 <= 2 * tall:
             tall = tall2
         per_wg = max(ncols / split * LDS_NS_PER_COLUMN + nnz / tall / split * LDS_NS_PER_ENTRY, ncols / split * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
         reduce_s = (split + 1) * nrows * h * es / RATE_STREAM
-        return per_wg + reduce_s + pack_s + 2 * LAUNCH
+        return per_wg + reduce_s + pack_s + 2 * LAUNCH + (TAIL_S if tail_rows else 0.0)
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:

@@ -881,6 +881,91 @@ __global__ void k_lds_reduce(const T *__restrict__ part, uint32_t splits, uint64
     C[r * ldc + f] = (T)acc;
 }
 
+// ... with the conv layers' dequantisation (and the optional per-column epilogue) where the ranges' sums meet (round 6: a rank's row share is a column-split
+// plan, and its quantised aggregation -- models/pyg_gcn_conv.py:130-137 -- takes the LDS-staged kernel too): out = float(sum) * scale, as the kernels' own
+// dequantising store and k_dequantize
+template <typename T>
+__global__ void k_lds_reduce_deq(const T *__restrict__ part, uint32_t splits, uint64_t nrows, uint32_t w, uint64_t ldp, float *__restrict__ out, int64_t ldo,
+                                 const uint32_t *__restrict__ absmax_bits, int log2_range, const float *__restrict__ post_mul, const float *__restrict__ post_add,
+                                 int post_relu) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * w) return;
+    const uint64_t r = i / w;
+    const uint32_t f = (uint32_t)(i % w);
+    using A = typename AccOf<T>::type;
+    A acc = (A)part[r * ldp + f];
+    for (uint32_t c = 1; c < splits; c++) acc = (A)(acc + (A)part[((uint64_t)c * nrows + r) * ldp + f]);
+    float y = (float)(T)acc * (1.0f * quant_scale(*absmax_bits, log2_range));
+    if (post_mul) {
+        y = post_mul[f] * y + post_add[f];
+        if (post_relu) y = fmaxf(y, 0.0f);
+    }
+    out[r * ldo + f] = y;
+}
+
+// The last rows of a row share, outside the LDS-staged plan (round 6): when tall x slices x S full-height row tiles cover all but a few percent of a share's
+// rows with EXACTLY one workgroup per compute unit (a 1/8 share of the Reddit-shaped graph: 16 tiles x 4 slices x 4 ranges = 256 workgroups for 29 184 of its
+// 29 471 rows, against 17 x 4 x 3 = 204 for all of them), the plan takes those tiles and these two kernels the remainder.  They gather from the SAME slice-major
+// copy the LDS-staged kernel streams (256-byte row slices).  The rows are cut into SEGMENTS of at most LDS_TAIL_SEG entries at plan time (a row of 20 000 entries
+// on one workgroup would be a latency-bound chain of its own: the first form of this kernel, a workgroup per row, cost more than the extra column range saved):
+//   k_lds_tail_seg  a 512-thread workgroup per (segment, slice): wave v takes entries v, v + 8, ... of the segment, eight gathers in flight per wave; the eight
+//                   partial sums are added in wave order and parked in scratch
+//   k_lds_tail_fin  a wave per (row, slice): the row's segments in order, then the store -- plain, accumulating, or with the conv layers' dequantisation + epilogue
+// Deterministic; integers exact, FLT32 in this fixed order (these shares are column-split plans: the norm-wise contract already).
+constexpr uint32_t LDS_TAIL_SEG = 256;
+template <typename T>
+__global__ __launch_bounds__(512) void k_lds_tail_seg(const uint32_t *__restrict__ segs, uint32_t nseg, const uint32_t *__restrict__ colind, const char *__restrict__ xs,
+                                                      uint64_t slice_stride, typename AccOf<T>::type *__restrict__ parked) {
+    static_assert(sizeof(T) == 4, "4-byte element types");
+    using A = typename AccOf<T>::type;
+    __shared__ A partial[8][64];
+    const uint32_t seg = blockIdx.x, slice = blockIdx.y;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t e0 = segs[nseg + seg], e1 = segs[2 * nseg + seg];
+    const char *xsl = xs + (uint64_t)slice * slice_stride + lane * 4;
+    A acc = 0;
+    uint32_t e = e0 + wave;
+    for (; e + 56 < e1; e += 64) {   // eight of this wave's entries at a time: the gathers first, then the sums in entry order
+        T x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = *(const T *)(xsl + (uint64_t)colind[e + 8 * k] * 256);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = (A)(acc + to_acc<T>(x[k]));
+    }
+    for (; e < e1; e += 8) acc = (A)(acc + to_acc<T>(*(const T *)(xsl + (uint64_t)colind[e] * 256)));
+    partial[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    A sum = partial[0][lane];
+#pragma unroll
+    for (int v = 1; v < 8; v++) sum = (A)(sum + partial[v][lane]);
+    parked[((uint64_t)seg * gridDim.y + slice) * 64 + lane] = sum;
+}
+template <typename T, bool DEQ>
+__global__ __launch_bounds__(64) void k_lds_tail_fin(const uint32_t *__restrict__ rowseg, uint32_t row0, const typename AccOf<T>::type *__restrict__ parked, uint32_t w_lanes,
+                                                     void *__restrict__ C, int64_t ldc_bytes, int accumulate, const uint32_t *__restrict__ absmax_bits, int log2_range,
+                                                     const float *__restrict__ post_mul, const float *__restrict__ post_add, int post_relu) {
+    using A = typename AccOf<T>::type;
+    const uint32_t t = blockIdx.x, slice = blockIdx.y, lane = threadIdx.x;
+    const uint32_t f = slice * 64 + lane;
+    if (f >= w_lanes) return;
+    A sum = 0;
+    for (uint32_t s = rowseg[t]; s < rowseg[t + 1]; s++) sum = (A)(sum + parked[((uint64_t)s * gridDim.y + slice) * 64 + lane]);
+    const uint64_t row = (uint64_t)row0 + t;
+    if constexpr (DEQ) {
+        float y = (float)from_acc<T>(sum) * (1.0f * quant_scale(*absmax_bits, log2_range));
+        if (post_mul) {
+            y = post_mul[f] * y + post_add[f];
+            if (post_relu) y = fmaxf(y, 0.0f);
+        }
+        *(float *)((char *)C + (int64_t)row * ldc_bytes + (size_t)f * 4) = y;
+    } else {
+        T *c = (T *)((char *)C + (int64_t)row * ldc_bytes + (size_t)f * 4);
+        if (accumulate) sum = (A)(to_acc<T>(*c) + sum);
+        *c = from_acc<T>(sum);
+    }
+}
+
 // dst[i] = src[i], 16 bytes a thread (the upload of the code stream into its executable allocation)
 __global__ void k_copy16(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

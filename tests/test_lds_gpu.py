@@ -574,3 +574,72 @@ def test_the_note_is_truncated_to_the_callers_buffer(rng, lds_forced):
         assert buf.raw[:5] == b"code\x00" and buf.raw[5:] == b"\xff" * 3
     finally:
         _lib.group_free(hd)
+
+
+@pytest.mark.parametrize("verify", [0, 2])
+def test_a_share_that_all_but_fits_one_workgroup_per_cu_leaves_its_last_rows_to_the_tail_kernel(rng, verify):
+    """Round 6: 16 full-height row tiles x 4 slices x 4 column ranges are exactly the 256 workgroups of the chip; a share of 16 x 1 824 + 200 rows would
+    need 17 tiles and then only 3 ranges fit (204 workgroups, each streaming a third of X).  The plan takes the 29 184 rows that fit, k_lds_tail the last
+    200 from the same staged copy.  INT32 exact against the oracle, FLT32 inside the path's 1e-5 (column-split sums), a ragged width, accumulation into C,
+    and the conv layers' quantised aggregation (the dequantisation where the ranges' partial sums meet) -- all on the LDS-staged kernel (lds_runs says so);
+    verify = 2: the device-written code stream compared word for word with the host encoder's for the plan that sees fewer rows."""
+    n, ncols = 16 * 1824 + 200, 40000
+    rowptr, col = random_csr(rng, n, ncols, 40, empty_frac=0.05, long_rows=[(n - 7, 3000), (11, 5000), (n - 150, 0)])
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    old = _lib.set_tunable("lds_col_split_f32", 2), _lib.set_tunable("lds_codegen", verify if verify else 1)
+    try:
+        for dt, code, h in ((np.int32, _lib.INT32, 256), (np.float32, _lib.FLT32, 256), (np.int32, _lib.INT32, 200)):
+            hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+            try:
+                geo, note = _lib.group_lds_geometry(hd), _lib.group_lds_note(hd)
+                assert geo["col_splits"] == 4 and "k_lds_tail" in note and str(16 * 1824) in note, (geo, note)
+                assert _lib.group_lds_plan(hd)["tiles"] == 16 * 4
+                x = features(rng, ncols, h, dt) if dt == np.float32 else rng.integers(-1000, 1000, size=(ncols, h)).astype(np.int32)
+                out = np.full((n, h), 77, dtype=dt)
+                _lib.spmm_run_group(hd, [np.ascontiguousarray(x).ctypes.data], out.ctypes.data)
+                want = oracle.spmm_csr(rowptr, col, None, x)
+                if dt == np.int32:
+                    assert np.array_equal(out, want), h
+                    # accumulate into C through the block entry point: what was there + the product
+                    base = rng.integers(-50, 50, size=(n, h)).astype(np.int32)
+                    acc = base.copy()
+                    xd_, accd_ = torch.from_numpy(x).cuda(), torch.from_numpy(acc).cuda()
+                    _lib.block_run(hd, 0, xd_.data_ptr(), h, accd_.data_ptr(), h, h, True)
+                    torch.cuda.synchronize()
+                    acc = accd_.cpu().numpy()
+                    assert np.array_equal(acc, (base.astype(np.int64) + want.astype(np.int64)).astype(np.int32)), h
+                else:
+                    bound = oracle.spmm_csr(rowptr, col, None, np.abs(x)).astype(np.float64)
+                    assert np.all(np.abs(out.astype(np.float64) - want.astype(np.float64)) <= 1e-5 * bound + 1e-30)
+                    assert np.array_equal(out[-200:][:, :8], out[-200:][:, :8])   # (finite)
+                runs = _lib.group_lds_runs(hd)
+                assert runs >= 1
+                if h == 256:   # quantise -> aggregate -> dequantise in one device call
+                    xf = (rng.standard_normal((ncols, h)) * 3).astype(np.float32)
+                    xd, od, sd = torch.from_numpy(xf).cuda(), torch.empty((n, h), dtype=torch.float32, device="cuda"), torch.empty((), dtype=torch.float32, device="cuda")
+                    _lib.quant_spmm_run(hd, xd.data_ptr(), h, od.data_ptr(), sd.data_ptr(), 0)
+                    torch.cuda.synchronize()
+                    assert _lib.group_lds_runs(hd) == runs + 1, "the quantised aggregation of a column-split share left the LDS-staged kernel"
+                    s_ref, xq = oracle.symmetric_quantize(xf, dt)
+                    assert np.float32(sd.item()) == s_ref
+                    want_q = oracle.spmm_csr(rowptr, col, None, xq)
+                    want_f = oracle.symmetric_dequantize(want_q, 1.0, s_ref)
+                    got = od.cpu().numpy()
+                    if dt == np.int32:
+                        assert got.tobytes() == want_f.tobytes()
+                    else:
+                        bq = oracle.spmm_csr(rowptr, col, None, np.abs(xq)).astype(np.float64) * float(s_ref)
+                        assert np.all(np.abs(got.astype(np.float64) - want_f.astype(np.float64)) <= 1e-5 * bq + 1e-30)
+            finally:
+                _lib.group_free(hd)
+        # never: the share keeps three ranges and all its rows inside the plan
+        _lib.set_tunable("lds_row_tail", 0)
+        hd = _lib.group_create(_lib.CSR, _lib.INT32, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [256], 256)
+        try:
+            assert _lib.group_lds_geometry(hd)["col_splits"] == 3 and "k_lds_tail" not in _lib.group_lds_note(hd)
+        finally:
+            _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("lds_row_tail", 3)
+        _lib.set_tunable("lds_col_split_f32", old[0])
+        _lib.set_tunable("lds_codegen", old[1])
