@@ -903,6 +903,31 @@ __global__ void k_lds_reduce_deq(const T *__restrict__ part, uint32_t splits, ui
     out[r * ldo + f] = y;
 }
 
+// ... and for the 16-bit streams (INT16, and INT8 on its widened features): the ranges' partial sums are 16-bit numbers, two to a dword; their sum wraps modulo 2^16,
+// whose low byte is the modular int8 sum.  MODE 0: INT8 result (the low byte; accumulate adds what was there), 1: dequantise the int8 sum, 2: dequantise the int16 sum
+template <int MODE>
+__global__ void k_lds_reduce16(const int16_t *__restrict__ part, uint32_t splits, uint64_t nrows, uint32_t w, uint64_t ldp, void *__restrict__ C, int64_t ldc, int accumulate,
+                               const uint32_t *__restrict__ absmax_bits, int log2_range, const float *__restrict__ post_mul, const float *__restrict__ post_add, int post_relu) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * w) return;
+    const uint64_t r = i / w;
+    const uint32_t f = (uint32_t)(i % w);
+    uint32_t acc = (uint32_t)(int32_t)part[r * ldp + f];
+    for (uint32_t c = 1; c < splits; c++) acc += (uint32_t)(int32_t)part[((uint64_t)c * nrows + r) * ldp + f];
+    if constexpr (MODE == 0) {
+        int8_t *c8 = (int8_t *)C + (int64_t)r * ldc + f;
+        if (accumulate) acc += (uint32_t)(int32_t)*c8;
+        *c8 = (int8_t)acc;
+    } else {
+        float y = (float)(MODE == 1 ? (int32_t)(int8_t)acc : (int32_t)(int16_t)acc) * (1.0f * quant_scale(*absmax_bits, log2_range));
+        if (post_mul) {
+            y = post_mul[f] * y + post_add[f];
+            if (post_relu) y = fmaxf(y, 0.0f);
+        }
+        ((float *)C)[(int64_t)r * ldc + f] = y;
+    }
+}
+
 // The last rows of a row share, outside the LDS-staged plan (round 6): when tall x slices x S full-height row tiles cover all but a few percent of a share's
 // rows with EXACTLY one workgroup per compute unit (a 1/8 share of the Reddit-shaped graph: 16 tiles x 4 slices x 4 ranges = 256 workgroups for 29 184 of its
 // 29 471 rows, against 17 x 4 x 3 = 204 for all of them), the plan takes those tiles and these two kernels the remainder.  They gather from the SAME slice-major

@@ -643,3 +643,44 @@ def test_a_share_that_all_but_fits_one_workgroup_per_cu_leaves_its_last_rows_to_
         _lib.set_tunable("lds_row_tail", 3)
         _lib.set_tunable("lds_col_split_f32", old[0])
         _lib.set_tunable("lds_codegen", old[1])
+
+
+@pytest.mark.parametrize("name,npdt,code", [("INT8", np.int8, 0), ("INT16", np.int16, 1)])
+def test_column_split_shares_of_the_16_bit_streams(rng, name, npdt, code):
+    """Round 6: a short row share of an INT8 / INT16 graph is split into column ranges too.  The ranges' partial sums are the INT16 stream's packed 16-bit
+    numbers; k_lds_reduce16 adds them (modulo 2^16) and makes the result: the int8 sum's byte (plain product, also accumulating into C), or -- the conv layers'
+    quantised aggregation, models/pyg_gcn_conv.py:130-137 -- float(sum) * scale.  All exact against the oracle; lds_runs says the LDS-staged kernel ran."""
+    n, ncols, h = 2500, 30000, 256
+    rowptr, col = random_csr(rng, n, ncols, 150, empty_frac=0.1, long_rows=[(3, 9000)])
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    assert code == (_lib.INT8 if name == "INT8" else _lib.INT16)
+    hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+    try:
+        geo = _lib.group_lds_geometry(hd)
+        assert geo["col_splits"] >= 4 and _lib.group_lds_code(hd)["active"] == 1, (geo, _lib.group_lds_note(hd))
+        lim = 127 if name == "INT8" else 30000
+        x = rng.integers(-lim, lim, size=(ncols, h)).astype(npdt)      # sums wrap
+        want = oracle.spmm_csr(rowptr, col, None, x)
+        out = np.full((n, h), 77, dtype=npdt)
+        _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+        assert np.array_equal(out, want)
+        runs = _lib.group_lds_runs(hd)
+        assert runs >= 1, _lib.group_lds_note(hd)
+        if name == "INT8":   # what was in C + the product
+            base = rng.integers(-100, 100, size=(n, h)).astype(npdt)
+            xd, cd = torch.from_numpy(x).cuda(), torch.from_numpy(base.copy()).cuda()
+            _lib.block_run(hd, 0, xd.data_ptr(), h, cd.data_ptr(), h, h, True)
+            torch.cuda.synchronize()
+            assert np.array_equal(cd.cpu().numpy(), (base.astype(np.int64) + want.astype(np.int64)).astype(npdt))
+            assert _lib.group_lds_runs(hd) == runs + 1
+            runs += 1
+        xf = (rng.standard_normal((ncols, h)) * 3).astype(np.float32)
+        xd, od, sd = torch.from_numpy(xf).cuda(), torch.empty((n, h), dtype=torch.float32, device="cuda"), torch.empty((), dtype=torch.float32, device="cuda")
+        _lib.quant_spmm_run(hd, xd.data_ptr(), h, od.data_ptr(), sd.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert _lib.group_lds_runs(hd) == runs + 1, "the quantised aggregation of a column-split share left the LDS-staged kernel"
+        s_ref, xq = oracle.symmetric_quantize(xf, npdt)
+        want_f = oracle.symmetric_dequantize(oracle.spmm_csr(rowptr, col, None, xq), 1.0, s_ref)
+        assert np.float32(sd.item()) == s_ref and od.cpu().numpy().tobytes() == want_f.tobytes()
+    finally:
+        _lib.group_free(hd)
