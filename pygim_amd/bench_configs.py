@@ -14,6 +14,8 @@ the two is why a far-gather shape sits at a few percent of the HBM roofline whil
 """
 from __future__ import annotations
 
+import json
+import os
 import time
 
 import numpy as np
@@ -49,10 +51,37 @@ def _kernel_name(hd, type_name):
     return f"k_csr_panel<{type_name}> x {max(int(plan['n_panels']), 1)} panel(s) (L2 / far-gather sweep)"
 
 
-def _roofline(alg_bytes, k_ms, kernel, line_bytes, launches_note=None):
+CFG_TRAFFIC_JSON = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "cfg_traffic_latest.json")
+
+
+def _replayed_traffic(key, k_ms):
+    """HBM bytes per product of a configuration's dominant kernel from the committed counter run (scripts/cfg_pmc.sh: 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes) -- replayed, and labelled so, only when this run's kernel time is within 10 % of the counter run's"""
+    try:
+        rec = json.load(open(CFG_TRAFFIC_JSON)).get(key)
+    except Exception:  # noqa: BLE001
+        return None, None
+    if not rec:
+        return None, None
+    src = {"replayed_from": "profiles/cfg_traffic_latest.json", "collected": rec.get("collected"), "command": rec.get("command"), "kernel_ms_then": rec.get("kernel_ms_per_product"),
+           "l2_hit_rate": rec.get("l2_hit_rate")}
+    then = rec.get("kernel_ms_per_product")
+    if not then or not k_ms or abs(k_ms - then) / then > 0.10:
+        src["not_replayed"] = f"the counter run's kernel(s) took {then} ms per product, this run's {k_ms:.3f} ms: more than 10 % apart"
+        return None, src
+    return rec.get("hbm_bytes_per_product"), src
+
+
+def _roofline(alg_bytes, k_ms, kernel, line_bytes, launches_note=None, traffic_key=None):
     ach = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+    traffic, traffic_src = _replayed_traffic(traffic_key, k_ms) if traffic_key else (None, None)
+    out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
            "kernel": kernel, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)}
+    if traffic_src:
+        out["traffic_source"] = traffic_src
+    if traffic:   # what the memory system really moved, against the HBM peak: the number that says whether the kernel or the formulation is the limit
+        out["traffic_GBs"] = round(traffic / (k_ms * 1e-3) / 1e9, 1)
+        out["traffic_frac_of_hbm_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if line_bytes is not None:   # far-gather shapes: what the gathers must move at a cache line per stored entry, against the HBM peak
         out.update({"line_bytes": int(line_bytes), "line_GBs": round(line_bytes / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                     "line_frac_of_hbm_peak": round(line_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None})
@@ -122,14 +151,14 @@ def config3_products_coo(dev, stream, h=256, steps=6):
                 "ms_per_step": round(ms, 4), "value_GOPs": round(2 * m * h / (ms * 1e-3) / 1e9, 1), "group_create_ms": round(create_ms, 1),
                 "roofline": _roofline(alg, k_ms, _kernel_name(hd, "i32"), m * max(h * 4, 128) + 2 * n * h * 4,
                                       "uniform columns over a 2.5 GB operand: every stored entry pulls its own 1 KiB row of X (8 lines) from HBM / Infinity Cache; "
-                                      "line_bytes = entries x row bytes + C read and written"),
+                                      "line_bytes = entries x row bytes + C read and written", traffic_key="c3"),
                 "check": ("bit-exact: weighted column-count checksum over all rows + 800 sampled rows against the oracle's COO loop" if ok and ok_rows else "MISMATCH"),
                 "lds_note": _lib.group_lds_note(hd)[:160]}
     finally:
         _lib.group_free(hd)
 
 
-def config5_papers_slices(dev, stream, steps=3):
+def config5_papers_slices(dev, stream, steps=3, only=None):
     """configs[4]'s per-GPU work at full size (111 M rows, 1.6 G entries): the ds_parts = 8 slice (all rows x 16 of 128 features) and the 2 x 4
     grid share (the first nnz-balanced half of the rows x 32 features)"""
     import oracle
@@ -141,6 +170,8 @@ def config5_papers_slices(dev, stream, steps=3):
     res = {}
     for key, name, nrows, h in (("feature_split_1x8", "ds_parts = 8: all rows x 16 of 128 features (64-byte rows of X)", n, 16),
                                 ("grid_2x4", "2 x 4 grid: half the rows (nnz-balanced) x 32 features (128-byte rows of X)", half, 32)):
+        if only and key != only:
+            continue
         m = int(rowptr[nrows])
         x = synth.features(n, h, torch.float32, seed=0, device=dev)
         out = torch.empty((nrows, h), dtype=torch.float32, device=dev)
@@ -163,7 +194,8 @@ def config5_papers_slices(dev, stream, steps=3):
                         "value_GFLOPs": round(2 * m * h / (ms * 1e-3) / 1e9, 1), "group_create_ms": round(create_ms, 1),
                         "roofline": _roofline(alg, k_ms, _kernel_name(hd, "f32"), m * 128 + 2 * nrows * h * 4,
                                               "14.5 entries per row over 111 M uniform columns: one 128-byte line from HBM per stored entry whatever the row holds "
-                                              "(a 64-byte row of X uses half of it); line_bytes = entries x 128 + C read and written"),
+                                              "(a 64-byte row of X uses half of it); line_bytes = entries x 128 + C read and written",
+                                              traffic_key="c5a" if key == "feature_split_1x8" else "c5b"),
                         "check": ("column-count checksum exact over all rows + 400 sampled rows bit-exact against the oracle" if ok and ok_rows else "MISMATCH")}
         finally:
             _lib.group_free(hd)

@@ -38,6 +38,23 @@ for k, d in sorted(agg.items()):
         hit = d.get("TCC_HIT_sum", [0, 1])[0] / max(d.get("TCC_HIT_sum", [0, 1])[0] + d.get("TCC_MISS_sum", [0, 1])[0], 1)
         lines.append(f"    => HBM traffic per launch {hbm / 1e9:.3f} GB (2 x FETCH_SIZE + WRITE_SIZE), kernel {ms:.3f} ms in the FETCH_SIZE pass = {hbm / 1e9 / max(ms, 1e-9) :.1f} GB/ms... "
                      f"{hbm / max(ms * 1e-3, 1e-12) / 1e12:.2f} TB/s; L2 hit rate {hit:.3f}")
+# per PRODUCT: the sweep's launches (slice groups, panels) of one product together; the script prints how many products it ran
+import re, datetime
+products = None
+for f in glob.glob(sys.argv[1] + "/pass*.log"):
+    m = re.search(r"PRODUCTS (\d+)", open(f).read())
+    if m: products = int(m.group(1))
+dom = max((k for k in agg if "k_csr_panel" in k or "k_lds_code" in k), key=lambda k: agg[k].get("FETCH_SIZE", [0, 1])[0], default=None)
+if dom and products and "FETCH_SIZE" in agg[dom] and "WRITE_SIZE" in agg[dom]:
+    d = agg[dom]
+    hbm_total = (2.0 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024.0
+    rec = {"collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "command": f"rocprofv3 --pmc <one counter group per pass> -- python3 scripts/exp_cfg_one.py {sys.argv[2]} (scripts/cfg_pmc.sh)",
+           "kernel": dom, "launches_per_product": d["FETCH_SIZE"][1] / products, "hbm_bytes_per_product": hbm_total / products,
+           "kernel_ms_per_product": dur[dom][0] * 1e-6 / products if dur[dom][1] else None,
+           "l2_hit_rate": d.get("TCC_HIT_sum", [0, 1])[0] / max(d.get("TCC_HIT_sum", [0, 1])[0] + d.get("TCC_MISS_sum", [0, 1])[0], 1),
+           "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), per MI355X_MICROARCH.md HBM section"}
+    json.dump(rec, open(sys.argv[1] + "/traffic.json", "w"), indent=1)
+    lines.append("per product: " + json.dumps(rec))
 open(sys.argv[1] + "/summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY

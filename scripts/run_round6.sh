@@ -10,6 +10,17 @@ bash scripts/profile_pmc.sh round > $out/pmc.log 2>&1
 cp gpurun_out/pmc_round/summary.txt $out/pmc_summary.txt 2>/dev/null
 cp gpurun_out/pmc_round/traffic.json $out/traffic.json 2>/dev/null
 cp $out/traffic.json profiles/traffic_latest.json 2>/dev/null
+for cfg in c3 c5a c5b; do bash scripts/cfg_pmc.sh $cfg > $out/cfgpmc_$cfg.log 2>&1; cp gpurun_out/cfgpmc_$cfg/summary.txt $out/cfgpmc_${cfg}_summary.txt; done
+python3 - <<'PY'
+import json, os
+out = {}
+for cfg in ("c3", "c5a", "c5b"):
+    f = f"gpurun_out/cfgpmc_{cfg}/traffic.json"
+    if os.path.exists(f):
+        out[cfg] = json.load(open(f))
+json.dump(out, open("gpurun_out/r06/cfg_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/cfg_traffic_latest.json", "w"), indent=1)
+PY
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_under_rocprof.log 2>&1
 cd $R
@@ -17,7 +28,6 @@ find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kern
 rm -rf $out/stats
 PYGIM_PLAN_TIMING=1 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-300
-for cfg in c3 c5; do bash scripts/cfg_pmc.sh $cfg > $out/cfgpmc_$cfg.log 2>&1; cp gpurun_out/cfgpmc_$cfg/summary.txt $out/cfgpmc_${cfg}_summary.txt; done
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cfg -o cfg -- python3 $R/scripts/exp_cfg_one.py c3 > $out/cfg_c3_under_rocprof.log 2>&1
 find $out/stats_cfg -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_c3.csv; rm -rf $out/stats_cfg
