@@ -578,6 +578,8 @@ def main():
                                    "predicted_product_ms": round(prior.product_s * 1e3, 4), "predicted_collective_ms": round(prior.collective_s * 1e3, 4),
                                    "predicted_1gpu_ms": round(prior_1.seconds * 1e3, 4),
                                    "predicted_speedup_vs_1gpu": round(prior_1.seconds / prior.seconds, 3) if prior.seconds > 0 else None,
+                                   # the ranks' products alone (what one GPU can measure, profiles/r06_exp_shard.txt); the rest of the step is the exchange over xGMI
+                                   "predicted_products_only_speedup": round(prior_1.product_s / prior.product_s, 3) if prior.product_s > 0 else None,
                                    "grids_priced_ms": {f"{c.row_parts}x{c.feat_parts}": round(c.seconds * 1e3, 4) for c in table}},
                    "per_rank": per_rank,
                    **({"headline_kernel_warning": headline_warning} if headline_warning else {}),
