@@ -42,6 +42,18 @@ def test_bench_emits_one_json_line_with_the_contract_fields():
     # value = whole-job GFLOP/s of the stated workload
     flops = 2 * d["config"]["nnz"] * d["config"]["h"]
     assert abs(d["value"] - flops / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 1e-3
+    # round 6: BASELINE's other configurations beside the headline, each with its own roofline object and a check that passed
+    bc = d["baseline_configs"]
+    c3, c4, c5 = bc["configs[2]_products_coo_i32"], bc["configs[3]_reddit_gcn_3_layers_one_gpu"], bc["configs[4]_papers100m_per_gpu"]
+    for cfg in (c3, c4, c5["feature_split_1x8"], c5["grid_2x4"]):
+        assert "error" not in cfg, cfg
+        r6 = cfg["roofline"]
+        assert r6["bound"] == "hbm" and r6["peak"] == 8000.0 and r6["kernel_ms"] > 0 and abs(r6["frac"] - r6["achieved"] / r6["peak"]) < 1e-3
+        assert "MISMATCH" not in cfg["check"], cfg["check"]
+    assert c3["dtype"] == "i32" and c3["N"] == 2449029 and c3["check"].startswith("bit-exact")
+    assert c5["feature_split_1x8"]["h"] == 16 and c5["grid_2x4"]["h"] == 32 and c4["aggregations_per_forward"] == 3
+    assert d["extra"]["end_to_end_cpu_tensors_ms"] > d["ms_per_step"] and "MISMATCH" not in d["extra"]["end_to_end_cpu_tensors"]["check"]
+    assert "NOT BASELINE" in d["extra"]["note_on_structured_graphs"]
 
 
 def _parse_like_the_harness(stdout):
