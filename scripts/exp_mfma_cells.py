@@ -22,7 +22,12 @@ import torch
 import oracle
 from pygim_amd import _lib, synth
 
-L = ctypes.CDLL(os.path.join(ROOT, "scripts", "micro", "libmfma_cells.so"))
+_SO = os.path.join(ROOT, "scripts", "micro", "libmfma_cells.so")
+if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SO.replace("libmfma_cells.so", "mfma_cells.hip")):   # (a prototype: not part of the library's build)
+    import subprocess
+
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", _SO.replace("libmfma_cells.so", "mfma_cells.hip"), "-o", _SO])
+L = ctypes.CDLL(_SO)
 vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 L.mfma_cells_run.argtypes = [vp, vp, vp, vp, vp, ci, ci, i64, ci, vp]
 L.mfma_cells_lds_run.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
