@@ -23,7 +23,8 @@ for kv in filter(None, tun.split(",")):
     k, v = kv.split("=")
     assert _lib.set_tunable(k, int(v)) != -1, k
 dtn = sys.argv[2] if len(sys.argv) > 2 else "FLT32"
-tdt, code = {"FLT32": (torch.float32, _lib.FLT32), "INT32": (torch.int32, _lib.INT32), "INT8": (torch.int8, _lib.INT8), "INT16": (torch.int16, _lib.INT16)}[dtn]
+tdt, code = {"FLT32": (torch.float32, _lib.FLT32), "INT32": (torch.int32, _lib.INT32), "INT8": (torch.int8, _lib.INT8), "INT16": (torch.int16, _lib.INT16),
+             "DBL64": (torch.float64, _lib.DBL64), "INT64": (torch.int64, _lib.INT64)}[dtn]
 want = (sys.argv[3] if len(sys.argv) > 3 else "r8,h64,h32,g24,g42").split(",")
 print("#", tun or "defaults", dtn, flush=True)
 n, nnz, dmax = synth.SHAPES["reddit"]
@@ -49,7 +50,7 @@ for name in want:
     frac, h = CASES[name]
     top = nnz_balanced_row_split(rp_cpu, frac)[1]
     m = int(rp_cpu[top])
-    if tdt == torch.float32:
+    if tdt in (torch.float32, torch.float64):
         x = synth.features(n, h, tdt, seed=1, device=dev, kind="uniform")
     else:
         x = synth.features(n, h, tdt, seed=1, device=dev)
@@ -73,7 +74,7 @@ for name in want:
         cc = col[lo:hi].cpu().numpy()
         ref = oracle.spmm_csr(np.array([0, hi - lo], np.int32), cc, None, xh)[0]
         got = out[r].cpu().numpy()
-        if tdt == torch.float32:
+        if tdt in (torch.float32, torch.float64):
             bound = np.abs(xh[cc]).sum(0) + 1e-30
             worst = max(worst, float(np.max(np.abs(got.astype(np.float64) - ref.astype(np.float64)) / bound)))
             ident = ident and got.tobytes() == ref.tobytes()
