@@ -104,7 +104,6 @@ def _kernel_ms(hd, fn, reps=3):
 
 def _sampled_rows_equal(rowptr, col, vals, x, out, picks, oracle):
     rp = rowptr.to(torch.int64)
-    xh = None
     for r0, r1 in picks:
         lo, hi = int(rp[r0]), int(rp[r1])
         sub_rp = (rp[r0:r1 + 1] - lo).cpu().numpy().astype(np.int32)
@@ -116,7 +115,6 @@ def _sampled_rows_equal(rowptr, col, vals, x, out, picks, oracle):
         ref = oracle.spmm_csr(sub_rp, remap, sub_val, xs)
         if not np.array_equal(out[r0:r1].cpu().numpy(), ref):
             return False
-    del xh
     return True
 
 

@@ -632,6 +632,18 @@ def test_a_share_that_all_but_fits_one_workgroup_per_cu_leaves_its_last_rows_to_
                         assert np.all(np.abs(got.astype(np.float64) - want_f.astype(np.float64)) <= 1e-5 * bq + 1e-30)
             finally:
                 _lib.group_free(hd)
+        # a share whose last rows hold no entries at all: no segment, no gather launch -- the rows are written as zeros all the same
+        rowptr0, col0 = random_csr(rng, n, ncols, 40, long_rows=[(r, 0) for r in range(n - 200, n)])
+        rp0, ci0 = np.ascontiguousarray(rowptr0, np.int32), np.ascontiguousarray(col0, np.int32)
+        hd = _lib.group_create(_lib.CSR, _lib.INT32, [rp0.ctypes.data], [ci0.ctypes.data], None, [n], [ncols], [len(ci0)], [1], [128], 128)
+        try:
+            assert "k_lds_tail" in _lib.group_lds_note(hd)
+            x = rng.integers(-1000, 1000, size=(ncols, 128)).astype(np.int32)
+            out = np.full((n, 128), 77, dtype=np.int32)
+            _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+            assert np.array_equal(out, oracle.spmm_csr(rowptr0, col0, None, x)) and not out[-200:].any()
+        finally:
+            _lib.group_free(hd)
         # never: the share keeps three ranges and all its rows inside the plan
         _lib.set_tunable("lds_row_tail", 0)
         hd = _lib.group_create(_lib.CSR, _lib.INT32, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [256], 256)
