@@ -245,7 +245,8 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
  * 1 = never, S), "lds_col_split_f32" (FLT32 shares too -- their sums are then sums of per-range sums, inside the path's 1e-5 of |A|.|x| but not the CPU loop's bits:
  * 1 = parts of 2^20 entries and more (the default since round 6), 2 = any part, 0 = never), "lds_row_tail" (percent of a share's rows that may stay outside its LDS plan -- summed by the
  * tail kernels from the same staged copy -- when that leaves exactly one workgroup per compute unit; 0 = never), "lds_fill_tiles", "lds_split_order" (round 6: tile counts / tile order of
- * column-split plans), "lds_code_nbuf" (its LDS ring: 0 = by width and geometry, 2 = two buffers of 320 columns with a barrier at every slot boundary,
+ * column-split plans), "lds_half_split" (round 6: 1 = products of at most 32 lanes of a 4-byte type fold two column ranges into the halves of a wave -- half the staged bytes; the plan is
+ * written by the host encoder, so 0 is the default), "lds_code_nbuf" (its LDS ring: 0 = by width and geometry, 2 = two buffers of 320 columns with a barrier at every slot boundary,
  * 3 / 4 / 5 ... 10 = 192 / 160 / 128 ... 64 columns; the default is 5 x 128 for the 8-wave geometry), "lds_code_boundary" (rings of three or more
  * buffers: 0 / 1 = the workgroup meets at every slot boundary with nbuf - 1 chunks in flight, 2 = once in the middle of a slot with nbuf - 2),
  * "lds_code_waves" (waves per workgroup of a code-stream plan: 16 x 96 accumulators, 8 x 228 = taller tiles and fewer rounds of workgroups, 0 = automatic),
@@ -258,7 +259,7 @@ int pygim_group_lds_note(int64_t handle, char *out, int64_t cap);
  * READ AT GROUP CREATION (they shape the plan; changing them afterwards does not touch existing groups, and switching "lds_code" off
  * after a code-stream group was created sends that group's products to the sweep): panel_*, long_*, split_unit_pattern, narrow_vals,
  * merge_parts, lds_code, lds_codegen, lds_tile_order, lds_lp_rounds, lds_hybrid, lds_hybrid_min, lds_code_waves, lds_code_nbuf, lds_code_kc, lds_code_gsize, lds_code_nsets, lds_code_boundary, lds_waves, lds_col_split,
- * lds_col_split_f32, lds_row_tail, lds_fill_tiles, lds_split_order, lds_min_width, lds_round_tiles, lds_long_slots, lds_min_reuse_x100 and lds_mode (whether a plan is made at all), lds_threads.
+ * lds_col_split_f32, lds_row_tail, lds_fill_tiles, lds_split_order, lds_half_split, lds_min_width, lds_round_tiles, lds_long_slots, lds_min_reuse_x100 and lds_mode (whether a plan is made at all), lds_threads.
  * The others are read per product.  */
 int64_t pygim_set_tunable(const char *name, int64_t value);
 

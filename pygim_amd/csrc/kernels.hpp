@@ -1079,6 +1079,23 @@ __global__ void k_slice_pack(const T *__restrict__ X, int64_t ldx, uint32_t nrow
     }
 }
 
+// Half-split staging (round 6, LdsGeometry::half_split): products of at most 32 lanes fold TWO column ranges into the halves of a wave -- row j of the copy is
+// [X[j][0 .. 32) | X[j + H][0 .. 32)], 128 bytes each (features beyond the width and rows beyond the matrix: zeros).  One thread per 16-byte piece; 4-byte types.
+template <typename T>
+__global__ void k_slice_pack_hs(const T *__restrict__ X, int64_t ldx, uint32_t ncols, uint32_t w, uint32_t H, T *__restrict__ Xs) {
+    static_assert(sizeof(T) == 4, "4-byte element types");
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = t >> 4;
+    if (j >= H) return;
+    const uint32_t pc = (uint32_t)(t & 15);
+    const uint64_t src = pc < 8 ? j : j + H;
+    const uint32_t f0 = (pc & 7) * 4;
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (src < ncols && f0 + k < w) ? X[(int64_t)src * ldx + f0 + k] : (T)0;
+    store_vec<T, 4>(Xs + j * 64 + pc * 4, v);
+}
+
 // INT8 features for the code-stream product (round 4): the slice-major copy holds them WIDENED to 16 bits -- a slice is 128 features =
 // 256 bytes, as for INT16 -- so that the stream's packed 16-bit adds carry them; the low byte of every 16-bit sum is the int8 sum.
 // One thread: 8 features (8 bytes in, 16 bytes out).

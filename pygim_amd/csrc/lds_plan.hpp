@@ -78,6 +78,9 @@ struct LdsGeometry {
                                  // j + NBUF - 1 is issued at the start of slot j, NBUF - 1 chunks are in flight while one is read -- one more than with
                                  // the barrier in the middle of a slot -- at the price of draining the read pipeline once per slot: for plans whose
                                  // workgroups mostly land chunks (few stored entries per staged column)
+    uint32_t half_split = 0;     // (round 6) 1 = products of at most 32 lanes with TWO column ranges folded into the two halves of a wave: a staged row is
+                                 // [X[c] | X[c + H]] (128 bytes each), the plan is made of the virtual columns c mod H, its value slot carries each entry's half (0 / 1),
+                                 // the code stream adds under the lower / upper half of EXEC, and the store adds the halves (host encoder only)
     uint32_t NBUF = 2;           // chunk buffers of the LDS ring: slot j streams into buffer j % NBUF = LDS rows [KC * (j % NBUF), + KC).
                                  // The token kernels: 2 x 320 columns.  The code-stream kernels: 3 x 192 (two chunks in flight: landing a chunk
                                  // takes ~1.1 us whatever else the CU does, and with one chunk in flight that is the length of every slot)
@@ -576,7 +579,8 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             e.op(0xBF8C0F70u | (nn & 15) | (((nn >> 4) & 3) << 14));
         };
         auto wait_lgkm = [&](uint32_t n) { e.op(0xBF8CC07Fu | (std::min(n, 15u) << 8)); };
-        const bool valued = !plan.wts.empty();
+        const bool halves = geo.half_split != 0;                    // (the value slot holds the entry's half, not a value)
+        const bool valued = !plan.wts.empty() && !halves;
         // the reads in flight: groups whose LDS instructions have been issued and whose adds have not, oldest first
         std::vector<Grp> ring(NS + 1);                              // (re-used: no allocation per group)
         std::vector<uint32_t> pend;                                 // indices into ring
@@ -633,7 +637,17 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             } else if (valued)   // acc += val * x, product and sum rounded separately (no FMA), as the CPU loop: the products first (every entry has
                           // its own x register here: the multiply overwrites it)
                 for (size_t q = 0; q < g.k.size(); q++) e.op(0x0A0000FFu | (g.xr[q] << 17) | (g.xr[q] << 9), g.v[q]);   // v_mul_f32 x, <literal value>, x
+            // half-split plans: the adds of the entries whose column lies in the lower range under the lower half of EXEC (s[76:77], set by the kernel), then the
+            // upper range's under the upper half (s[78:79]); a row's entries of one range keep their order
+            for (uint32_t pass = 0; pass < (halves ? 2u : 1u); pass++) {
+            if (halves) {
+                bool any = false;
+                for (size_t q = 0; q < g.k.size() && !any; q++) any = (g.v[q] & 1u) == pass;
+                if (!any) continue;
+                e.op(0xBEFE0100u | (pass ? 78u : 76u));                                                                      // s_mov_b64 exec, s[76:77] / s[78:79]
+            }
             for (size_t q = 0; q < g.k.size() && !(valued && opcode_add == LDS_CODE_ADD_U64); q++) {   // (valued INT64: the sum is part of the v_mad_u64_u32 above)
+                if (halves && (g.v[q] & 1u) != pass) continue;
                 const uint32_t vk = Rr.acc0 + g.k[q] * (wide ? 2 : 1), vx = g.xr[q];
                 if (opcode_add == LDS_CODE_PK_ADD_U16) e.op(0xD38A4000u | vk, 0x18000000u | ((256 + vk) << 9) | (256 + vx));   // v_pk_add_u16 acc, x, acc
                 else if (opcode_add == LDS_CODE_ADD_F64) e.op(0xD2800000u | vk, (256 + vx) | ((256 + vk) << 9));             // v_add_f64 acc[0:1], x[0:1], acc[0:1]
@@ -642,6 +656,8 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
                     e.op(0x38000000u | ((vk + 1) << 17) | ((vk + 1) << 9) | (256 + vx + 1));                                  // v_addc_co_u32 acc1, vcc, x1, acc1, vcc
                 } else e.op(opcode_add | (vk << 17) | (vk << 9) | (256 + vx));
             }
+            }
+            if (halves) e.op(0xBEFE01C1u);                                                                                     // s_mov_b64 exec, -1
             pend.erase(pend.begin());
         };
         // the first NBUF - 1 chunks, then the slots
@@ -665,7 +681,7 @@ inline void lds_code_from_plan(const LdsPlanHost &plan, uint32_t opcode_add, Lds
             toks.clear();
             for (uint32_t b = 0; b < nb * B; b++) {
                 const uint32_t tk = plan.tok[at + b] & ((1u << LDS_HDR_SHIFT) - 1);
-                if ((tk & 0xFF) < KA) toks.push_back((uint64_t)tk | (valued ? (uint64_t)plan.wts[at + b] << 32 : 0));
+                if ((tk & 0xFF) < KA) toks.push_back((uint64_t)tk | ((valued || halves) ? (uint64_t)plan.wts[at + b] << 32 : 0));
             }
             at += (uint64_t)nb * B;
             // by staged column (stable): every row's entries are in column order already, so each row's order is kept; entries of

@@ -151,6 +151,11 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None, 
             a(f"v_and_b32 {VL128}, 7, %[lane]")    # lane offsets (lane % 8) * 128
             a(f"v_lshlrev_b32 {VL128}, 7, {VL128}")  # (the 8-wave shell touches with lane * 16: the same 8 lines)
         a("s_addc_u32 s85, s85, 0")
+        # half-split plans (round 6, lds_plan.hpp LdsGeometry::half_split): the stream adds under these two masks -- lanes 0..31 / lanes 32..63
+        a("s_mov_b32 s76, -1")
+        a("s_mov_b32 s77, 0")
+        a("s_mov_b32 s78, 0")
+        a("s_mov_b32 s79, -1")
         stamp(1)
         a("s_swappc_b64 s[86:87], %[code]")
         a("s_branch L_out_%=")                     # (the token loop below is not part of this form)
@@ -533,9 +538,24 @@ def body(op_add, g, ablate=0, op_mul=None, deq=None, code=False, out_kind=None, 
         a(f"s_add_u32 {PA_LO}, {PA_LO}, %[c_lo]")
         a(f"s_addc_u32 {PA_HI}, {PA_HI}, %[c_hi]")
         a(f"s_add_u32 {DLDS}, {KREG}, {i}")            # (TMP holds half of the saved exec mask here)
+        if code and not deq:
+            a("s_mov_b64 exec, -1")                    # (a half-split plan needs the accumulator's upper lanes too: the copy below is made by every lane)
         a(f"s_set_gpr_idx_on {DLDS}, gpr_idx(SRC0)")
         a(f"v_mov_b32 {VT0}, v{ACC0}")
         a("s_set_gpr_idx_off")
+        if code and not deq:
+            # half-split plans: lanes 0..31 hold the row's sum over the lower column range, lanes 32..63 over the upper one -- the row's sum is their sum
+            # (v_permlane32_swap_b32 vdst, src: lanes 0..31 of vdst <-> lanes 32..63 of src; with two copies of the accumulator one ends up [hi | hi], the
+            # other [lo | lo]); every lane takes part, the store below is masked again (vcc still holds the lanes of this slice)
+            a("s_cmp_eq_u32 %[hsplit], 0")
+            a(f"s_cbranch_scc1 L_nh{tag}_%=")
+            a(f"v_mov_b32 {VT1}, {VT0}")
+            a("s_nop 1")
+            a(f"v_permlane32_swap_b32 {VT0}, {VT1}")
+            a("s_nop 1")
+            a(f"{op_add} {VT0}, {VT1}, {VT0}")
+            a(f"L_nh{tag}_%=:")
+            a(f"s_and_b64 exec, {EX}, vcc")
         if deq:
             # the conv layers' dequantisation in the store (models/quantize.py:35-38): float(sum) * scale, as the sweep's fused store
             if deq == "i32":
@@ -614,6 +634,7 @@ struct LdsArgs {
     uint32_t piece_bytes;              // code-stream kernels: bytes of a chunk that one wave DMAs (chunk bytes / 16: the plan's ring geometry)
     uint32_t xcd_sx;                   // slices per XCD (round 5): 1 = an XCD streams ONE slice of X (X shared in its L2, a tile's code fetched by every
                                        // slice's XCDs); 2 / 4 = consecutive workgroups of an XCD are slices of the SAME tile and share its code in L2
+    uint32_t half_split;               // (round 6) the plan folds two column ranges into the halves of a wave: the store adds the halves (plain 4-byte code-stream kernels)
     uint64_t *stamps;                  // measurement build (k_lds_code8_f32_ts): four 100 MHz clock values per wave (start, stream entered, stream left, stored)
     uint32_t xcd_contig;               // 0 = an XCD takes every xcd_group-th tile; T > 0 = a contiguous run of T tiles (plans whose neighbouring tiles stage the
                                        // same chunks -- the dense half of a density split: they then meet in that XCD's L2)
@@ -750,7 +771,7 @@ def main():
                                         ("\n    const uint64_t stamps_a = (uint64_t)(a.stamps + ((uint64_t)b * NW + wave) * 4);\n"
                                          "    const uint64_t stamps_s = ((uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(stamps_a >> 32))) << 32) | "
                                          "(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)stamps_a);" if ts else ""),
-                              code_ops=((',\n          [code] "s"(code_s)' if is_code else "") + (', [stamps] "s"(stamps_s)' if ts else "")),
+                              code_ops=((',\n          [code] "s"(code_s), [hsplit] "s"(a.half_split)' if is_code else "") + (', [stamps] "s"(stamps_s)' if ts else "")),
                               piece_expr=("a.piece_bytes" if is_code else "PIECE"))
         if guard:
             text += "#endif  // PYGIM_LDS_ABLATE\n"

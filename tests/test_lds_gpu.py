@@ -696,3 +696,47 @@ def test_column_split_shares_of_the_16_bit_streams(rng, name, npdt, code):
         assert np.float32(sd.item()) == s_ref and od.cpu().numpy().tobytes() == want_f.tobytes()
     finally:
         _lib.group_free(hd)
+
+
+@pytest.mark.parametrize("h", [32, 17, 24])
+def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
+    """Round 6: a product of 17..32 lanes (all rows x 32 FLT32 features: a feature-split rank) would leave half of every 64-lane slice empty.  The half-split plan
+    folds TWO column ranges into the halves of a wave instead -- a staged row is [X[c] | X[c + H]], the stream adds under the lower / upper half of EXEC, the store
+    adds the halves -- so every tile stages half the bytes.  INT32 exact against the oracle (odd column count, empty rows, a long row, accumulation into C, a ragged
+    width), FLT32 inside 1e-5 of |A|.|x|; lds_half_split = 0 (the default: the form's plan is written by the host encoder) keeps the plain plan with the same results."""
+    n, ncols = 5000, 30001
+    rowptr, col = random_csr(rng, n, ncols, 60, empty_frac=0.1, long_rows=[(3, 9000), (n - 1, 4000)])
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    old = _lib.set_tunable("lds_col_split_f32", 2)
+    try:
+        for dt, code in ((np.int32, _lib.INT32), (np.float32, _lib.FLT32)):
+            outs = {}
+            for hs in (1, 0):
+                _lib.set_tunable("lds_half_split", hs)
+                hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+                try:
+                    note = _lib.group_lds_note(hd)
+                    assert ("half-split" in note) == bool(hs) and _lib.group_lds_code(hd)["active"] == 1, note
+                    x = features(rng, ncols, h, dt) if dt == np.float32 else rng.integers(-1000, 1000, size=(ncols, h)).astype(np.int32)
+                    if hs == 1:
+                        outs["x"] = x
+                    x = outs["x"]
+                    out = np.full((n, h), 77, dtype=dt)
+                    _lib.spmm_run_group(hd, [np.ascontiguousarray(x).ctypes.data], out.ctypes.data)
+                    assert _lib.group_lds_runs(hd) == 1, note
+                    want = oracle.spmm_csr(rowptr, col, None, x)
+                    if dt == np.int32:
+                        assert np.array_equal(out, want), (h, hs)
+                        base = rng.integers(-50, 50, size=(n, h)).astype(np.int32)
+                        xd_, accd_ = torch.from_numpy(x).cuda(), torch.from_numpy(base.copy()).cuda()
+                        _lib.block_run(hd, 0, xd_.data_ptr(), h, accd_.data_ptr(), h, h, True)
+                        torch.cuda.synchronize()
+                        assert np.array_equal(accd_.cpu().numpy(), (base.astype(np.int64) + want.astype(np.int64)).astype(np.int32)), (h, hs)
+                    else:
+                        bound = oracle.spmm_csr(rowptr, col, None, np.abs(x)).astype(np.float64)
+                        assert np.all(np.abs(out.astype(np.float64) - want.astype(np.float64)) <= 1e-5 * bound + 1e-30), (h, hs)
+                finally:
+                    _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("lds_half_split", 0)
+        _lib.set_tunable("lds_col_split_f32", old)
