@@ -708,6 +708,8 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
     rowptr, col = random_csr(rng, n, ncols, 60, empty_frac=0.1, long_rows=[(3, 9000), (n - 1, 4000)])
     rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
     old = _lib.set_tunable("lds_col_split_f32", 2)
+    old_split = _lib.set_tunable("lds_col_split", 1 if h == 24 else 0)   # (h = 24: whole-X tiles -- the kernel's own store adds the halves, and adds into C)
+    old_mode = _lib.set_tunable("lds_mode", 1 if h == 24 else 0)         # (... which the reuse rule would not plan for a matrix this small)
     try:
         for dt, code in ((np.int32, _lib.INT32), (np.float32, _lib.FLT32)):
             outs = {}
@@ -739,4 +741,6 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
                     _lib.group_free(hd)
     finally:
         _lib.set_tunable("lds_half_split", 0)
+        _lib.set_tunable("lds_col_split", old_split)
+        _lib.set_tunable("lds_mode", old_mode)
         _lib.set_tunable("lds_col_split_f32", old)
