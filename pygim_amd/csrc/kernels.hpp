@@ -903,6 +903,52 @@ __global__ void k_lds_reduce_deq(const T *__restrict__ part, uint32_t splits, ui
     out[r * ldo + f] = y;
 }
 
+// the same two kernels, four features to a thread (16-byte loads and stores), for widths and strides that are multiples of four elements: 4-byte types
+template <typename T, bool DEQ>
+__global__ void k_lds_reduce_v4(const T *__restrict__ part, uint32_t splits, uint64_t nrows, uint32_t w, uint64_t ldp, void *__restrict__ C, int64_t ldc, int accumulate,
+                                const uint32_t *__restrict__ absmax_bits, int log2_range, const float *__restrict__ post_mul, const float *__restrict__ post_add, int post_relu) {
+    static_assert(sizeof(T) == 4, "4-byte element types");
+    using A = typename AccOf<T>::type;
+    const uint32_t w4 = w >> 2;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * w4) return;
+    const uint64_t r = i / w4;
+    const uint32_t f = (uint32_t)(i % w4) * 4;
+    T v[4];
+    load_vec<T, 4>(part + r * ldp + f, v);
+    A acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = to_acc<T>(v[k]);
+    for (uint32_t c = 1; c < splits; c++) {
+        load_vec<T, 4>(part + ((uint64_t)c * nrows + r) * ldp + f, v);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = (A)(acc[k] + to_acc<T>(v[k]));
+    }
+    if constexpr (DEQ) {
+        const float scale = 1.0f * quant_scale(*absmax_bits, log2_range);
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            y[k] = (float)from_acc<T>(acc[k]) * scale;
+            if (post_mul) {
+                y[k] = post_mul[f + k] * y[k] + post_add[f + k];
+                if (post_relu) y[k] = fmaxf(y[k], 0.0f);
+            }
+        }
+        store_vec<float, 4>((float *)C + r * ldc + f, y);
+    } else {
+        T *c = (T *)C + r * ldc + f;
+        if (accumulate) {
+            load_vec<T, 4>(c, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = (A)(to_acc<T>(v[k]) + acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = from_acc<T>(acc[k]);
+        store_vec<T, 4>(c, v);
+    }
+}
+
 // ... and for the 16-bit streams (INT16, and INT8 on its widened features): the ranges' partial sums are 16-bit numbers, two to a dword; their sum wraps modulo 2^16,
 // whose low byte is the modular int8 sum.  MODE 0: INT8 result (the low byte; accumulate adds what was there), 1: dequantise the int8 sum, 2: dequantise the int16 sum
 template <int MODE>
