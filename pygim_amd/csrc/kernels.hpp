@@ -979,7 +979,7 @@ __global__ void k_lds_reduce16(const int16_t *__restrict__ part, uint32_t splits
 // 29 471 rows, against 17 x 4 x 3 = 204 for all of them), the plan takes those tiles and these two kernels the remainder.  They gather from the SAME slice-major
 // copy the LDS-staged kernel streams (256-byte row slices).  The rows are cut into SEGMENTS of at most LDS_TAIL_SEG entries at plan time (a row of 20 000 entries
 // on one workgroup would be a latency-bound chain of its own: the first form of this kernel, a workgroup per row, cost more than the extra column range saved):
-//   k_lds_tail_seg  a 512-thread workgroup per (segment, slice): wave v takes entries v, v + 8, ... of the segment, eight gathers in flight per wave; the eight
+//   k_lds_tail_seg  a 512-thread workgroup per (segment, slice): wave v takes entries v, v + 8, ... of the segment (at most 32), all their gathers in flight together; the eight
 //                   partial sums are added in wave order and parked in scratch
 //   k_lds_tail_fin  a wave per (row, slice): the row's segments in order, then the store -- plain, accumulating, or with the conv layers' dequantisation + epilogue
 // Deterministic; integers exact, FLT32 in this fixed order (these shares are column-split plans: the norm-wise contract already).
@@ -994,16 +994,20 @@ __global__ __launch_bounds__(512) void k_lds_tail_seg(const uint32_t *__restrict
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t e0 = segs[nseg + seg], e1 = segs[2 * nseg + seg];
     const char *xsl = xs + (uint64_t)slice * slice_stride + lane * 4;
-    A acc = 0;
-    uint32_t e = e0 + wave;
-    for (; e + 56 < e1; e += 64) {   // eight of this wave's entries at a time: the gathers first, then the sums in entry order
-        T x[8];
+    // a segment holds at most LDS_TAIL_SEG = 256 entries: at most 32 for this wave -- all their gathers go out together (one round trip), the sums follow in entry order
+    static_assert(LDS_TAIL_SEG == 256, "32 entries per wave");
+    uint32_t cols[32];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = *(const T *)(xsl + (uint64_t)colind[e + 8 * k] * 256);
-#pragma unroll
-        for (int k = 0; k < 8; k++) acc = (A)(acc + to_acc<T>(x[k]));
+    for (int k = 0; k < 32; k++) {
+        const uint32_t e = e0 + wave + 8u * k;
+        cols[k] = e < e1 ? colind[e] : 0xFFFFFFFFu;
     }
-    for (; e < e1; e += 8) acc = (A)(acc + to_acc<T>(*(const T *)(xsl + (uint64_t)colind[e] * 256)));
+    T x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) x[k] = cols[k] != 0xFFFFFFFFu ? *(const T *)(xsl + (uint64_t)cols[k] * 256) : (T)0;
+    A acc = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc = (A)(acc + to_acc<T>(x[k]));   // (entries beyond the segment add an exact zero)
     partial[wave][lane] = acc;
     __syncthreads();
     if (wave != 0) return;
