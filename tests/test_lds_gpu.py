@@ -744,3 +744,44 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
         _lib.set_tunable("lds_col_split", old_split)
         _lib.set_tunable("lds_mode", old_mode)
         _lib.set_tunable("lds_col_split_f32", old)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shares_around_the_tile_multiples(seed):
+    """Round 6, randomised: row counts just above a whole number of full-height tiles (where the plan leaves the last rows to the tail kernels), random degrees (long rows in
+    the tail included), 256 / 192 / 64 features, INT32 exact and FLT32 inside 1e-5 of |A|.|x| against the oracle; every code stream also compared word for word with the
+    host encoder's (lds_codegen = 2)."""
+    r = np.random.default_rng(9000 + seed)
+    h = int(r.choice([256, 192, 64]))
+    nsl = (h + 63) // 64
+    S2 = int(r.choice([8, 4])) if nsl > 1 else 8
+    tall2 = 256 // (nsl * S2)
+    n = tall2 * 1824 + int(r.integers(1, max(2, int(0.028 * tall2 * 1824))))
+    ncols = int(r.integers(6000, 20000))
+    deg = float(r.uniform(4, 12)) if nsl == 1 else float(r.uniform(8, 40))
+    longs = [(int(n - 1 - r.integers(0, 20)), int(r.integers(1500, 5000))), (int(r.integers(0, 100)), 3000)]
+    rowptr, col = random_csr(r, n, ncols, deg, empty_frac=0.1, long_rows=longs)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    old = _lib.set_tunable("lds_col_split_f32", 2), _lib.set_tunable("lds_codegen", 2), _lib.set_tunable("lds_mode", 1)
+    try:
+        for dt, code in ((np.int32, _lib.INT32), (np.float32, _lib.FLT32)):
+            hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+            try:
+                note = _lib.group_lds_note(hd)
+                assert "k_lds_tail" in note, (n, h, note)
+                x = features(r, ncols, h, dt) if dt == np.float32 else r.integers(-10000, 10000, size=(ncols, h)).astype(np.int32)
+                out = np.full((n, h), 77, dtype=dt)
+                _lib.spmm_run_group(hd, [np.ascontiguousarray(x).ctypes.data], out.ctypes.data)
+                assert _lib.group_lds_runs(hd) == 1
+                want = oracle.spmm_csr(rowptr, col, None, x)
+                if dt == np.int32:
+                    assert np.array_equal(out, want), (seed, n, h)
+                else:
+                    bound = oracle.spmm_csr(rowptr, col, None, np.abs(x)).astype(np.float64)
+                    assert np.all(np.abs(out.astype(np.float64) - want.astype(np.float64)) <= 1e-5 * bound + 1e-30), (seed, n, h)
+            finally:
+                _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("lds_col_split_f32", old[0])
+        _lib.set_tunable("lds_codegen", old[1])
+        _lib.set_tunable("lds_mode", old[2])
