@@ -26,6 +26,7 @@ dtn = sys.argv[2] if len(sys.argv) > 2 else "FLT32"
 tdt, code = {"FLT32": (torch.float32, _lib.FLT32), "INT32": (torch.int32, _lib.INT32), "INT8": (torch.int8, _lib.INT8), "INT16": (torch.int16, _lib.INT16),
              "DBL64": (torch.float64, _lib.DBL64), "INT64": (torch.int64, _lib.INT64)}[dtn]
 want = (sys.argv[3] if len(sys.argv) > 3 else "r8,h64,h32,g24,g42").split(",")
+QUANT = len(sys.argv) > 4 and sys.argv[4] == "quant"   # time the conv layers' quantise -> aggregate -> dequantise (pygim_quant_spmm_run) instead of the plain product
 print("#", tun or "defaults", dtn, flush=True)
 n, nnz, dmax = synth.SHAPES["reddit"]
 rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
@@ -56,6 +57,23 @@ for name in want:
         x = synth.features(n, h, tdt, seed=1, device=dev)
     out = torch.empty((top, h), dtype=tdt, device=dev)
     hd = _lib.group_create(_lib.CSR, code, [rowptr.data_ptr()], [col.data_ptr()], None, [top], [n], [m], [1], [h], h)
+    if QUANT:
+        xf = torch.randn((n, h), device=dev)
+        of = torch.empty((top, h), dtype=torch.float32, device=dev)
+        sc = torch.empty((), dtype=torch.float32, device=dev)
+        runs0 = _lib.group_lds_runs(hd)
+        for _ in range(3):
+            _lib.quant_spmm_run(hd, xf.data_ptr(), h, of.data_ptr(), sc.data_ptr(), 0)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(9):
+            a.record(); _lib.quant_spmm_run(hd, xf.data_ptr(), h, of.data_ptr(), sc.data_ptr(), 0); b.record(); b.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        print(f"{name:5s} rows 1/{frac} ({top}), h={h}: quantise -> aggregate -> dequantise {ts[4]:6.3f} ms  on the LDS-staged kernel: {_lib.group_lds_runs(hd) > runs0}  [{_lib.group_lds_note(hd)[:90]}]", flush=True)
+        _lib.group_free(hd)
+        continue
     t = timed(hd, x, out)
     _lib.group_kernel_events(hd, True)
     _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), 0)
