@@ -19,7 +19,7 @@ EXPORTS = [
     "pygim_quant_absmax", "pygim_quantize", "pygim_dequantize", "pygim_spmm_run_group_x", "pygim_block_run_x",
     "pygim_group_kernel_events", "pygim_group_plan", "pygim_spmm_run_dequant",
     "pygim_quant_spmm_run_post", "pygim_generation", "pygim_group_lds_plan", "pygim_group_lds_code", "pygim_group_lds_geometry", "pygim_group_lds_note",
-    "pygim_group_lds_tiles", "pygim_group_lds_runs", "pygim_group_serial",
+    "pygim_group_lds_tiles", "pygim_group_lds_runs", "pygim_group_serial", "pygim_group_host_windows",
 ]
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED = 0, 1, 2, 3, 4
@@ -77,6 +77,7 @@ def lib():
         L.pygim_group_lds_note.argtypes = [c_i64, ctypes.c_char_p, c_i64]
         L.pygim_group_lds_tiles.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_runs.argtypes = [c_i64, p_i64]
+        L.pygim_group_host_windows.argtypes = [c_i64, p_i64]
         L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
@@ -219,6 +220,13 @@ def group_lds_runs(handle):
     """products (or blocks) the LDS-staged kernels served for this group so far"""
     out = ctypes.c_int64(0)
     check(lib().pygim_group_lds_runs(int(handle), ctypes.byref(out)))
+    return int(out.value)
+
+
+def group_host_windows(handle):
+    """feature windows the last run with host operands moved as a pipeline (1 = upload, product, download one after the other)"""
+    out = ctypes.c_int64(0)
+    check(lib().pygim_group_host_windows(int(handle), ctypes.byref(out)))
     return int(out.value)
 
 

@@ -283,10 +283,33 @@ def end_to_end_cpu_tensors(rowptr, col, n, h, steps=4):
         ts.sort()
         dev_x = x.cuda()
         want = A.mul(dev_x).cpu()
+        windows = _lib.group_host_windows(A.sp_info_ptr)
+        timers = _lib.group_timers(A.sp_info_ptr)
+        # the same call with upload, product and download one after the other (what every round before this one measured)
+        prev = _lib.set_tunable("host_windows", 1)
+        try:
+            A.mul(x)
+            serial = []
+            for _ in range(steps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out1 = A.mul(x)
+                torch.cuda.synchronize()
+                serial.append((time.perf_counter() - t0) * 1e3)
+            serial.sort()
+        finally:
+            _lib.set_tunable("host_windows", prev)
+        dev_x = x.cuda()
+        want = A.mul(dev_x).cpu()
+        ok = out.device.type == "cpu" and torch.equal(out, want) and torch.equal(out1, want)
         return {"ms_per_mul": round(ts[len(ts) // 2], 3), "ms_per_mul_min": round(ts[0], 3), "steps": steps,
+                "feature_windows": windows, "ms_until_x_is_up": round(timers[0], 3), "ms_last_product_after_that": round(timers[1], 3),
+                "ms_last_download_after_that": round(timers[2], 3), "ms_per_mul_serial": round(serial[len(serial) // 2], 3),
                 "bytes_host_to_device": n * h * 4, "bytes_device_to_host": n * h * 4,
-                "check": "equal to the device-resident product, element by element" if out.device.type == "cpu" and torch.equal(out, want) else "MISMATCH",
+                "check": "equal to the device-resident product, element by element (pipelined and serial)" if ok else "MISMATCH",
                 "note": "Reddit-shaped CSR FLT32 h = 256, CPU tensors in and out through backend_pim.spmm.SparseTensorCOO.mul (pageable X, pinned result): "
-                        "host -> device of X, slice pack + product, device -> host of C; outside the timed region"}
+                        "two windows of 128 features -- window 1 goes up while window 0 is multiplied and comes down (rt_run.inc run_group_windows; "
+                        "bit-identical: a feature window keeps each row's stored order); ms_per_mul_serial = upload, product, download one after the other "
+                        "(tunable host_windows = 1); outside the timed region"}
     finally:
         A.free_group()

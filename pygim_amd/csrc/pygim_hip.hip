@@ -143,6 +143,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "coo_chunk") slot = &g_tune.coo_chunk;
     else if (n == "coo_via_rowptr") slot = &g_tune.coo_via_rowptr;
     else if (n == "kernel_events") slot = &g_tune.kernel_events;
+    else if (n == "host_windows") slot = &g_tune.host_windows;
     else if (n == "panel_mode") slot = &g_tune.panel_mode;
     else if (n == "panel_bytes") slot = &g_tune.panel_bytes;
     else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
@@ -541,6 +542,13 @@ int pygim_group_lds_runs(int64_t handle, int64_t *out) {
     Group *g = lookup(handle);
     if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
     *out = g->lds_runs;
+    return 0;
+}
+
+int pygim_group_host_windows(int64_t handle, int64_t *out) {
+    Group *g = lookup(handle);
+    if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    *out = g->host_windows_used;
     return 0;
 }
 

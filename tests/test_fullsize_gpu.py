@@ -92,6 +92,39 @@ def test_reddit_csr_f32_h256():
         _lib.group_free(hd)
 
 
+def test_reddit_default_call_with_cpu_tensors_is_a_pipeline_of_two_feature_windows():
+    """the reference driver's default call at the benchmark's size (spmm_test.py:29-35: CPU tensors in, a CPU tensor back): through the Python surface the
+    238.6 MB of X go up and the 238.6 MB of C come down as two windows of 128 features around two half-width products (run_group_windows) -- bit-identical
+    to the device-resident product (real-valued features: a window keeps each row's stored order), for a pageable and for a page-locked X; the serial call
+    (host_windows = 1) gives the same bits"""
+    from pygim_amd import pim_ops
+    from pygim_amd.backend_pim import spmm as spmm_mod
+    from pygim_amd.sparse_tensor import SparseTensorShim
+
+    dev = torch.device("cuda", 0)
+    n, nnz, d_max = synth.SHAPES["reddit"]
+    h = 256
+    rowptr, col = synth.make_csr(n, nnz, d_max, seed=0, device=dev)
+    pim_ops.load("spmm")
+    A = spmm_mod.SparseTensorCOO(SparseTensorShim(rowptr=rowptr, col=col, sparse_sizes=(n, n)), dtype=torch.float32, format="CSR")
+    A.to_pim_group(h, 1)
+    try:
+        x = synth.features(n, h, torch.float32, seed=1, kind="uniform")
+        want = A.mul(x.to(dev)).cpu()
+        for xin in (x, x.pin_memory()):
+            out = A.mul(xin)
+            assert out.device.type == "cpu" and _lib.group_host_windows(A.sp_info_ptr) == 2
+            assert torch.equal(out, want)
+        old = _lib.set_tunable("host_windows", 1)
+        try:
+            out = A.mul(x)
+            assert _lib.group_host_windows(A.sp_info_ptr) == 1 and torch.equal(out, want)
+        finally:
+            _lib.set_tunable("host_windows", old)
+    finally:
+        A.free_group()
+
+
 def test_products_coo_i32_h256():
     """configs[2]: ogbn-products-shaped COO, h = 256, INT32, bit-exact"""
     dev = torch.device("cuda", 0)

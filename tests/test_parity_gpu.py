@@ -180,6 +180,64 @@ def test_group_partitions(rng, fmt, sp_parts, ds_parts):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("dt", ALL_DTYPES)
+def test_host_operands_as_a_pipeline_of_feature_windows(rng, dt):
+    """the reference driver's default call (spmm_test.py:29-35: CPU tensors in, a CPU tensor back, pytorch_api.cpp:269-271) as a pipeline of feature
+    windows (rt_run.inc run_group_windows): 2 / 3 / 4 windows and the caller's own feature blocks (ds_parts), one sparse part and three (the merged
+    matrix), CSR and COO, the result in pageable and in page-locked memory -- equal to the oracle AND, bit for bit, to the serial call; the group
+    reports how many windows the call really moved"""
+    npdt = NP_DTYPES[dt]
+    es = np.dtype(npdt).itemsize
+    n = 700
+    for h, fmt, bounds in ((256, "CSR", [0, n]), (200, "COO", [0, n]), (320, "CSR", [0, 250, 251, n])):
+        rowptr, col = random_csr(rng, n, n, 11, long_rows=[(5, 2300)])
+        x = driver_features(rng, n, h, npdt)
+        if np.dtype(npdt).kind == "f":
+            x = (x + rng.random((n, h))).astype(npdt)
+        a = sp.csr_matrix((np.ones(len(col), dtype=np.int64), col.copy(), rowptr.copy()), shape=(n, n))
+        idx0, cols, nrows, ncols = [], [], [], []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            blk = a[:, lo:hi].tocsr()
+            blk.sort_indices()
+            rows_of = np.repeat(np.arange(n), np.diff(blk.indptr))
+            idx0.append(np.ascontiguousarray(blk.indptr if fmt == "CSR" else rows_of, dtype=np.int32))
+            cols.append(np.ascontiguousarray(blk.indices, dtype=np.int32))
+            nrows.append(n)
+            ncols.append(hi - lo)
+        # (duplicates were summed by scipy's slicing?  no: csr slicing keeps them; the reference multiplies a unit pattern, so weights stay 1 per stored entry)
+        ref = oracle.group(fmt == "COO", idx0, cols, None, nrows, ncols, [x], h)
+        slices = (h * es + 255) // 256
+        for ds_parts in (1, 3):
+            xs = [np.ascontiguousarray(t.numpy()) for t in torch.chunk(torch.from_numpy(x), ds_parts, 1)] if ds_parts > 1 else [x]
+            widths = [t.shape[1] for t in xs]
+            hd = _lib.group_create(_lib.COO if fmt == "COO" else _lib.CSR, CODE[dt], [_ptr(i) for i in idx0], [_ptr(c) for c in cols], None, nrows, ncols,
+                                   [len(c) for c in cols], [len(xs)] * len(cols), widths * len(cols), h)
+            try:
+                outs = {}
+                for hw in (1, 2, 3, 4):
+                    old = _lib.set_tunable("host_windows", hw)
+                    try:
+                        for pinned in (False, True):
+                            out_t = torch.full((n, h), 77, dtype=torch.from_numpy(x).dtype, pin_memory=pinned)
+                            _lib.spmm_run_group(hd, [_ptr(t) for t in xs], out_t.data_ptr())
+                            want_windows = 1 if hw == 1 else (len(xs) if ds_parts > 1 else min(hw, slices))
+                            assert _lib.group_host_windows(hd) == want_windows, (dt, h, fmt, ds_parts, hw)
+                            outs[(hw, pinned)] = out_t.numpy().copy()
+                    finally:
+                        _lib.set_tunable("host_windows", old)
+                for key, got in outs.items():
+                    assert np.array_equal(got, outs[(1, False)]), (dt, h, fmt, ds_parts, key, "differs from the serial call")
+                if np.dtype(npdt).kind == "f":
+                    scale = abs_scale(np.concatenate([[0], np.cumsum(np.diff(rowptr))]).astype(np.int32), col, None, x)
+                    assert np.all(np.abs(outs[(1, False)].astype(np.float64) - ref.astype(np.float64)) <= 1e-5 * scale + 1e-30)
+                else:
+                    assert np.array_equal(outs[(1, False)], ref), (dt, h, fmt, ds_parts)
+            finally:
+                _lib.group_free(hd)
+    # small operands keep the serial call when nothing is forced
+    assert _lib.set_tunable("host_windows", 0) == 0
+
+
 def test_device_pointers_and_block_run(rng):
     """device-resident operands: no staging, result stays in HBM"""
     npdt = np.float32
