@@ -226,10 +226,11 @@ int pygim_group_lds_tiles(int64_t handle, int64_t out[4]);
  * kernel per build, spmm_default/dpu_kernels/spmm_mul_csr_dpu.c, so nothing to ask there) */
 int pygim_group_lds_runs(int64_t handle, int64_t *out);
 /* host operands (the reference driver's default call, spmm_test.py:29-35 with CPU tensors; spmm_default/pytorch_api.cpp:269-271 returns one): how many
- * feature windows the LAST run of this group moved as a pipeline -- window k + 1 uploaded while window k is multiplied and window k - 1 is downloaded
- * (tunable "host_windows"); 1 = upload, product and download one after the other; 0 = no run with host operands yet.  A window is a
- * column range of X and of C: every row's sum keeps its stored order */
-int pygim_group_host_windows(int64_t handle, int64_t *out);
+ * feature windows the LAST run of this group moved as a pipeline -- window k + 1 uploaded while window k is multiplied and its result travels back
+ * (tunable "host_windows"); 1 = upload, product and download one after the other; 0 = no run with host operands yet.  A window is a column range of X
+ * and of C: every row's sum keeps its stored order.  *direct (may be NULL): 1 when the windows' products stored their rows straight into the caller's
+ * page-locked result (tunable "host_direct"), 0 when the result was staged in device memory and copied down */
+int pygim_group_host_windows(int64_t handle, int64_t *windows, int64_t *direct);
 /* geometry of that schedule, as the library planned it (callers price staged bytes from THIS, not from assumed constants):
  * waves per workgroup, accumulators (rows) per wave, columns per chunk (chunk bytes = 256 x this), chunk buffers of the LDS ring,
  * staged columns per group of reads and x-register sets of a code stream (0 0 for a token plan), stored entries served by another

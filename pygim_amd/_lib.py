@@ -77,7 +77,7 @@ def lib():
         L.pygim_group_lds_note.argtypes = [c_i64, ctypes.c_char_p, c_i64]
         L.pygim_group_lds_tiles.argtypes = [c_i64, p_i64]
         L.pygim_group_lds_runs.argtypes = [c_i64, p_i64]
-        L.pygim_group_host_windows.argtypes = [c_i64, p_i64]
+        L.pygim_group_host_windows.argtypes = [c_i64, p_i64, p_i64]
         L.pygim_generation.restype = c_i64
         L.pygim_quant_spmm_run.argtypes = [c_i64, vp, c_i64, vp, vp, vp]
         L.pygim_quant_spmm_run_post.argtypes = [c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp]
@@ -225,9 +225,14 @@ def group_lds_runs(handle):
 
 def group_host_windows(handle):
     """feature windows the last run with host operands moved as a pipeline (1 = upload, product, download one after the other)"""
-    out = ctypes.c_int64(0)
-    check(lib().pygim_group_host_windows(int(handle), ctypes.byref(out)))
-    return int(out.value)
+    return group_host_call(handle)["windows"]
+
+
+def group_host_call(handle):
+    """... and whether their products stored straight into the caller's page-locked result (``direct``)"""
+    w, d = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib().pygim_group_host_windows(int(handle), ctypes.byref(w), ctypes.byref(d)))
+    return {"windows": int(w.value), "direct": int(d.value)}
 
 
 def group_lds_geometry(handle):

@@ -272,18 +272,20 @@ def end_to_end_cpu_tensors(rowptr, col, n, h, steps=4):
     A.to_pim_group(h, 1)
     x = synth.features(n, h, torch.float32, seed=0)   # pageable host memory, as the driver's torch.randint gives
     try:
-        out = A.mul(x)
+        out = A.mul(x)   # (untimed: the first result tensor is a fresh page-locked allocation)
         ts = []
-        for _ in range(steps):
+        for _ in range(steps + 2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = A.mul(x)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
-        ts.sort()
+        ts_order = list(ts)
+        ts = sorted(ts[2:])   # (the first calls of a group may still be settling between the copies and the direct stores: rt_run.inc)
         dev_x = x.cuda()
         want = A.mul(dev_x).cpu()
-        windows = _lib.group_host_windows(A.sp_info_ptr)
+        call = _lib.group_host_call(A.sp_info_ptr)
+        windows = call["windows"]
         timers = _lib.group_timers(A.sp_info_ptr)
         # the same call with upload, product and download one after the other (what every round before this one measured)
         prev = _lib.set_tunable("host_windows", 1)
@@ -303,7 +305,7 @@ def end_to_end_cpu_tensors(rowptr, col, n, h, steps=4):
         want = A.mul(dev_x).cpu()
         ok = out.device.type == "cpu" and torch.equal(out, want) and torch.equal(out1, want)
         return {"ms_per_mul": round(ts[len(ts) // 2], 3), "ms_per_mul_min": round(ts[0], 3), "steps": steps,
-                "feature_windows": windows, "ms_until_x_is_up": round(timers[0], 3), "ms_last_product_after_that": round(timers[1], 3),
+                "feature_windows": windows, "direct_stores": call["direct"], "ms_each_call": [round(t, 2) for t in ts_order], "ms_until_x_is_up": round(timers[0], 3), "ms_last_product_after_that": round(timers[1], 3),
                 "ms_last_download_after_that": round(timers[2], 3), "ms_per_mul_serial": round(serial[len(serial) // 2], 3),
                 "bytes_host_to_device": n * h * 4, "bytes_device_to_host": n * h * 4,
                 "check": "equal to the device-resident product, element by element (pipelined and serial)" if ok else "MISMATCH",

@@ -144,6 +144,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "coo_via_rowptr") slot = &g_tune.coo_via_rowptr;
     else if (n == "kernel_events") slot = &g_tune.kernel_events;
     else if (n == "host_windows") slot = &g_tune.host_windows;
+    else if (n == "host_direct") slot = &g_tune.host_direct;
     else if (n == "panel_mode") slot = &g_tune.panel_mode;
     else if (n == "panel_bytes") slot = &g_tune.panel_bytes;
     else if (n == "panel_min_seg") slot = &g_tune.panel_min_seg;
@@ -545,10 +546,11 @@ int pygim_group_lds_runs(int64_t handle, int64_t *out) {
     return 0;
 }
 
-int pygim_group_host_windows(int64_t handle, int64_t *out) {
+int pygim_group_host_windows(int64_t handle, int64_t *windows, int64_t *direct) {
     Group *g = lookup(handle);
-    if (!g || !out) return fail(PYGIM_ERR_INVALID, "unknown group handle");
-    *out = g->host_windows_used;
+    if (!g || !windows) return fail(PYGIM_ERR_INVALID, "unknown group handle");
+    *windows = g->host_windows_used;
+    if (direct) *direct = g->host_direct_used;
     return 0;
 }
 

@@ -52,15 +52,47 @@ out_pin = torch.empty((n, h), dtype=tdt, pin_memory=True)
 out_page = torch.empty((n, h), dtype=tdt)
 for xname, x in (("pageable X", x_page), ("page-locked X", x_pin)):
     for oname, out in (("page-locked C", out_pin), ("pageable C", out_page)):
-        for hw in (1, 0, 2, 3, 4):
-            if True:
-                _lib.set_tunable("host_windows", hw)
-                out.zero_()
-                med, best = run(x, out)
-                used = _lib.group_host_windows(hd)
-                t = _lib.group_timers(hd)
-                ok = torch.equal(out, want)
-                print(f"{xname:14s} {oname:14s} host_windows={hw} (ran {used})  {med:7.3f} ms  (min {best:7.3f})  "
-                      f"up {t[0]:.2f} + product tail {t[1]:.2f} + down tail {t[2]:.2f}  {'equal to the device-resident product' if ok else 'MISMATCH'}", flush=True)
+        for hw, direct in ((1, 0), (0, 1), (0, 2), (2, 2), (4, 2), (0, 0), (2, 0), (3, 0), (4, 0)):
+            if oname == "pageable C" and direct:
+                continue
+            _lib.set_tunable("host_windows", hw)
+            _lib.set_tunable("host_direct", direct)
+            out.zero_()
+            med, best = run(x, out)
+            used = _lib.group_host_call(hd)
+            t = _lib.group_timers(hd)
+            ok = torch.equal(out, want)
+            how = "stores straight into C" if used["direct"] else "staged C, DMA engines" if used["windows"] > 1 else "serial"
+            print(f"{xname:14s} {oname:14s} host_windows={hw} host_direct={direct} (ran {used['windows']} windows, {how})  {med:7.3f} ms  (min {best:7.3f})  "
+                  f"up {t[0]:.2f} + product tail {t[1]:.2f} + down tail {t[2]:.2f}  {'equal to the device-resident product' if ok else 'MISMATCH'}", flush=True)
+_lib.set_tunable("host_direct", 1)
 _lib.set_tunable("host_windows", 0)
 _lib.group_free(hd)
+
+# ---- the same call through the Python surface (backend_pim.spmm.SparseTensorCOO.mul): the result tensor is a NEW page-locked tensor per call (pim_ops._new_out)
+from pygim_amd import pim_ops
+from pygim_amd.backend_pim import spmm as spmm_mod
+from pygim_amd.sparse_tensor import SparseTensorShim
+
+if dtn == "FLT32":
+    pim_ops.load("spmm")
+    A = spmm_mod.SparseTensorCOO(SparseTensorShim(rowptr=rowptr, col=col, sparse_sizes=(n, n)), dtype=tdt, format="CSR")
+    A.to_pim_group(h, 1)
+    for hw in (1, 0):
+        _lib.set_tunable("host_windows", hw)
+        for keep in (False, True):
+            held = []
+            ts = []
+            for it in range(8):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = A.mul(x_page)
+                ts.append((time.perf_counter() - t0) * 1e3)
+                if keep:
+                    held.append(out)    # (every result stays alive: the allocator must hand out fresh blocks)
+            t = _lib.group_timers(A.sp_info_ptr)
+            print(f"wrapper  host_windows={hw} results {'kept alive' if keep else 'dropped'}: " + " ".join(f"{v:.2f}" for v in ts) +
+                  f"   last call: up {t[0]:.2f} + product tail {t[1]:.2f} + down tail {t[2]:.2f}  ptr of the last result {out.data_ptr():#x}", flush=True)
+            del held
+    _lib.set_tunable("host_windows", 0)
+    A.free_group()

@@ -96,7 +96,7 @@ def test_reddit_default_call_with_cpu_tensors_is_a_pipeline_of_two_feature_windo
     """the reference driver's default call at the benchmark's size (spmm_test.py:29-35: CPU tensors in, a CPU tensor back): through the Python surface the
     238.6 MB of X go up and the 238.6 MB of C come down as two windows of 128 features around two half-width products (run_group_windows) -- bit-identical
     to the device-resident product (real-valued features: a window keeps each row's stored order), for a pageable and for a page-locked X; the serial call
-    (host_windows = 1) gives the same bits"""
+    (host_windows = 1) and the direct mode (host_direct = 2: no staged C, the kernel stores into the host tensor) give the same bits"""
     from pygim_amd import pim_ops
     from pygim_amd.backend_pim import spmm as spmm_mod
     from pygim_amd.sparse_tensor import SparseTensorShim
@@ -121,6 +121,16 @@ def test_reddit_default_call_with_cpu_tensors_is_a_pipeline_of_two_feature_windo
             assert _lib.group_host_windows(A.sp_info_ptr) == 1 and torch.equal(out, want)
         finally:
             _lib.set_tunable("host_windows", old)
+        # the direct mode (the products' store stage writes the page-locked result itself: what a group turns to when the runtime's pitched copies to
+        # the host run slow) and the staged-C copies, each forced
+        for direct in (2, 0):
+            old = _lib.set_tunable("host_direct", direct)
+            try:
+                out = A.mul(x)
+                assert _lib.group_host_call(A.sp_info_ptr) == {"windows": 2, "direct": 1 if direct else 0}
+                assert torch.equal(out, want)
+            finally:
+                _lib.set_tunable("host_direct", old)
     finally:
         A.free_group()
 

@@ -297,6 +297,93 @@ def test_all_six_types_with_the_lds_path_forced(rng, lds_forced, dt):
         assert out.tobytes() == oracle.spmm_csr(rowptr, col, v, x).tobytes(), (dt, v is not None)
 
 
+@pytest.mark.parametrize("dt", ["INT8", "INT16", "INT32", "INT64", "FLT32", "DBL64"])
+def test_host_windows_store_straight_into_the_page_locked_result(rng, lds_forced, dt):
+    """the host-operand pipeline's DIRECT mode (rt_run.inc run_group_windows, tunable host_direct = 2): each feature window's product is one pass of the
+    LDS-staged kernel whose store stage writes the caller's page-locked tensor itself -- every val_dt, unit weights and values, column-split shares (the
+    reduce kernel then does the writing) -- byte-equal to the oracle and to the staged-C pipeline; a result in pageable memory, or a group without an
+    LDS-staged plan, keeps the copies (and says so)"""
+    from conftest import NP_DTYPES
+
+    npdt = NP_DTYPES[dt]
+    es = np.dtype(npdt).itemsize
+    code = {"INT8": _lib.INT8, "INT16": _lib.INT16, "INT32": _lib.INT32, "INT64": _lib.INT64, "FLT32": _lib.FLT32, "DBL64": _lib.DBL64}[dt]
+    n, ncols = 2100, 1900
+    h = 1024 // es if es < 8 else 192          # 4 slices of 256 bytes (8-byte types: 3 of 512)
+    rowptr, col = random_csr(rng, n, ncols, 14, empty_frac=0.2, long_rows=[(9, 400)])
+    if np.issubdtype(npdt, np.floating):
+        x = (rng.random((ncols, h)) * 2 - 1).astype(npdt)
+        vals = (rng.random(len(col)) * 2 - 1).astype(npdt)
+    else:
+        info = np.iinfo(npdt)
+        x = rng.integers(info.min, info.max, size=(ncols, h), dtype=np.int64, endpoint=True).astype(npdt)
+        vals = rng.integers(info.min, info.max, size=len(col), dtype=np.int64, endpoint=True).astype(npdt)
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    tdt = torch.from_numpy(x).dtype
+    old_d = _lib.set_tunable("host_direct", 2)
+    try:
+        for v, split in ((None, 0), (vals, 0), (None, 3)):
+            if split and dt in ("INT64", "DBL64"):
+                continue   # (8-byte plans have no column ranges)
+            old_s = _lib.set_tunable("lds_col_split", split)
+            old_f = _lib.set_tunable("lds_col_split_f32", 2 if split else 1)
+            try:
+                hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None if v is None else [v.ctypes.data], [n], [ncols],
+                                       [len(ci)], [1], [h], h)
+            finally:
+                _lib.set_tunable("lds_col_split", old_s)
+                _lib.set_tunable("lds_col_split_f32", old_f)
+            try:
+                assert _lib.group_lds_plan(hd)["tiles"] > 0, dt
+                ref = oracle.spmm_csr(rowptr, col, v, x)
+                got = {}
+                for hw in (2, 4):
+                    old_w = _lib.set_tunable("host_windows", hw)
+                    try:
+                        for direct in (2, 0):
+                            _lib.set_tunable("host_direct", direct)
+                            out = torch.full((n, h), 77, dtype=tdt, pin_memory=True)
+                            runs = _lib.group_lds_runs(hd)
+                            _lib.spmm_run_group(hd, [x.ctypes.data], out.data_ptr())
+                            call = _lib.group_host_call(hd)
+                            assert call["windows"] == min(hw, (h * es + 255) // 256) and call["direct"] == (1 if direct else 0), (dt, hw, direct, call)
+                            assert _lib.group_lds_runs(hd) == runs + call["windows"]   # (every window took the LDS-staged kernel)
+                            got[(hw, direct)] = out.numpy().copy()
+                        _lib.set_tunable("host_direct", 2)
+                        out = np.full((n, h), 77, dtype=npdt)   # pageable: the copies
+                        _lib.spmm_run_group(hd, [x.ctypes.data], out.ctypes.data)
+                        assert _lib.group_host_call(hd) == {"windows": min(hw, (h * es + 255) // 256), "direct": 0}
+                        got[(hw, "pageable")] = out
+                    finally:
+                        _lib.set_tunable("host_windows", old_w)
+                for key, o in got.items():
+                    if split and np.issubdtype(npdt, np.floating):   # (a row's sum = the sum of its ranges' sums: the norm-wise contract)
+                        assert o.tobytes() == got[(2, 0)].tobytes(), (dt, key)
+                        scale = np.abs(oracle.spmm_csr(rowptr, col, None, np.abs(x)).astype(np.float64))
+                        assert np.all(np.abs(o.astype(np.float64) - ref.astype(np.float64)) <= 1e-5 * scale + 1e-30)
+                    else:
+                        assert o.tobytes() == ref.tobytes(), (dt, v is not None, split, key)
+            finally:
+                _lib.group_free(hd)
+        # a group the sweep serves: nothing to store directly
+        old_m = _lib.set_tunable("lds_mode", 2)
+        try:
+            hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+        finally:
+            _lib.set_tunable("lds_mode", old_m)
+        try:
+            old_w = _lib.set_tunable("host_windows", 2)
+            out = torch.full((n, h), 77, dtype=tdt, pin_memory=True)
+            _lib.spmm_run_group(hd, [x.ctypes.data], out.data_ptr())
+            _lib.set_tunable("host_windows", old_w)
+            assert _lib.group_host_call(hd) == {"windows": 2, "direct": 0}
+            assert out.numpy().tobytes() == oracle.spmm_csr(rowptr, col, None, x).tobytes()
+        finally:
+            _lib.group_free(hd)
+    finally:
+        _lib.set_tunable("host_direct", old_d)
+
+
 def test_denormals_and_infinities_follow_the_cpu_loop(rng, lds_forced):
     """the assembly inherits the kernel's float mode (denormals kept, round to nearest even): sums of subnormal features stay
     subnormal exactly as on the CPU, an infinite feature makes its rows infinite"""
