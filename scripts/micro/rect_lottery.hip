@@ -46,5 +46,36 @@ int main() {
         }
         for (auto s : ss) CHECK(hipStreamDestroy(s));
     }
+    // does it depend on WHERE the device buffer lives?  Churn the device heap (what bench.py's papers100M leg does: tens of GB allocated and freed), then a NEW source
+    // buffer beside the one made at the start; and a new page-locked destination
+    {
+        std::vector<void *> big;
+        for (int i = 0; i < 12; i++) { void *q = nullptr; if (hipMalloc(&q, (size_t)12 << 30) == hipSuccess) { CHECK(hipMemset(q, 1, (size_t)12 << 30)); big.push_back(q); } }
+        std::vector<void *> small;
+        for (int i = 0; i < 64; i++) { void *q = nullptr; if (hipMalloc(&q, (size_t)37 << 20) == hipSuccess) small.push_back(q); }
+        CHECK(hipDeviceSynchronize());
+        for (size_t i = 0; i < big.size(); i++) CHECK(hipFree(big[i]));
+        for (size_t i = 0; i < small.size(); i += 2) CHECK(hipFree(small[i]));
+        printf("# churned: %zu x 12 GB allocated, written and freed; every other of %zu x 37 MB freed\n", big.size(), small.size());
+        char *dc2, *c_pin2;
+        CHECK(hipMalloc((void **)&dc2, BYTES));
+        CHECK(hipMemset(dc2, 3, BYTES));
+        CHECK(hipHostMalloc((void **)&c_pin2, BYTES, hipHostMallocDefault));
+        memset(c_pin2, 0, BYTES);
+        hipStream_t s;
+        CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        const char *names[4] = {"old device buffer -> old host buffer", "old device buffer -> new host buffer", "new device buffer -> old host buffer", "new device buffer -> new host buffer"};
+        for (int v = 0; v < 4; v++) {
+            char *src = (v & 2) ? dc2 : dc, *dst = (v & 1) ? c_pin2 : c_pin;
+            double t2[3];
+            for (int r = 0; r < 3; r++) {
+                const double t0 = now_ms();
+                CHECK(hipMemcpy2DAsync(dst, PITCH, src, PITCH, W, N, hipMemcpyDeviceToHost, s));
+                CHECK(hipStreamSynchronize(s));
+                t2[r] = now_ms() - t0;
+            }
+            printf("after the churn, %s: %6.3f %6.3f %6.3f ms (%5.1f GB/s)\n", names[v], t2[0], t2[1], t2[2], N * W / t2[2] * 1e-6);
+        }
+    }
     return 0;
 }
