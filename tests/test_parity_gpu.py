@@ -220,7 +220,18 @@ def test_host_operands_as_a_pipeline_of_feature_windows(rng, dt):
                         for pinned in (False, True):
                             out_t = torch.full((n, h), 77, dtype=torch.from_numpy(x).dtype, pin_memory=pinned)
                             _lib.spmm_run_group(hd, [_ptr(t) for t in xs], out_t.data_ptr())
-                            want_windows = 1 if hw == 1 else (len(xs) if ds_parts > 1 else min(hw, slices))
+                            if hw == 1:
+                                want_windows = 1
+                            elif ds_parts == 1:
+                                want_windows = min(hw, slices)
+                            elif all(wk * es >= 512 for wk in widths):   # blocks of 512 bytes of a row and more: each is a window
+                                want_windows = len(xs)
+                            else:   # narrower blocks are gathered into windows of >= ceil(h / hw) columns
+                                target, cur, want_windows = -(-h // hw), 0, 0
+                                for i, wk in enumerate(widths):
+                                    cur += wk
+                                    if cur >= target or i + 1 == len(widths):
+                                        want_windows, cur = want_windows + 1, 0
                             assert _lib.group_host_windows(hd) == want_windows, (dt, h, fmt, ds_parts, hw)
                             outs[(hw, pinned)] = out_t.numpy().copy()
                     finally:
@@ -236,6 +247,56 @@ def test_host_operands_as_a_pipeline_of_feature_windows(rng, dt):
                 _lib.group_free(hd)
     # small operands keep the serial call when nothing is forced
     assert _lib.set_tunable("host_windows", 0) == 0
+
+
+@pytest.mark.parametrize("dt", ["INT8", "INT32", "FLT32", "DBL64"])
+def test_grande_windows_with_host_operands_are_gathered_into_pipeline_windows(rng, dt):
+    """grande's call with CPU tensors (grande.py:12-23, 95-107: per-unit feature windows of `pad` columns each, contiguous copies, neighbours overlapping by the
+    padding): with ONE sparse part the narrow windows go up as they are, are laid into their columns on the device and multiplied as windows of several units --
+    equal to the oracle and to the serial call, for a result in page-locked and in pageable memory"""
+    npdt = NP_DTYPES[dt]
+    es = np.dtype(npdt).itemsize
+    mul = 8 // es
+    n, units = 900, 8
+    for h in (256, 100):
+        rowptr, col = random_csr(rng, n, n, 12, long_rows=[(3, 1500)])
+        x = driver_features(rng, n, h, npdt)
+        if np.dtype(npdt).kind == "f":
+            x = (x + rng.random((n, h))).astype(npdt)
+        ref = oracle.spmm_csr(rowptr, col, None, x)
+        base, extra = divmod(h, units)
+        widths = [base + (1 if u < extra else 0) for u in range(units)]
+        pad = (widths[0] + mul - 1) // mul * mul
+        tail = widths[-1] % pad
+        xp = np.pad(x, ((0, 0), (0, pad - tail))) if tail else x
+        wins, start = [], 0
+        for w in widths:
+            wins.append(np.ascontiguousarray(xp[:, start:start + pad]))
+            start += w
+        rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+        hd = _lib.group_create(_lib.CSR, CODE[dt], [_ptr(rp)], [_ptr(ci)], None, [n], [n], [len(ci)], [units], widths, h)
+        try:
+            outs = {}
+            for hw in (1, 2, 3):
+                old = _lib.set_tunable("host_windows", hw)
+                try:
+                    for pinned in (False, True):
+                        out_t = torch.full((n, h), 77, dtype=torch.from_numpy(x).dtype, pin_memory=pinned)
+                        _lib.grande_run_group(hd, [_ptr(w) for w in wins], [pad] * units, out_t.data_ptr())
+                        got_windows = _lib.group_host_windows(hd)
+                        assert (got_windows == 1) if hw == 1 else (2 <= got_windows <= units), (dt, h, hw, got_windows)
+                        outs[(hw, pinned)] = out_t.numpy().copy()
+                finally:
+                    _lib.set_tunable("host_windows", old)
+            for key, got in outs.items():
+                assert np.array_equal(got, outs[(1, False)]), (dt, h, key, "differs from the serial call")
+            if np.dtype(npdt).kind == "f":
+                scale = abs_scale(rowptr, col, None, x)
+                assert np.all(np.abs(outs[(1, False)].astype(np.float64) - ref.astype(np.float64)) <= 1e-5 * scale + 1e-30)
+            else:
+                assert np.array_equal(outs[(1, False)], ref), (dt, h)
+        finally:
+            _lib.group_free(hd)
 
 
 def test_device_pointers_and_block_run(rng):
