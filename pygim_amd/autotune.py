@@ -35,6 +35,7 @@ LDS_ROWS_MAX = 8 * 228      # rows of a tile (waves x accumulators per wave)
 # + stored entries x 0.26 ns      (what the entries add on top: LDS reads beside the DMA's writes)
 LDS_NS_PER_COLUMN = 3.43
 LDS_NS_PER_ENTRY = 0.26
+LDS_NS_PER_ENTRY_HALF = 0.5  # ... in a half-split plan (its adds run under half of EXEC, range by range: 0.94 us per chunk of twice the entries, profiles/r06_exp_shard.txt)
 LDS_NS_PER_COLUMN_FLOOR = 4.4   # ... and never less than this per column, however few entries a tile has: with every CU streaming, the L2 -> LDS path
                                 # lands ~57 GB/s per CU (round 6, profiles/r06_stamps.txt: lighter tiles leave the 0.57 us per 128-column chunk unchanged)
 LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are split into column ranges (the library's default since round 6; tunable
@@ -42,6 +43,7 @@ LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are spl
 LDS_ROW_TAIL = 3            # percent of a share's rows that may stay outside the plan (tunable lds_row_tail)
 TAIL_S = 30e-6              # the two tail kernels
 LDS_MIN_LANES = 17          # narrower products keep the sweep (tunable lds_min_width)
+LDS_HALF_SPLIT = True       # products of at most 32 lanes fold two column ranges into the halves of a wave (tunable lds_half_split, on since the device generator writes these plans)
 LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
 
@@ -77,6 +79,13 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
         return None
     nsl = -(-h // 64)
     pack_s = ncols * h * es * 2 / RATE_STREAM
+    cols_x = ncols      # columns a row tile stages
+    ns_entry = LDS_NS_PER_ENTRY
+    if LDS_HALF_SPLIT and h * es <= 128 and ncols >= 4 * 128:
+        # (round 6) products of at most 32 lanes: two column ranges in the halves of a wave -- a staged row holds X[c] and X[c + H], every tile stages half the rows
+        # (and meets twice the entries per chunk): all rows x 32 features 0.59 -> 0.49 ms
+        cols_x = -(-ncols // 2)
+        ns_entry = LDS_NS_PER_ENTRY_HALF
     # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
     tall = -(-int(nrows) // LDS_ROWS_MAX)
     split = min(8, CUS // (tall * nsl)) if tall * nsl * 2 <= CUS else 1
@@ -100,14 +109,14 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
         tall2 = CUS // (nsl * split)            # (round 6) more, lighter row tiles when tall x slices x ranges leaves compute units idle
         if not tail_rows and tall < tall2 <= 2 * tall:
             tall = tall2
-        per_wg = max(ncols / split * LDS_NS_PER_COLUMN + nnz / tall / split * LDS_NS_PER_ENTRY, ncols / split * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
+        per_wg = max(cols_x / split * LDS_NS_PER_COLUMN + nnz / tall / split * ns_entry, cols_x / split * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
         reduce_s = (split + 1) * nrows * h * es / RATE_STREAM
         return per_wg + reduce_s + pack_s + 2 * LAUNCH + (TAIL_S if tail_rows else 0.0)
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
     if nnz / (tiles * ncols) < LDS_MIN_REUSE:
         return None
-    per_wg = max(ncols * LDS_NS_PER_COLUMN + nnz / tiles * LDS_NS_PER_ENTRY, ncols * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
+    per_wg = max(cols_x * LDS_NS_PER_COLUMN + nnz / tiles * ns_entry, cols_x * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
     rounds = -(-tiles * nsl // CUS)
     return rounds * per_wg + pack_s + LAUNCH
 

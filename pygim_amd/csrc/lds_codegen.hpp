@@ -53,6 +53,8 @@ struct CgParams {
     uint32_t nrows = 0, ncols = 0, nchunks = 0, ntiles = 0, nstreams = 0;
     uint32_t S = 1, row_tiles = 0;                  // column ranges per row tile (col_splits); ntiles = row_tiles * S
     uint32_t col_bits = 1;                          // key = stream << (col_bits + 8) | col << 8 | k
+    uint32_t half_H = 0;                            // half-split plans (LdsGeometry::half_split): column c of the matrix is the VIRTUAL column c mod H, staged beside its twin in one
+                                                    // 256-byte row; ncols (above) = H; an entry's half (c >= H) rides in the sorted payload and picks the EXEC mask of its add
     // register map (LdsCodeRegs)
     uint32_t x0 = 6, acc0 = 28, vbase0 = 1, vbase1 = 2, vbase2 = 3, vl16 = 4, vtouch = 4, vjunk = 5;
     uint32_t s_xs = 80, s_ldsw = 82, s_cb = 84, s_ret = 86, s_pa = 92;
@@ -62,7 +64,7 @@ struct CgParams {
 constexpr uint32_t CG_TOUCH_EVERY_DW = 256;   // (lds_code_from_plan: TOUCH_EVERY_DW)
 
 inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valued, uint32_t nrows, uint32_t ncols, uint32_t gsize = 0, uint32_t nsets = 0,
-                          bool int_inline = false, bool i64_full = false) {
+                          bool int_inline = false, bool i64_full = false, uint32_t half_H = 0) {
     if (geo.NBUF >= 3 && !geo.boundary) throw std::runtime_error("lds codegen: the mid-slot hand-off takes the host encoder");
     CgParams P;
     const bool wide = geo.row_bytes == 512;
@@ -85,6 +87,9 @@ inline CgParams cg_params(const LdsGeometry &geo, uint32_t opcode_add, bool valu
     P.chunk_bytes = geo.KC * geo.row_bytes;
     if ((geo.KC * geo.NBUF + P.RPB - 1) / P.RPB > 3) throw std::runtime_error("lds codegen: the ring is larger than three 64 KiB blocks");
     if (geo.NBUF > 12) throw std::runtime_error("lds codegen: more than 12 ring buffers");
+    if ((geo.half_split != 0) != (half_H != 0)) throw std::runtime_error("lds codegen: a half-split plan names its H (and only such a plan does)");
+    if (half_H && (valued || wide || half_H % geo.KC || ncols != half_H)) throw std::runtime_error("lds codegen: half-split plans are unit-weight plans of 4-byte types over H = whole chunks of virtual columns");
+    P.half_H = half_H;
     P.nrows = nrows; P.ncols = ncols;
     P.nchunks = (ncols + geo.KC - 1) / geo.KC;
     const uint32_t R_rows = geo.rows_per_tile ? std::min(geo.rows_per_tile, geo.NW * geo.KA) : geo.NW * geo.KA;
@@ -220,6 +225,7 @@ struct CgTables {
     uint32_t *slot_firstcol = nullptr, *slot_ng = nullptr, *slot_firstgroup = nullptr;
     // per group
     uint32_t *g_nent = nullptr, *g_first = nullptr, *g_firstcol = nullptr;   // entries, first entry, first column
+    uint32_t *g_n0 = nullptr;                                                // half-split plans: the group's entries of the LOWER column range (their adds come first, under the lower half of EXEC)
     uint8_t *g_nlds = nullptr, *g_ncols = nullptr, *g_xset = nullptr;
     uint32_t *g_rpos = nullptr, *g_apos = nullptr;                           // dword offsets inside the code blob (absolute)
     // per stream
@@ -275,18 +281,23 @@ PYGIM_HD inline void cg_sj_decode(const CgParams &P, const CgTables &T, uint32_t
     *s = lo * P.NW + rel / n;
     *j = rel % n;
 }
+// half-split plans: the virtual column of a stored column, and which half of the staged row holds it
+PYGIM_HD inline uint32_t cg_vcol(const CgParams &P, uint32_t c) { return (P.half_H && c >= P.half_H) ? c - P.half_H : c; }
+PYGIM_HD inline uint32_t cg_half(const CgParams &P, uint32_t c) { return (P.half_H && c >= P.half_H) ? 1u : 0u; }
 // D0 / D1: per row (the device runs a wave per row, lanes over its entries)
 PYGIM_HD inline uint32_t cg_tile_of_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {   // (row tile, column range), unsorted index
-    return ((T.rowinfo[row] >> 8) / P.NW) * P.S + cg_range_of(P, T.colind[e] / P.KC);
+    return ((T.rowinfo[row] >> 8) / P.NW) * P.S + cg_range_of(P, cg_vcol(P, T.colind[e]) / P.KC);
 }
 PYGIM_HD inline void cg_mark_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
-    const uint32_t ti = cg_stream_of(P, T, T.rowinfo[row], T.colind[e]) / P.NW;
-    T.flags[(size_t)ti * P.nchunks + T.colind[e] / P.KC] = 1;
+    const uint32_t c = cg_vcol(P, T.colind[e]);
+    const uint32_t ti = cg_stream_of(P, T, T.rowinfo[row], c) / P.NW;
+    T.flags[(size_t)ti * P.nchunks + c / P.KC] = 1;
 }
 PYGIM_HD inline void cg_key_entry(const CgParams &P, const CgTables &T, uint32_t row, uint32_t e) {
-    const uint32_t ri = T.rowinfo[row], c = T.colind[e];
+    const uint32_t ri = T.rowinfo[row], c = cg_vcol(P, T.colind[e]);
     T.keys[e] = ((uint64_t)cg_stream_of(P, T, ri, c) << (P.col_bits + 8)) | ((uint64_t)c << 8) | (ri & 255u);
     if (P.valued) T.vals[e] = P.wide ? e : T.vals_in[e];   // (8-byte values: the entry's index rides with the key)
+    else if (P.half_H) T.vals[e] = cg_half(P, T.colind[e]);   // (the stable sort keeps a row's lower-range entry of a virtual column ahead of its upper-range one: CSR order)
 }
 // D3: per sorted entry
 PYGIM_HD inline void cg_colflag(const CgParams &P, const CgTables &T, uint64_t i) {
@@ -353,6 +364,11 @@ PYGIM_HD inline unsigned long long cg_slot_groups(const CgParams &P, const CgTab
         }
         T.g_first[g] = T.col_first[c];
         T.g_nent[g] = T.col_first[ce] - T.col_first[c];
+        if (P.half_H) {
+            uint32_t n0 = 0;
+            for (uint32_t i = T.col_first[c]; i < T.col_first[ce]; i++) n0 += T.vals[i] == 0u;
+            T.g_n0[g] = n0;
+        }
         T.g_firstcol[g] = c;
         T.g_nlds[g] = (uint8_t)nlds;
         T.g_ncols[g] = (uint8_t)(ce - c);
@@ -437,6 +453,7 @@ PYGIM_HD inline void cg_stream_pass(const CgParams &P, const CgTables &T, uint32
         const uint32_t g = pend_g[0];
         if (write) T.g_apos[g] = (uint32_t)(base_dw + e.n);
         e.skip(T.g_nent[g] * (P.mulw + P.addw));
+        if (P.half_H) e.skip((T.g_n0[g] > 0 ? 1u : 0u) + (T.g_n0[g] < T.g_nent[g] ? 1u : 0u) + 1u);   // s_mov_b64 exec, <half> per range present + s_mov_b64 exec, -1
         for (uint32_t q = 1; q < npend; q++) {
             pend_g[q - 1] = pend_g[q];
             pend_nlds[q - 1] = pend_nlds[q];
@@ -484,6 +501,14 @@ PYGIM_HD inline void cg_stream_pass(const CgParams &P, const CgTables &T, uint32
 
 // D10: per group: its LDS reads
 PYGIM_HD inline void cg_emit_reads(const CgParams &P, const CgTables &T, uint32_t g) {
+    if (P.half_H) {   // the EXEC masks around the group's adds (lds_code_from_plan: s[76:77] = lanes 0..31, s[78:79] = lanes 32..63, set by the kernel)
+        uint32_t *a = T.code + T.g_apos[g];
+        const uint32_t n0 = T.g_n0[g], n1 = T.g_nent[g] - n0;
+        uint32_t at = 0;
+        if (n0) { a[at] = 0xBEFE0100u | 76u; at += 1 + n0 * P.addw; }
+        if (n1) { a[at] = 0xBEFE0100u | 78u; at += 1 + n1 * P.addw; }
+        a[at] = 0xBEFE01C1u;
+    }
     const uint32_t c0 = T.g_firstcol[g], nc = T.g_ncols[g];
     const uint32_t xb = P.x0 + P.G * P.XW * T.g_xset[g];
     uint32_t *w = T.code + T.g_rpos[g];
@@ -561,7 +586,13 @@ PYGIM_HD inline void cg_emit_entry(const CgParams &P, const CgTables &T, uint64_
         }
         w += P.mulw * T.g_nent[g];
     }
-    w += q * P.addw;
+    if (P.half_H) {   // the lower range's adds first (one word of EXEC ahead of each range present), a range's entries in the group's order
+        uint32_t q0 = 0;
+        for (uint32_t j = T.g_first[g]; j < (uint32_t)i; j++) q0 += T.vals[j] == 0u;
+        const uint32_t n0 = T.g_n0[g];
+        w += T.vals[i] == 0u ? 1 + q0 * P.addw : (n0 ? 1 + n0 * P.addw : 0) + 1 + (q - q0) * P.addw;
+    } else
+        w += q * P.addw;
     if (P.opcode_add == LDS_CODE_PK_ADD_U16) {
         w[0] = 0xD38A4000u | vk;
         w[1] = 0x18000000u | ((256 + vk) << 9) | (256 + vx);
@@ -590,7 +621,7 @@ struct CgHostResult {
 // vals: 4-byte values (FLT32 / INT32 raw bits); vals64: DBL64 values (then vals is ignored: the payload is the entry index)
 inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const uint32_t *vals, uint32_t nrows, uint32_t ncols, const LdsGeometry &geo,
                            uint32_t opcode_add, CgHostResult &out, uint32_t gsize = 0, uint32_t nsets = 0, const uint32_t *rorder = nullptr,
-                           const uint64_t *vals64 = nullptr) {
+                           const uint64_t *vals64 = nullptr, uint32_t half_H = 0) {   // half_H: col holds the STORED columns, ncols = H (the virtual columns)
     std::vector<uint32_t> idx_payload;
     if (vals64) {   // (any non-null 4-byte array switches the valued form on)
         idx_payload.assign(1, 0);
@@ -604,7 +635,8 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
                                          return true; }()),
                                  vals64 && opcode_add == LDS_CODE_ADD_U64 && [&] {
                                      for (uint64_t i = 0; i < nnz; i++) { const int64_t v = (int64_t)vals64[i]; if (v != (int64_t)(int32_t)v) return true; }
-                                     return false; }());
+                                     return false; }(), half_H);
+    const bool payload = vals != nullptr || half_H != 0;   // something rides with the keys through the sort
     cg_deal_rows_a(rowptr, geo, P, out.rows, rorder);
     CgTables T;
     T.rowptr = rowptr; T.colind = col; T.vals_in = vals; T.vals_in64 = vals64; T.rowinfo = out.rows.rowinfo.data(); T.nnz = nnz;
@@ -620,7 +652,7 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
     cg_chunk_lists(flags.data(), P, out.chunks);
     T.nch = out.chunks.nch.data(); T.choff = out.chunks.choff.data(); T.chunks = out.chunks.chunks.data();
     std::vector<uint64_t> keys(nnz + 1);
-    std::vector<uint32_t> v(vals ? nnz + 1 : 1);
+    std::vector<uint32_t> v(payload ? nnz + 1 : 1);
     T.keys = keys.data(); T.vals = v.data();
     for (uint32_t r = 0; r < nrows; r++)
         for (uint32_t e = rowptr[r]; e < rowptr[r + 1]; e++) cg_key_entry(P, T, r, e);
@@ -629,10 +661,10 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
         for (uint64_t i = 0; i < nnz; i++) perm[i] = (uint32_t)i;
         std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
         std::vector<uint64_t> k2(nnz + 1);
-        std::vector<uint32_t> v2(vals ? nnz + 1 : 1);
+        std::vector<uint32_t> v2(payload ? nnz + 1 : 1);
         for (uint64_t i = 0; i < nnz; i++) {
             k2[i] = keys[perm[i]];
-            if (vals) v2[i] = v[perm[i]];
+            if (payload) v2[i] = v[perm[i]];
         }
         keys.swap(k2);
         v.swap(v2);
@@ -664,6 +696,8 @@ inline void cg_run_on_host(const uint32_t *rowptr, const uint32_t *col, const ui
     T.ngroups = run;
     std::vector<uint32_t> g_nent((size_t)run + 1), g_first((size_t)run + 1), g_firstcol((size_t)run + 1), g_rpos((size_t)run + 1), g_apos((size_t)run + 1);
     std::vector<uint8_t> g_nlds((size_t)run + 1), g_ncols((size_t)run + 1), g_xset((size_t)run + 1);
+    std::vector<uint32_t> g_n0(half_H ? (size_t)run + 1 : 1);
+    T.g_n0 = g_n0.data();
     T.g_nent = g_nent.data(); T.g_first = g_first.data(); T.g_firstcol = g_firstcol.data(); T.g_rpos = g_rpos.data(); T.g_apos = g_apos.data();
     T.g_nlds = g_nlds.data(); T.g_ncols = g_ncols.data(); T.g_xset = g_xset.data();
     unsigned long long pairs = 0;

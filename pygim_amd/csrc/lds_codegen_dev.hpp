@@ -290,7 +290,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
                                     uint32_t nrows, uint32_t ncols,
                                     const LdsGeometry &geo, uint32_t opcode_add, uint32_t gsize, uint32_t nsets, hipStream_t st,
                                     const std::function<void *(size_t)> &alloc_exec, const std::function<void(void *)> &free_exec, CgDeviceResult &out,
-                                    const std::function<double()> &now_ms) {
+                                    const std::function<double()> &now_ms, uint32_t half_H = 0) {   // half_H: a half-split plan -- d_col holds the STORED columns, ncols = H
     const uint64_t nnz = h_rowptr[nrows];
     if (nnz == 0 || nnz >= (1ull << 31)) return "lds codegen: no entries, or 2^31 and more";
     bool int_inline = false;
@@ -313,7 +313,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     }
     CgParams P;
     try {
-        P = cg_params(geo, opcode_add, d_vals != nullptr || d_vals64 != nullptr, nrows, ncols, gsize, nsets, int_inline, i64_full);
+        P = cg_params(geo, opcode_add, d_vals != nullptr || d_vals64 != nullptr, nrows, ncols, gsize, nsets, int_inline, i64_full, half_H);
     } catch (const std::exception &e) {
         return e.what();
     }
@@ -402,7 +402,8 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     // D1 + D2: keys, stable sort
     uint64_t *keys_a = (uint64_t *)dalloc((nnz + 1) * 8), *keys_b = (uint64_t *)dalloc((nnz + 1) * 8);
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
-    if (P.valued) {
+    const bool payload = P.valued || P.half_H;   // something rides with the keys through the sort (values; the entries' halves)
+    if (payload) {
         vals_a = (uint32_t *)dalloc((nnz + 1) * 4);
         vals_b = (uint32_t *)dalloc((nnz + 1) * 4);
     }
@@ -414,7 +415,7 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     T.keys = keys_a;
     T.vals = vals_a;
     hipLaunchKernelGGL((k_cg_rows<1>), dim3(row_blocks), dim3(256), 0, st, P, T);
-    cg_radix_sort(&keys_a, &keys_b, P.valued ? &vals_a : nullptr, P.valued ? &vals_b : nullptr, nnz, cg_key_bits(P), d_hist, d_scan, st);
+    cg_radix_sort(&keys_a, &keys_b, payload ? &vals_a : nullptr, payload ? &vals_b : nullptr, nnz, cg_key_bits(P), d_hist, d_scan, st);
     T.keys = keys_a;
     T.vals = vals_a;
     if (!ok(hipGetLastError())) return bail("lds codegen: sort launch");
@@ -458,7 +459,9 @@ inline std::string cg_run_on_device(const uint32_t *d_rowptr, const uint32_t *d_
     uint32_t *d_gn = (uint32_t *)dalloc(((size_t)ngroups + 1) * 4), *d_gf = (uint32_t *)dalloc(((size_t)ngroups + 1) * 4), *d_gc = (uint32_t *)dalloc(((size_t)ngroups + 1) * 4);
     uint32_t *d_gr = (uint32_t *)dalloc(((size_t)ngroups + 1) * 4), *d_ga = (uint32_t *)dalloc(((size_t)ngroups + 1) * 4);
     uint8_t *d_g8 = (uint8_t *)dalloc(((size_t)ngroups + 1) * 3);
+    uint32_t *d_gn0 = P.half_H ? (uint32_t *)dalloc(((size_t)ngroups + 1) * 4) : nullptr;
     if (failed) return bail("lds codegen: out of device memory (groups)");
+    T.g_n0 = d_gn0;
     T.g_nent = d_gn; T.g_first = d_gf; T.g_firstcol = d_gc; T.g_rpos = d_gr; T.g_apos = d_ga;
     T.g_nlds = d_g8; T.g_ncols = d_g8 + ((size_t)ngroups + 1); T.g_xset = d_g8 + 2 * ((size_t)ngroups + 1);
     if (T.nsj) hipLaunchKernelGGL((k_cg_slots<2>), dim3((unsigned)(((uint64_t)T.nsj + 255) / 256)), dim3(256), 0, st, P, T);

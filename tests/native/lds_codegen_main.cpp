@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     const uint32_t geos[][7] = {{8, 228, 128, 5, 10, 2, 256}, {8, 228, 128, 5, 0, 0, 256}, {16, 96, 320, 2, 8, 2, 256}, {16, 96, 192, 3, 8, 2, 256}, {8, 228, 320, 2, 10, 2, 256},
                                 {8, 228, 192, 3, 6, 3, 256}, {8, 228, 160, 4, 12, 2, 256}, {8, 228, 64, 8, 2, 2, 256}, {8, 228, 32, 5, 4, 3, 256}, {8, 7, 128, 5, 10, 2, 256},
                                 {16, 5, 128, 4, 12, 2, 256}, {8, 114, 64, 5, 5, 2, 512}, {8, 114, 48, 6, 3, 3, 512}, {8, 114, 96, 3, 2, 2, 512}, {8, 9, 16, 5, 5, 2, 512}};
+    int half_cases = 0;
     for (int c = 0; c < cases; c++) {
         const uint32_t nrows = 1 + (uint32_t)(rng() % 2500), ncols = 1 + (uint32_t)(rng() % 3500);
         const double deg = 1 + (double)(rng() % 50);
@@ -89,6 +90,28 @@ int main(int argc, char **argv) {
                 else vals64[i] = cls == 2 ? (rng() % 4 ? rng() : (uint64_t)(int64_t)(int32_t)rng()) : (uint64_t)(int64_t)(cls == 0 ? (int32_t)(rng() % 81) - 16 : (int32_t)rng());
             }
         }
+        // half-split plans (round 6): two column ranges folded into the halves of a wave -- the host encoder sees the VIRTUAL matrix (columns c mod H, every row's two
+        // sorted runs merged, the lower range first on ties; the entry's half in its value slot), the data-parallel form the stored columns and H
+        const bool half = !wide && !valued && (op == 0x02000000u || op == 0x68000000u) && geo.NW == 8 && rng() % 3 == 0;
+        uint32_t half_H = 0;
+        std::vector<uint32_t> col2, hv;
+        if (half) {
+            half_H = (((ncols + 1) / 2 + geo.KC - 1) / geo.KC) * geo.KC;
+            geo.half_split = 1;
+            half_cases++;
+            col2.resize(m.col.size());
+            hv.resize(m.col.size());
+            for (uint32_t r = 0; r < nrows; r++) {
+                const uint32_t e0 = m.rowptr[r], e1 = m.rowptr[r + 1];
+                const uint32_t mid = (uint32_t)(std::lower_bound(m.col.begin() + e0, m.col.begin() + e1, half_H) - m.col.begin());
+                uint32_t a = e0, b = mid, o = e0;
+                while (a < mid || b < e1) {
+                    const bool low = b >= e1 || (a < mid && m.col[a] <= m.col[b] - half_H);
+                    if (low) { col2[o] = m.col[a++]; hv[o++] = 0u; }
+                    else { col2[o] = m.col[b++] - half_H; hv[o++] = 1u; }
+                }
+            }
+        }
         // tiles of consecutive rows, or of rows in an arbitrary order (similarity tiles)
         std::vector<uint32_t> rorder;
         if (rng() % 3 == 0) {
@@ -99,15 +122,16 @@ int main(int argc, char **argv) {
         const uint32_t *ro = rorder.empty() ? nullptr : rorder.data();
         // the host encoder
         LdsPlanHost plan;
-        lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : (valued64 ? eidx.data() : nullptr), ro);
+        if (half) lds_plan_build(m.rowptr.data(), col2.data(), nrows, half_H, geo, plan, 2, hv.data(), ro);
+        else lds_plan_build(m.rowptr.data(), m.col.data(), nrows, ncols, geo, plan, 2, valued ? vals.data() : (valued64 ? eidx.data() : nullptr), ro);
         LdsCodeHost ch;
         lds_code_from_plan(plan, op, ch, 2, q[4], q[5], 0, valued64 ? vals64.data() : nullptr);
         // the data-parallel form
         CgHostResult r;
-        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, ncols, geo, op, r, q[4], q[5], ro, valued64 ? vals64.data() : nullptr);
+        cg_run_on_host(m.rowptr.data(), m.col.data(), valued ? vals.data() : nullptr, nrows, half ? half_H : ncols, geo, op, r, q[4], q[5], ro, valued64 ? vals64.data() : nullptr, half_H);
         auto bad = [&](const char *what) {
-            printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, splits %u, op %08x, valued %d, dups %d, clustered %d)\n", c, what, q[0], q[1], q[2], q[3],
-                   q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, geo.col_splits, op, (int)valued, (int)dups, (int)clustered);
+            printf("case %d: %s differs (geo %u %u %u %u %u %u %u, %u x %u, nnz %zu, rpt %u, splits %u, op %08x, valued %d, dups %d, clustered %d, half H %u)\n", c, what, q[0], q[1], q[2], q[3],
+                   q[4], q[5], q[6], nrows, ncols, m.col.size(), geo.rows_per_tile, geo.col_splits, op, (int)valued, (int)dups, (int)clustered, half_H);
             return 1;
         };
         if (r.rows.rowmap != plan.rowmap) return bad("row map");
@@ -125,6 +149,6 @@ int main(int argc, char **argv) {
             if (plan.tiles[t].nch != r.chunks.nch[t] || plan.tiles[t].row0 != r.rows.tile_row0[t] || plan.tiles[t].nnz != r.rows.tile_nnz[t]) return bad("tile table");
         if (r.entries != ch.entries || r.pairs != ch.pairs || r.shared != ch.shared || r.chunks.slots != plan.slots) return bad("statistics");
     }
-    printf("codegen: %d cases, data-parallel form == host encoder, byte for byte\n", cases);
+    printf("codegen: %d cases (%d of them half-split plans), data-parallel form == host encoder, byte for byte\n", cases, half_cases);
     return 0;
 }

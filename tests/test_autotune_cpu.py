@@ -28,7 +28,7 @@ def test_model_against_the_measured_shapes_of_round_6():
     """ms measured on one MI355X (profiles/r06_exp_shard.txt), model within 25 %"""
     n, nnz, _ = synth.SHAPES["reddit"]
     for rows, frac, h, measured in ((232965, 1, 256, 2.07), (116638, 2, 256, 1.11), (58490, 4, 256, 0.69), (29471, 8, 256, 0.45), (232965, 1, 128, 1.08),
-                                    (232965, 1, 64, 0.65), (232965, 1, 32, 0.60), (116638, 2, 64, 0.365), (58490, 4, 128, 0.385)):
+                                    (232965, 1, 64, 0.65), (232965, 1, 32, 0.49), (116638, 2, 64, 0.365), (58490, 4, 128, 0.385)):   # (h = 32: the half-split plan, 0.60 before it)
         t, _ = autotune.product_seconds(rows, n, nnz // frac, h, 4)
         assert abs(t * 1e3 - measured) <= 0.25 * measured, (rows, h, t * 1e3, measured)
 
@@ -45,6 +45,6 @@ def test_eight_ranks_prefer_the_grid_whose_product_is_cheapest():
     best, table = autotune.choose(n, n, nnz, 256, 4, 8)
     by = {(c.row_parts, c.feat_parts): c for c in table}
     assert (best.row_parts, best.feat_parts) == (2, 4)
-    assert by[(2, 4)].product_s < by[(8, 1)].product_s < by[(1, 8)].product_s      # 0.36 < 0.45 < 0.59 ms measured
+    assert by[(2, 4)].product_s < by[(8, 1)].product_s < by[(1, 8)].product_s      # 0.36 < 0.45 < 0.49 ms measured
     one, _ = autotune.choose(n, n, nnz, 256, 4, 1)
     assert one.product_s / by[(2, 4)].product_s > 5.0     # products alone: 5.6 x measured (the exchange over xGMI is the rest of the step)

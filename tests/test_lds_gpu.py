@@ -790,7 +790,9 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
     """Round 6: a product of 17..32 lanes (all rows x 32 FLT32 features: a feature-split rank) would leave half of every 64-lane slice empty.  The half-split plan
     folds TWO column ranges into the halves of a wave instead -- a staged row is [X[c] | X[c + H]], the stream adds under the lower / upper half of EXEC, the store
     adds the halves -- so every tile stages half the bytes.  INT32 exact against the oracle (odd column count, empty rows, a long row, accumulation into C, a ragged
-    width), FLT32 inside 1e-5 of |A|.|x|; lds_half_split = 0 (the default: the form's plan is written by the host encoder) keeps the plain plan with the same results."""
+    width), FLT32 inside 1e-5 of |A|.|x|; lds_half_split = 0 keeps the plain plan with the same results.  The plan is written by the DEVICE code generator (the
+    default since the round's last session) and compared word for word with the host encoder's inside the library (lds_codegen = 2); lds_codegen = 0 takes the host
+    encoder alone."""
     n, ncols = 5000, 30001
     rowptr, col = random_csr(rng, n, ncols, 60, empty_frac=0.1, long_rows=[(3, 9000), (n - 1, 4000)])
     rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
@@ -800,14 +802,19 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
     try:
         for dt, code in ((np.int32, _lib.INT32), (np.float32, _lib.FLT32)):
             outs = {}
-            for hs in (1, 0):
+            for hs, cg in ((1, 2), (1, 0), (0, 2)):
                 _lib.set_tunable("lds_half_split", hs)
-                hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+                old_cg = _lib.set_tunable("lds_codegen", cg)
+                try:
+                    hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+                finally:
+                    _lib.set_tunable("lds_codegen", old_cg)
                 try:
                     note = _lib.group_lds_note(hd)
                     assert ("half-split" in note) == bool(hs) and _lib.group_lds_code(hd)["active"] == 1, note
+                    assert _lib.group_lds_code(hd)["device_generated"] == (1 if cg else 0), note
                     x = features(rng, ncols, h, dt) if dt == np.float32 else rng.integers(-1000, 1000, size=(ncols, h)).astype(np.int32)
-                    if hs == 1:
+                    if "x" not in outs:
                         outs["x"] = x
                     x = outs["x"]
                     out = np.full((n, h), 77, dtype=dt)
@@ -827,7 +834,7 @@ def test_half_split_plans_for_products_of_at_most_32_lanes(rng, h):
                 finally:
                     _lib.group_free(hd)
     finally:
-        _lib.set_tunable("lds_half_split", 0)
+        _lib.set_tunable("lds_half_split", 1)
         _lib.set_tunable("lds_col_split", old_split)
         _lib.set_tunable("lds_mode", old_mode)
         _lib.set_tunable("lds_col_split_f32", old)
