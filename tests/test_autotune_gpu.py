@@ -29,6 +29,14 @@ def _time_product(hd, x, out, reps=8):
         b.synchronize()
         ts.append(a.elapsed_time(b))
     ts.sort()
+    # ... and the same product queued back to back (what a rank does inside a step: the launch latency of the product's three or four kernels is hidden
+    # behind the previous product) -- printed beside the single-call time, not asserted
+    a.record()
+    for _ in range(reps):
+        _lib.spmm_run_group(hd, [x.data_ptr()], out.data_ptr(), st)
+    b.record()
+    b.synchronize()
+    _time_product.back_to_back = a.elapsed_time(b) / reps * 1e-3
     return ts[len(ts) // 2] * 1e-3
 
 
@@ -50,16 +58,18 @@ def test_product_model_within_25_percent_of_measured_shares(capsys):
             out = torch.empty((top, h), dtype=torch.float32, device=dev)
             hd = _lib.group_create(_lib.CSR, _lib.FLT32, [rowptr.data_ptr()], [col.data_ptr()], None, [top], [n], [m], [1], [h], h)
             t = _time_product(hd, x, out)
+            t_queue = _time_product.back_to_back
             _lib.group_free(hd)
             pred, _panel = autotune.product_seconds(top, n, m, h, 4)
-            rows.append((name, t, pred))
+            rows.append((name, t, pred, t_queue))
     finally:
         _lib.release()
     with capsys.disabled():
-        for name, t, pred in rows:
-            print(f"\\n[autotune] {name:22s} measured {t * 1e3:7.3f} ms   model {pred * 1e3:7.3f} ms   ratio {pred / t:5.2f}", end="")
+        for name, t, pred, t_queue in rows:
+            print(f"\n[autotune] {name:22s} measured {t * 1e3:7.3f} ms (a single call; {t_queue * 1e3:7.3f} ms per call queued back to back)   "
+                  f"model {pred * 1e3:7.3f} ms   ratio {pred / t:5.2f}", end="")
         print()
-    for name, t, pred in rows:
+    for name, t, pred, _ in rows:
         assert abs(pred - t) <= 0.25 * t, (name, t, pred)
 
 
