@@ -394,3 +394,16 @@ def test_random_lds_spmv(seed):
     finally:
         for k, v in old.items():
             _lib.set_tunable(k, v)
+
+
+def test_random_host_operand_pipelines():
+    """the host-operand pipeline over random shapes, element types, sparse parts, caller feature blocks, window counts, direct stores on / off, page-locked or pageable
+    results (scripts/stress_host_pipeline.py, in its own process: it changes tunables): every pipelined result byte-equal to the serial call's; forced float windows
+    on the sweep inside the norm-wise bound"""
+    import subprocess
+    import sys
+
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    cases = 40 + 4 * _EXTRA
+    r = subprocess.run([sys.executable, _os.path.join(root, "scripts", "stress_host_pipeline.py"), str(cases), "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and f"host pipeline: {cases} cases" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])
