@@ -192,6 +192,7 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_row_tail") slot = &g_tune.lds_row_tail;
     else if (n == "lds_split_order") slot = &g_tune.lds_split_order;
     else if (n == "lds_half_split") slot = &g_tune.lds_half_split;
+    else if (n == "lds_direct_x") slot = &g_tune.lds_direct_x;
     else if (n == "lds_long_slots") slot = &g_tune.lds_long_slots;
     if (!slot) {
         fail(PYGIM_ERR_INVALID, "unknown tunable: " + n);

@@ -384,6 +384,44 @@ def test_host_windows_store_straight_into_the_page_locked_result(rng, lds_forced
         _lib.set_tunable("host_direct", old_d)
 
 
+@pytest.mark.parametrize("dt,h", [(np.float32, 64), (np.int32, 64), (np.int16, 128), (np.float64, 64)])
+def test_one_slice_products_read_the_callers_matrix_in_place(rng, lds_forced, dt, h):
+    """a product of ONE slice whose rows of X are exactly the staged row (256 bytes; 512 for the 8-byte types) reads the caller's matrix instead of a slice-major copy
+    (launch_lds, tunable lds_direct_x): same bytes as with the copy and as the oracle, for a row count that is no multiple of the chunk -- the last chunk's padding rows
+    are read (never used) when they lie inside the caller's allocation, and the copy is made when they do not (X at the very end of its allocation)"""
+    code = {np.dtype(np.float32): _lib.FLT32, np.dtype(np.int32): _lib.INT32, np.dtype(np.int16): _lib.INT16, np.dtype(np.float64): _lib.DBL64}[np.dtype(dt)]
+    n, ncols = 3000, 2001
+    rowptr, col = random_csr(rng, n, ncols, 20, empty_frac=0.1, long_rows=[(7, 1500)])
+    rp, ci = np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(col, np.int32)
+    x = (rng.random((ncols, h)) * 2 - 1).astype(dt) if np.issubdtype(dt, np.floating) else rng.integers(-1000, 1000, size=(ncols, h)).astype(dt)
+    want = oracle.spmm_csr(rowptr, col, None, x)
+    hd = _lib.group_create(_lib.CSR, code, [rp.ctypes.data], [ci.ctypes.data], None, [n], [ncols], [len(ci)], [1], [h], h)
+    try:
+        assert _lib.group_lds_plan(hd)["tiles"] > 0
+        tdt = torch.from_numpy(x).dtype
+        row_bytes = h * x.itemsize
+        # (a) X somewhere inside a larger allocation; (b) X as the LAST rows of its allocation: the padding rows would lie outside
+        big = torch.zeros((ncols + 4096) * row_bytes, dtype=torch.uint8, device="cuda")
+        tail = torch.zeros(ncols * row_bytes + 256, dtype=torch.uint8, device="cuda")
+        off = (-tail.data_ptr()) % 256
+        views = [big[:ncols * row_bytes].view(tdt).view(ncols, h), tail[off:off + ncols * row_bytes].view(tdt).view(ncols, h)]
+        for xv in views:
+            xv.copy_(torch.from_numpy(x))
+            for direct in (1, 0):
+                old = _lib.set_tunable("lds_direct_x", direct)
+                try:
+                    out = torch.full((n, h), 77, dtype=tdt, device="cuda")
+                    runs = _lib.group_lds_runs(hd)
+                    _lib.spmm_run_group(hd, [xv.data_ptr()], out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    assert _lib.group_lds_runs(hd) == runs + 1
+                finally:
+                    _lib.set_tunable("lds_direct_x", old)
+                assert out.cpu().numpy().tobytes() == want.tobytes(), (np.dtype(dt).name, direct)
+    finally:
+        _lib.group_free(hd)
+
+
 def test_denormals_and_infinities_follow_the_cpu_loop(rng, lds_forced):
     """the assembly inherits the kernel's float mode (denormals kept, round to nearest even): sums of subnormal features stay
     subnormal exactly as on the CPU, an infinite feature makes its rows infinite"""
