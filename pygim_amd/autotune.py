@@ -42,7 +42,8 @@ LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are spl
                             # lds_col_split_f32 = 0 keeps the bit-identical stored-order form -- callers that set it set this to False)
 LDS_ROW_TAIL = 3            # percent of a share's rows that may stay outside the plan (tunable lds_row_tail)
 TAIL_S = 30e-6              # the two tail kernels
-LDS_MIN_LANES = 17          # narrower products keep the sweep (tunable lds_min_width)
+LDS_MIN_LANES = 5           # narrower products keep the sweep / the SpMV kernels (tunable lds_min_width; 17 until the round's last session)
+LDS_MIN_REUSE_NARROW = 2.5  # products of at most 32 lanes: stored entries per staged column below which the sweep is kept (x 1.6 for a half-split plan, which stages half the columns)
 LDS_HALF_SPLIT = True       # products of at most 32 lanes fold two column ranges into the halves of a wave (tunable lds_half_split, on since the device generator writes these plans)
 LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 
@@ -86,6 +87,8 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
         # (and meets twice the entries per chunk): all rows x 32 features 0.59 -> 0.49 ms
         cols_x = -(-ncols // 2)
         ns_entry = LDS_NS_PER_ENTRY_HALF
+    # (narrow products gather fewer bytes per entry on the sweep: their plans must serve more entries per staged column; rt_plans.inc)
+    min_reuse = LDS_MIN_REUSE if h * es > 128 else max(LDS_MIN_REUSE, LDS_MIN_REUSE_NARROW * (1.6 if cols_x != ncols else 1.0))
     # short row shares (pygim_hip.hip build_lds_plan): full-height tiles split into S column ranges, each workgroup lands 1 / S of X
     tall = -(-int(nrows) // LDS_ROWS_MAX)
     split = min(8, CUS // (tall * nsl)) if tall * nsl * 2 <= CUS else 1
@@ -104,7 +107,7 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
                 split, tall, tail_rows = s2, tall_s, nrows - covered
                 break
     if LDS_COL_SPLIT and nnz >= (1 << 20) and split > 1:
-        if nnz / (tall * ncols) < LDS_MIN_REUSE:
+        if nnz / (tall * cols_x) < min_reuse:
             return None
         tall2 = CUS // (nsl * split)            # (round 6) more, lighter row tiles when tall x slices x ranges leaves compute units idle
         if not tail_rows and tall < tall2 <= 2 * tall:
@@ -114,7 +117,7 @@ def lds_product_seconds(nrows, ncols, nnz, h, es):
         return per_wg + reduce_s + pack_s + 2 * LAUNCH + (TAIL_S if tail_rows else 0.0)
     rpt = lds_rows_per_tile(int(nrows), nsl)
     tiles = -(-int(nrows) // rpt)
-    if nnz / (tiles * ncols) < LDS_MIN_REUSE:
+    if nnz / (tiles * cols_x) < min_reuse:
         return None
     per_wg = max(cols_x * LDS_NS_PER_COLUMN + nnz / tiles * ns_entry, cols_x * LDS_NS_PER_COLUMN_FLOOR) * 1e-9
     rounds = -(-tiles * nsl // CUS)

@@ -165,6 +165,8 @@ int64_t pygim_set_tunable(const char *name, int64_t value) {
     else if (n == "lds_mode") slot = &g_tune.lds_mode;
     else if (n == "lds_min_reuse_x100") slot = &g_tune.lds_min_reuse_x100;
     else if (n == "lds_min_width") slot = &g_tune.lds_min_width;
+    else if (n == "lds_min_width8") slot = &g_tune.lds_min_width8;
+    else if (n == "lds_min_reuse_narrow_x100") slot = &g_tune.lds_min_reuse_narrow_x100;
     else if (n == "lds_threads") slot = &g_tune.lds_threads;
     else if (n == "lds_waves") slot = &g_tune.lds_waves;
     else if (n == "lds_ablate") slot = &g_tune.lds_ablate;

@@ -31,7 +31,7 @@ print("#", tun or "defaults", dtn, flush=True)
 n, nnz, dmax = synth.SHAPES["reddit"]
 rowptr, col = synth.make_csr(n, nnz, dmax, seed=0, device=dev)
 rp_cpu = rowptr.cpu()
-CASES = {"full": (1, 256), "r8": (8, 256), "h64": (1, 64), "h32": (1, 32), "g24": (2, 64), "g42": (4, 128), "r2": (2, 256), "r4": (4, 256), "h128": (1, 128), "h16": (1, 16)}
+CASES = {"full": (1, 256), "r8": (8, 256), "h64": (1, 64), "h32": (1, 32), "g24": (2, 64), "g42": (4, 128), "r2": (2, 256), "r4": (4, 256), "h128": (1, 128), "h16": (1, 16), "h8": (1, 8), "h24": (1, 24), "h12": (1, 12)}
 
 
 def timed(hd, x, out, reps=9):

@@ -35,9 +35,11 @@ def test_model_against_the_measured_shapes_of_round_6():
 
 def test_products_too_narrow_for_the_lds_path_keep_the_sweep_price():
     n, nnz, _ = synth.SHAPES["reddit"]
-    assert autotune.lds_product_seconds(n, n, nnz, 16, 4) is None and autotune.lds_product_seconds(n, n, nnz, 17, 4) is not None
-    t16, _ = autotune.product_seconds(n, n, nnz, 16, 4)
-    assert t16 > 0
+    assert autotune.lds_product_seconds(n, n, nnz, 4, 4) is None and autotune.lds_product_seconds(n, n, nnz, 5, 4) is not None
+    t4, _ = autotune.product_seconds(n, n, nnz, 4, 4)
+    assert t4 > 0
+    # a narrow product weighs the staged columns against fewer gathered bytes per entry: a graph with a fifth of the entries keeps the sweep at 16 features, not at 256
+    assert autotune.lds_product_seconds(n, n, nnz // 5, 16, 4) is None and autotune.lds_product_seconds(n, n, nnz // 5, 256, 4) is not None
 
 
 def test_eight_ranks_prefer_the_grid_whose_product_is_cheapest():

@@ -117,7 +117,7 @@ def test_calls_the_lds_kernel_does_not_take_keep_the_parts_own_plan(split_forced
     try:
         assert "density split" in _lib.group_lds_note(hd)
         out = torch.full((n, 256), 3, dtype=torch.int32, device=dev)
-        _lib.block_run(hd, 0, x.data_ptr(), 256, out.data_ptr(), 256, 8, accumulate=False)           # 8 columns: too narrow for the LDS kernel
+        _lib.block_run(hd, 0, x.data_ptr(), 256, out.data_ptr(), 256, 4, accumulate=False)           # 4 columns: too narrow for the LDS kernel (lds_min_width = 5 lanes)
         _lib.block_run(hd, 0, x.data_ptr() + 4 * 64, 256, out.data_ptr() + 4 * 64, 256, 192, accumulate=True)    # accumulating: the part's own plan
         torch.cuda.synchronize()
         runs = _lib.group_lds_runs(hd)
@@ -127,9 +127,9 @@ def test_calls_the_lds_kernel_does_not_take_keep_the_parts_own_plan(split_forced
     full = oracle.spmm_csr(rowptr.cpu().numpy(), col.cpu().numpy(), None, xc)
     got = out.cpu().numpy()
     assert runs == 0
-    assert np.array_equal(got[:, :8], full[:, :8])
+    assert np.array_equal(got[:, :4], full[:, :4])
     assert np.array_equal(got[:, 64:256], full[:, 64:256] + 3)
-    assert np.all(got[:, 8:64] == 3)
+    assert np.all(got[:, 4:64] == 3)
 
 
 def test_split_under_feature_windows(split_forced):
