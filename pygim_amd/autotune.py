@@ -43,7 +43,8 @@ LDS_COL_SPLIT = True        # FLT32 shares of a million entries and more are spl
 LDS_ROW_TAIL = 3            # percent of a share's rows that may stay outside the plan (tunable lds_row_tail)
 TAIL_S = 30e-6              # the two tail kernels
 LDS_MIN_LANES = 5           # narrower products keep the sweep / the SpMV kernels (tunable lds_min_width; 17 until the round's last session)
-LDS_MIN_REUSE_NARROW = 2.5  # products of at most 32 lanes: stored entries per staged column below which the sweep is kept (x 1.6 for a half-split plan, which stages half the columns)
+LDS_MIN_REUSE_NARROW = 0.75 # products of at most 32 lanes: stored entries per staged column below which the sweep is kept (x 1.6 for a half-split plan, which stages half the columns);
+                            # measured: the same crossing as the wide products' (scripts/exp_narrow_rule.py)
 LDS_HALF_SPLIT = True       # products of at most 32 lanes fold two column ranges into the halves of a wave (tunable lds_half_split, on since the device generator writes these plans)
 LDS_MIN_REUSE = 0.75        # stored entries per staged column below which the sweep is kept (pygim_hip.hip lds_min_reuse_x100)
 

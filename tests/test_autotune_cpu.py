@@ -38,8 +38,9 @@ def test_products_too_narrow_for_the_lds_path_keep_the_sweep_price():
     assert autotune.lds_product_seconds(n, n, nnz, 4, 4) is None and autotune.lds_product_seconds(n, n, nnz, 5, 4) is not None
     t4, _ = autotune.product_seconds(n, n, nnz, 4, 4)
     assert t4 > 0
-    # a narrow product weighs the staged columns against fewer gathered bytes per entry: a graph with a fifth of the entries keeps the sweep at 16 features, not at 256
-    assert autotune.lds_product_seconds(n, n, nnz // 5, 16, 4) is None and autotune.lds_product_seconds(n, n, nnz // 5, 256, 4) is not None
+    # a fifth of the entries (0.77 per staged column): the LDS-staged kernel still pays at 16 features as at 256 (measured: 0.26 against 0.38 ms on the sweep); a tenth: neither
+    assert autotune.lds_product_seconds(n, n, nnz // 5, 16, 4) is not None and autotune.lds_product_seconds(n, n, nnz // 5, 256, 4) is not None
+    assert autotune.lds_product_seconds(n, n, nnz // 10, 16, 4) is None and autotune.lds_product_seconds(n, n, nnz // 10, 256, 4) is None
 
 
 def test_eight_ranks_prefer_the_grid_whose_product_is_cheapest():
