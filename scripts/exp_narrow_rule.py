@@ -29,8 +29,8 @@ def timed(hd, x, out, reps=9):
     return a.elapsed_time(b) / reps
 
 
-for h in (16, 32):
-    for div in (1, 2, 3, 5):
+for h in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("16", "32"))]:
+    for div in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("1", "2", "3", "5"))]:
         m = nnz // div
         rowptr, col = synth.make_csr(n, m, max(dmax // div, 64), seed=3, device=dev)
         x = synth.features(n, h, torch.float32, seed=1, device=dev)
